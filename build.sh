@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds webauthn-halo2_amd/libzkmi355.so for gfx950 (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")/webauthn-halo2_amd"
+OUT=libzkmi355.so
+SRCS="csrc/engine.hip csrc/ntt.hip csrc/msm.hip csrc/poly.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+mkdir -p build
+objs=""
+pids=""
+for s in $SRCS; do
+  o=build/$(basename $s .hip).o
+  objs="$objs $o"
+  if [ ! -f $o ] || [ $s -nt $o ] || [ -n "$(find csrc ../include -name '*.h' -newer $o)" ]; then
+    hipcc $FLAGS -c $s -o $o &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
+echo "built $(pwd)/$OUT"

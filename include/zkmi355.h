@@ -1,0 +1,113 @@
+/*
+ * zkmi355.h — C ABI of libzkmi355.so, the MI355X (gfx950) proving engine that
+ * sits behind halo2_proofs::plonk::create_proof for the reference's
+ * secp256r1-ECDSA circuit.
+ *
+ * Every entry point replaces a Rust routine of the (un-vendored) halo2_proofs /
+ * halo2curves crates that the reference reaches from its three create_proof
+ * call sites:
+ *     halo2-circuits/src/ecc/ecdsa_p256.rs:366-373   (EvmTranscript + GWC, /prove_evm)
+ *     halo2-circuits/src/ecc/ecdsa_p256.rs:416-423   (Blake2b + SHPLONK, /prove)
+ *     halo2-circuits/src/ecc/ecdsa_p256.rs:555-562   (bench_secp256r1_ecdsa)
+ * and from keygen at ecdsa_p256.rs:258-260.  The upstream routine replaced is
+ * named on each declaration; INTEGRATION.md shows the Rust `extern "C"` shim.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer, the
+ *     engine never keeps a host pointer past return;
+ *   - memory images are those of the Rust types: Fr / Fq = 4 x u64 little-endian
+ *     limbs in Montgomery form (R = 2^256); G1Affine = x || y (64 B), identity
+ *     (0,0); G1 = Jacobian x || y || z (96 B), identity z = 0;
+ *   - every function returns 0 on success or a negative ZK_E* code, never
+ *     throws; outputs are untouched on error; no CPU fallback exists — a missing
+ *     device is ZK_ENODEV;
+ *   - a zk_ctx is bound to one HIP device and one stream and serialises its
+ *     callers internally; use one context per worker thread / GPU;
+ *   - the engine consumes no randomness: blinding values are
+ *     supplied by the caller.
+ */
+#ifndef ZKMI355_H
+#define ZKMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_EINVAL (-1)   /* bad size / argument / handle */
+#define ZK_ENOMEM (-2)   /* device or host allocation failed */
+#define ZK_EHIP (-3)     /* HIP runtime error (zk_last_hip_error) */
+#define ZK_ENODEV (-4)   /* no usable gfx950 device */
+#define ZK_ESTATE (-5)   /* missing prerequisite (SRS / key not loaded) */
+
+typedef struct zk_ctx zk_ctx;
+typedef uint64_t zk_poly; /* opaque device-resident vector of Fr; 0 is never valid */
+
+#define ZK_BASIS_MONOMIAL 0 /* ParamsKZG::commit          (basis g)          */
+#define ZK_BASIS_LAGRANGE 1 /* ParamsKZG::commit_lagrange (basis g_lagrange) */
+
+/* ---- context ------------------------------------------------------------- */
+int zk_device_count(void);
+int zk_ctx_create(int device_id, zk_ctx** out);
+void zk_ctx_destroy(zk_ctx* ctx);
+const char* zk_strerror(int code);
+int zk_last_hip_error(const zk_ctx* ctx); /* raw hipError_t of the last ZK_EHIP */
+int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
+
+/* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------
+ * replaces halo2_proofs::arithmetic::best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1 */
+int zk_msm_bn254(zk_ctx* ctx, const uint64_t* scalars_mont /* n x 4 */,
+                 const uint64_t* bases_affine_mont /* n x 8 */, size_t n,
+                 uint64_t out_jacobian_mont[12]);
+/* replaces halo2_proofs::arithmetic::best_fft(a: &mut [Fr], omega: Fr, log_n: u32); in place,
+ * natural order in and out */
+int zk_ntt_bn254_fr(zk_ctx* ctx, uint64_t* a_mont /* 2^log_n x 4 */, const uint64_t omega_mont[4],
+                    uint32_t log_n);
+
+/* ---- SRS (ParamsKZG<Bn256>) ----------------------------------------------
+ * replaces ParamsKZG::setup(k, ChaCha20Rng::from_seed(seed)) as run by halo2-base gen_srs(k)
+ * (ecdsa_p256.rs:258,338,388): s = Fr::from_u512(first 64 keystream bytes);
+ * g[i] = [s^i]G1, g_lagrange[i] = [L_i(s)]G1, both generated on the device. */
+int zk_srs_setup(zk_ctx* ctx, uint32_t k, const uint8_t seed[32]);
+/* replaces ParamsKZG::read: adopt caller-supplied bases (n = 2^k points each, affine Montgomery) */
+int zk_srs_load(zk_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange);
+int zk_srs_export(zk_ctx* ctx, int basis, uint64_t* out_affine_mont /* n x 8 */, size_t first, size_t count);
+int zk_srs_k(const zk_ctx* ctx); /* -1 if none */
+
+/* ---- resident polynomials -------------------------------------------------- */
+int zk_poly_alloc(zk_ctx* ctx, size_t n, zk_poly* out);
+int zk_poly_free(zk_ctx* ctx, zk_poly p);
+int zk_poly_len(zk_ctx* ctx, zk_poly p, size_t* out);
+int zk_poly_upload(zk_ctx* ctx, zk_poly p, const uint64_t* host_mont, size_t n);
+int zk_poly_download(zk_ctx* ctx, zk_poly p, uint64_t* host_mont, size_t n);
+int zk_poly_copy(zk_ctx* ctx, zk_poly dst, zk_poly src);
+
+/* replaces ParamsKZG::commit / commit_lagrange (MSM against the resident SRS) + to_affine */
+int zk_commit(zk_ctx* ctx, zk_poly p, int basis, uint64_t out_affine_mont[8]);
+/* replaces EvaluationDomain::lagrange_to_coeff (in place: iNTT, x 1/n) */
+int zk_lagrange_to_coeff(zk_ctx* ctx, zk_poly p);
+/* replaces EvaluationDomain::coeff_to_lagrange (in place) */
+int zk_coeff_to_lagrange(zk_ctx* ctx, zk_poly p);
+/* replaces EvaluationDomain::coeff_to_extended: dst (2^ext_k) = NTT of zero-extended src scaled by zeta^i */
+int zk_coeff_to_extended(zk_ctx* ctx, zk_poly src, zk_poly dst_ext);
+/* replaces EvaluationDomain::extended_to_coeff: in place on a 2^ext_k vector; first n_out coefficients valid */
+int zk_extended_to_coeff(zk_ctx* ctx, zk_poly ext, size_t n_out);
+/* replaces arithmetic::eval_polynomial(poly, x) */
+int zk_eval(zk_ctx* ctx, zk_poly p, const uint64_t x_mont[4], uint64_t out_mont[4]);
+
+/* ---- timing of the last call of each kind, measured with HIP events on the
+ *      context stream (ms); used by bench.py for the roofline figures ---------- */
+#define ZK_T_MSM 0
+#define ZK_T_NTT 1
+#define ZK_T_QUOTIENT 2
+#define ZK_T_EVAL 3
+#define ZK_T_COUNT 8
+int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI355_H */

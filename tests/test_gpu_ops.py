@@ -1,0 +1,233 @@
+"""GPU parity: HIP MSM / NTT / SRS / eval through the C-ABI vs the oracle.
+
+Bit-exact (integer arithmetic; group elements compared after affine
+normalisation, which is canonical).  Sizes the oracle finishes in seconds, plus
+size-independent properties at BASELINE sizes (2^19, 2^21)."""
+import random
+
+import numpy as np
+import pytest
+
+from zkoracle import cops, curve as C, field as F, srs
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr(rng, n):
+    return [rng.randrange(F.R) for _ in range(n)]
+
+
+def mont1(x):
+    return cops.fr_mont([x])[0]
+
+
+# ------------------------------------------------------------------- NTT ----
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 7, 8, 9, 11, 13, 14, 15, 17])
+def test_ntt_matches_oracle(engine, log_n):
+    rng = random.Random(100 + log_n)
+    n = 1 << log_n
+    a = np.frombuffer(np.random.default_rng(log_n).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF  # < 2^252 < r: valid Montgomery residues
+    w = F.omega(log_n)
+    want = cops.ntt(a, w, log_n)
+    got = engine.ntt(a, mont1(w), log_n)
+    assert np.array_equal(got, want)
+    # inverse root takes the reversed-table path
+    wi = F.inv(w, F.R)
+    assert np.array_equal(engine.ntt(a, mont1(wi), log_n), cops.ntt(a, wi, log_n))
+    del rng
+
+
+def test_ntt_nonstandard_omega(engine):
+    # a 2^6-th root used on a 2^6 domain but not the canonical one (odd power): own twiddle table
+    log_n = 6
+    w = pow(F.omega(log_n), 5, F.R)
+    a = cops.fr_mont(rand_fr(random.Random(5), 1 << log_n))
+    assert np.array_equal(engine.ntt(a, mont1(w), log_n), cops.ntt(a, w, log_n))
+
+
+@pytest.mark.parametrize("log_n", [19, 21])
+def test_ntt_roundtrip_large(engine, log_n):
+    n = 1 << log_n
+    a = np.frombuffer(np.random.default_rng(77).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    w = F.omega(log_n)
+    fwd = engine.ntt(a, mont1(w), log_n)
+    # spot-check 3 outputs against the definition via Horner evaluation at w^i (oracle side)
+    ai = cops.fr_ints(a)
+    for i in (0, 1, n - 1):
+        x = pow(w, i, F.R)
+        acc = 0
+        for c in reversed(ai):
+            acc = (acc * x + c) % F.R
+        assert cops.fr_ints(fwd[i:i + 1])[0] == acc
+    back = engine.ntt(fwd, mont1(F.inv(w, F.R)), log_n)
+    ninv = cops.fr_mont([F.inv(n, F.R)])
+    # back = n * a  ->  compare a few hundred entries exactly, and all via linear check
+    bi = cops.fr_ints(back[:256])
+    assert [x * F.inv(n, F.R) % F.R for x in bi] == ai[:256]
+    p = engine.poly(n, fwd)
+    engine.lagrange_to_coeff(p)  # fused 1/n
+    assert np.array_equal(engine.download(p), a)
+    p.free()
+    del ninv
+
+
+# ------------------------------------------------------------------- MSM ----
+
+def small_srs(n):
+    return cops.fixed_base_g1(cops.fr_powers(srs.TAU, n))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 100, 1000, 4096, 5000, 1 << 14])
+def test_msm_matches_oracle(engine, n):
+    rng = random.Random(n)
+    g = small_srs(max(n, 1))[:n]
+    s = rand_fr(rng, n)
+    if n >= 17:
+        s[0] = 0
+        s[1] = 1
+        s[2] = F.R - 1
+        s[3] = 2
+        s[4] = (1 << 128) - 1
+        s[5] = 1 << 253
+    sm = cops.fr_mont(s) if n else np.zeros((0, 4), dtype=np.uint64)
+    got = cops.jac_to_affine_ints(engine.msm(sm, g))
+    want = cops.jac_to_affine_ints(cops.msm(sm, g)) if n else None
+    assert got == want
+
+
+def test_msm_edge_bases(engine):
+    """identity bases, repeated bases (doubling path), P and -P (cancellation)."""
+    rng = random.Random(99)
+    n = 2048
+    g = small_srs(n)
+    g[10] = 0  # identity
+    g[11] = 0
+    g[20] = g[21]  # same point twice
+    g[22] = g[21]
+    neg = cops.affine_arr_to_ints(g[30:31])[0]
+    negp = cops.to_mont_arr(cops.ints_to_arr([neg[0], (-neg[1]) % F.P]), 1).reshape(8)
+    g[31] = negp  # g[31] = -g[30]
+    s = rand_fr(rng, n)
+    s[20] = s[21] = s[22] = 5  # equal scalars on equal points -> same bucket -> doubling
+    s[30] = s[31] = 7  # P and -P in one bucket -> identity
+    sm = cops.fr_mont(s)
+    assert cops.jac_to_affine_ints(engine.msm(sm, g)) == cops.jac_to_affine_ints(cops.msm(sm, g))
+    # all-zero scalars -> identity
+    z = np.zeros((n, 4), dtype=np.uint64)
+    assert cops.jac_to_affine_ints(engine.msm(z, g)) is None
+    # all scalars equal one -> sum of points
+    ones = cops.fr_mont([1] * n)
+    assert cops.jac_to_affine_ints(engine.msm(ones, g)) == cops.jac_to_affine_ints(cops.msm(ones, g))
+
+
+def test_msm_witness_like_distribution(engine):
+    """Hot low buckets: the mix SURVEY.md §8d prescribes for advice columns."""
+    rng = random.Random(0x5EED0019)
+    n = 1 << 15
+    g = small_srs(n)
+    s = []
+    for _ in range(n):
+        u = rng.random()
+        if u < 0.40:
+            s.append(rng.randrange(1 << 18))
+        elif u < 0.75:
+            s.append(rng.randrange(1 << 88))
+        elif u < 0.90:
+            s.append(rng.randrange(F.R))
+        else:
+            s.append(0)
+    sm = cops.fr_mont(s)
+    assert cops.jac_to_affine_ints(engine.msm(sm, g)) == cops.jac_to_affine_ints(cops.msm(sm, g))
+    b = cops.fr_mont([rng.randrange(2) for _ in range(n)])  # boolean column: one giant bucket
+    assert cops.jac_to_affine_ints(engine.msm(b, g)) == cops.jac_to_affine_ints(cops.msm(b, g))
+
+
+# ------------------------------------------------------------- SRS / commit ---
+
+def test_srs_setup_matches_reference_known_answers(engine):
+    k = 17
+    n = 1 << k
+    engine.srs_setup(k)  # seed [0;32] = gen_srs
+    g = cops.affine_arr_to_ints(engine.srs_export(0, 0, 4))
+    assert g[0] == C.G1_GEN  # reference P256Verifier.yul:777-778
+    assert g[1] == C.mul(C.G1_GEN, srs.TAU)
+    assert g[3] == C.mul(C.G1_GEN, pow(srs.TAU, 3, F.R))
+    last = cops.affine_arr_to_ints(engine.srs_export(0, n - 1, 1))[0]
+    assert last == C.mul(C.G1_GEN, pow(srs.TAU, n - 1, F.R))
+    lag = srs.lagrange_at(k, srs.TAU)
+    gl = cops.affine_arr_to_ints(engine.srs_export(1, 0, 2)) + cops.affine_arr_to_ints(engine.srs_export(1, n - 2, 2))
+    for pt, i in zip(gl, (0, 1, n - 2, n - 1)):
+        assert pt == C.mul(C.G1_GEN, lag[i])
+    # K2: commit_lagrange(range table 0..2^16-1) == fixed-column commitment of the reference's
+    # k=17 verifying key, proving-server/P256Verifier.yul:889-890
+    table = cops.fr_mont(list(range(1 << 16)) + [0] * (n - (1 << 16)))
+    p = engine.poly(n, table)
+    c = cops.affine_arr_to_ints(engine.commit(p, 1))[0]
+    assert c == (
+        0x2F579160607CC547A54EF72E5A1A2966A65305C955CF8D94F507169386A10F4C,
+        0x15932D491AAAA6D3673EEB19941A96EE53B011A6923028A70466A155B753D46B,
+    )
+    # commit(iNTT(v)) == commit_lagrange(v)
+    engine.lagrange_to_coeff(p)
+    assert cops.affine_arr_to_ints(engine.commit(p, 0))[0] == c
+    p.free()
+
+
+def test_commit_tau_oracle_k19(engine):
+    """MSM(s, SRS) == [sum s_i tau^i] G1 at the BASELINE size 2^19 (any-n oracle)."""
+    k = 19
+    n = 1 << k
+    engine.srs_setup(k)
+    a = np.frombuffer(np.random.default_rng(0x5EED0019).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    p = engine.poly(n, a)
+    got = cops.affine_arr_to_ints(engine.commit(p, 0))[0]
+    want = srs.g1_of_scalar(srs.commit_scalar_monomial(cops.fr_ints(a)))
+    assert got == want
+    # and through the fine-grained seam with bases exported back to the host
+    bases = engine.srs_export(0, 0, n)
+    assert cops.jac_to_affine_ints(engine.msm(a, bases)) == want
+    p.free()
+
+
+# ------------------------------------------------------------ eval / coset ----
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 4096, 70000])
+def test_eval_matches_horner(engine, n):
+    rng = random.Random(n)
+    c = rand_fr(rng, n)
+    x = rng.randrange(F.R)
+    p = engine.poly(n, cops.fr_mont(c))
+    got = cops.fr_ints(engine.eval(p, mont1(x)).reshape(1, 4))[0]
+    acc = 0
+    for ci in reversed(c):
+        acc = (acc * x + ci) % F.R
+    assert got == acc
+    p.free()
+
+
+@pytest.mark.parametrize("k", [4, 9, 12])
+def test_coset_extended_domain(engine, k):
+    """coeff_to_extended: ext[i] = f(zeta * w_ext^i); extended_to_coeff inverts it."""
+    rng = random.Random(k)
+    n, ext = 1 << k, 1 << (k + 2)
+    f = rand_fr(rng, n)
+    src = engine.poly(n, cops.fr_mont(f))
+    dst = engine.poly(ext)
+    engine.coeff_to_extended(src, dst)
+    got = cops.fr_ints(engine.download(dst))
+    wext = F.omega(k + 2)
+    for i in (0, 1, 2, 3, ext // 2 + 1, ext - 1):
+        x = F.ZETA * pow(wext, i, F.R) % F.R
+        acc = 0
+        for c in reversed(f):
+            acc = (acc * x + c) % F.R
+        assert got[i] == acc
+    engine.extended_to_coeff(dst, ext)
+    back = cops.fr_ints(engine.download(dst))
+    assert back[:n] == f and all(v == 0 for v in back[n:])
+    src.free()
+    dst.free()

@@ -1,0 +1,98 @@
+"""Pins the oracle to the reference's own artefacts
+and checks the C restatement against the Python one.  CPU only."""
+import random
+
+import numpy as np
+
+from zkoracle import cops, curve as C, field as F, srs
+
+
+def test_k1_tau_and_s_g2():
+    # tau = Fr::from_u512(ChaCha20(seed 0) first 64 bytes)  
+    assert srs.TAU == 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA
+    sg2 = C.g2_mul(C.G2_GEN, srs.TAU)
+    # reference proving-server/P256Verifier.yul:1131-1134 holds -[tau]G2 as (x.c1, x.c0, y.c1, y.c0)
+    assert sg2[0][1] == 0x0181624E80F3D6AE28DF7E01EAEAB1C0E919877A3B8A6B7FBC69A6817D596EA2
+    assert sg2[0][0] == 0x1783D30DCB12D259BB89098ADDF6280FA4B653BE7A152542A28F7B926E27E648
+    assert (-sg2[1][1]) % F.P == 0x00AE44489D41A0D179E2DFDC03BDDD883B7109F8B6AE316A59E815C1A6B35304
+    assert (-sg2[1][0]) % F.P == 0x0B2147AB62A386BD63E6DE1522109B8C9588AB466F5AADFDE8C41CA3749423EE
+
+
+def test_k4_domain_constants():
+    # reference proving-server/P256Verifier.yul:767 (omega_17), :307 (n^-1), :465 (delta)
+    assert F.omega(17) == 21846745818185811051373434299876022191132089169516983080959277716660228899818
+    assert F.inv(1 << 17, F.R) == 21888075877798810139885396174900942254113179552665176677420557563313886988289
+    assert F.DELTA == 4131629893567559867359510883348571134090853742863529169391034518566172092834
+    assert F.ROOT_OF_UNITY == 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+    # omega^-7 * ... : Lagrange numerators at yul:308-323 use omega^{-7..0}
+    assert pow(F.omega(17), -7, F.R) == 21180393220728113421338195116216869725258066600961496947533653125588029756005
+    assert pow(F.ZETA, 3, F.R) == 1 and F.ZETA != 1
+
+
+def test_k2_table_column_commitment():
+    # fixed column #1 of the k=17 vk = range table 0..2^16-1: reference P256Verifier.yul:889-890
+    lag = srs.lagrange_at(17, srs.TAU)
+    s = sum(i * lag[i] for i in range(1 << 16)) % F.R
+    assert srs.g1_of_scalar(s) == (
+        0x2F579160607CC547A54EF72E5A1A2966A65305C955CF8D94F507169386A10F4C,
+        0x15932D491AAAA6D3673EEB19941A96EE53B011A6923028A70466A155B753D46B,
+    )
+
+
+def test_c_field_roundtrip_and_mul():
+    rng = random.Random(7)
+    a = [rng.randrange(F.R) for _ in range(64)] + [0, 1, F.R - 1]
+    am = cops.fr_mont(a)
+    assert cops.fr_ints(am) == a
+    assert cops.arr_to_ints(am) == [x * F.MONT_R % F.R for x in a]
+
+
+def test_c_msm_matches_tau_oracle_and_python():
+    rng = random.Random(11)
+    k = 9
+    n = 1 << k
+    g = cops.fixed_base_g1(cops.fr_powers(srs.TAU, n))
+    pts = cops.affine_arr_to_ints(g)
+    assert pts[0] == C.G1_GEN and pts[5] == C.mul(C.G1_GEN, pow(srs.TAU, 5, F.R))
+    s = [rng.randrange(F.R) for _ in range(n)]
+    s[3] = 0
+    s[4] = 1
+    s[5] = F.R - 1
+    want = srs.g1_of_scalar(srs.commit_scalar_monomial(s))
+    for threads in (1, 3, 8):
+        assert cops.jac_to_affine_ints(cops.msm(cops.fr_mont(s), g, threads)) == want
+    # tiny sizes take halo2's c = 1 / c = 3 branches
+    for m in (1, 2, 3, 5, 31, 33):
+        want = C.msm_naive(s[:m], pts[:m])
+        assert cops.jac_to_affine_ints(cops.msm(cops.fr_mont(s[:m]), g[:m], 1)) == want
+
+
+def test_c_ntt_matches_definition():
+    rng = random.Random(13)
+    for k in (1, 2, 5, 8):
+        n = 1 << k
+        w = F.omega(k)
+        a = [rng.randrange(F.R) for _ in range(n)]
+        out = cops.fr_ints(cops.ntt(cops.fr_mont(a), w, k, 2))
+        for i in range(n):
+            assert out[i] == sum(a[j] * pow(w, i * j, F.R) for j in range(n)) % F.R
+    # inverse: NTT with w^-1 then / n
+    k = 10
+    n = 1 << k
+    a = [rng.randrange(F.R) for _ in range(n)]
+    fwd = cops.ntt(cops.fr_mont(a), F.omega(k), k)
+    back = cops.fr_ints(cops.ntt(fwd, F.inv(F.omega(k), F.R), k))
+    ninv = F.inv(n, F.R)
+    assert [x * ninv % F.R for x in back] == a
+
+
+def test_commit_identity_intt_vs_lagrange():
+    # commit(iNTT(v)) == commit_lagrange(v): ties NTT ordering to the SRS's Lagrange basis
+    rng = random.Random(17)
+    k = 6
+    n = 1 << k
+    v = [rng.randrange(F.R) for _ in range(n)]
+    coeff = cops.fr_ints(cops.ntt(cops.fr_mont(v), F.inv(F.omega(k), F.R), k))
+    ninv = F.inv(n, F.R)
+    coeff = [c * ninv % F.R for c in coeff]
+    assert srs.commit_scalar_monomial(coeff) == srs.commit_scalar_lagrange(k, v)

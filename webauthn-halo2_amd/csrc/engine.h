@@ -1,0 +1,51 @@
+// engine.h — internal declarations shared by the HIP translation units of
+// libzkmi355.so (not part of the public C-ABI; that is include/zkmi355.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ec.hip.h"
+#include "field.hip.h"
+
+namespace zk {
+
+// ---- NTT (ntt.hip) ---------------------------------------------------------
+struct NttJob {
+    const Fr* src;      // n_in elements (rest of the 2^log_n vector is zero)
+    Fr* dst;            // 2^log_n elements (n_out stored)
+    Fr* tmp;            // 2^log_n scratch (required when more than one pass, or src == dst)
+    const Fr* tw;       // twiddle table w^i, i < 2^log_n
+    uint32_t log_n;
+    uint32_t inverse;   // use w^-1
+    uint32_t n_in, n_out;
+    uint32_t has_pre, has_post;
+    Fr pre[3], post[3]; // period-3 scale factors by index (coset zeta powers, 1/N)
+    uint32_t max_log_r; // 0 = default
+};
+hipError_t ntt_run(const NttJob& job, hipStream_t st);
+void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);
+int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
+
+// ---- MSM (msm.hip) ---------------------------------------------------------
+struct MsmWorkspace;  // opaque, sized for a maximum n
+struct MsmConfig {
+    uint32_t c;        // window bits (signed digits), 0 = auto
+    uint32_t seg_len;  // entries per accumulate thread, 0 = default
+};
+size_t msm_workspace_bytes(size_t max_n, uint32_t c);
+MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err);
+void msm_workspace_destroy(MsmWorkspace* ws);
+uint32_t msm_auto_window(size_t n);
+// Launches the whole device pipeline on `st`; window sums (XYZZ) land in
+// ws->window_sums (device) and are copied to `host_window_sums` (pinned or
+// pageable, nwin * 128 B) asynchronously.  Returns the number of windows.
+hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
+                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out);
+// Host-side finish: Horner over windows -> Jacobian (Montgomery).
+G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
+
+// ---- host helpers (hostmath.cpp) --------------------------------------------
+G1Affine g1_jac_to_affine_host(const G1Jac& p);
+
+}  // namespace zk

@@ -1,0 +1,671 @@
+// engine.hip — context, device memory and the C ABI of libzkmi355.so
+// (declarations and the reference routines each entry point replaces:
+// include/zkmi355.h).
+#include "../../include/zkmi355.h"
+
+#include <map>
+#include <mutex>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "engine.h"
+#include "hostutil.h"
+
+namespace zk {
+// poly.hip
+uint32_t eval_blocks(uint32_t n);
+void launch_eval(const Fr* c, uint32_t n, const Fr& x, Fr* scratch, hipStream_t st);
+void launch_srs_lagrange_scalars(const Fr* tw, uint32_t n, const Fr& s, const Fr& c, Fr* out, hipStream_t st);
+void launch_srs_fixed_base(const Fr* scalars, uint32_t n, const G1Affine* table, G1Affine* out, hipStream_t st);
+
+G1Affine g1_jac_to_affine_host(const G1Jac& p) {
+    G1Affine r;
+    if (p.z.is_zero()) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+        return r;
+    }
+    const Fq zi = fe_inv(p.z);
+    const Fq zi2 = fe_sqr(zi);
+    r.x = fe_mul(p.x, zi2);
+    r.y = fe_mul(p.y, fe_mul(zi2, zi));
+    return r;
+}
+}  // namespace zk
+
+using namespace zk;
+
+struct PolyRec {
+    Fr* ptr;
+    size_t n;
+};
+
+struct zk_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    std::mutex mu;
+    std::map<uint32_t, Fr*> twiddles;  // log_n -> w_{2^log_n}^i table
+    // SRS
+    int srs_k = -1;
+    G1Affine* g = nullptr;
+    G1Affine* g_lagrange = nullptr;
+    // MSM
+    MsmWorkspace* msm_ws = nullptr;
+    G1X* host_wsum = nullptr;  // pinned
+    // scratch
+    Fr* scratch = nullptr;
+    size_t scratch_n = 0;
+    Fr* small = nullptr;  // 2048 + 8 elements for reductions
+    Fr* host_small = nullptr;  // pinned, 8 elements
+    // polys
+    std::unordered_map<uint64_t, PolyRec> polys;
+    uint64_t next_handle = 1;
+    // constants
+    Fr zeta, zeta2;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms[ZK_T_COUNT] = {0};
+};
+
+#define HIPCHK(ctx, x)                 \
+    do {                               \
+        hipError_t _e = (x);           \
+        if (_e != hipSuccess) {        \
+            (ctx)->last_hip = (int)_e; \
+            return ZK_EHIP;            \
+        }                              \
+    } while (0)
+
+static int bind(zk_ctx* c) {
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        return ZK_EHIP;
+    }
+    return ZK_OK;
+}
+
+static int ensure_scratch(zk_ctx* c, size_t n) {
+    if (c->scratch_n >= n) return ZK_OK;
+    if (c->scratch) hipFree(c->scratch);
+    c->scratch = nullptr;
+    c->scratch_n = 0;
+    hipError_t e = hipMalloc(&c->scratch, n * sizeof(Fr));
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        return ZK_ENOMEM;
+    }
+    c->scratch_n = n;
+    return ZK_OK;
+}
+
+static int get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
+    auto it = c->twiddles.find(log_n);
+    if (it != c->twiddles.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    if (log_n > 28) return ZK_EINVAL;
+    Fr* tw = nullptr;
+    const size_t n = (size_t)1 << log_n;
+    if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    launch_twiddles(tw, fr_omega(log_n), (uint32_t)n, c->stream);
+    c->twiddles[log_n] = tw;
+    *out = tw;
+    return ZK_OK;
+}
+
+namespace zk {
+size_t msm_ws_max_n(const MsmWorkspace* ws);
+}
+
+static int get_msm_ws(zk_ctx* c, size_t n, MsmWorkspace** out) {
+    size_t want = 1;
+    while (want < n) want <<= 1;
+    if (want < 1024) want = 1024;
+    if (c->msm_ws && msm_ws_max_n(c->msm_ws) != want) {
+        msm_workspace_destroy(c->msm_ws);
+        c->msm_ws = nullptr;
+    }
+    if (!c->msm_ws) {
+        hipError_t e;
+        c->msm_ws = msm_workspace_create(want, 0, &e);
+        if (!c->msm_ws) {
+            c->last_hip = (int)e;
+            return e == hipErrorInvalidValue ? ZK_EINVAL : ZK_ENOMEM;
+        }
+    }
+    *out = c->msm_ws;
+    return ZK_OK;
+}
+
+// MSM of device-resident scalars against device-resident bases -> Jacobian on host
+static int msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out) {
+    MsmWorkspace* ws;
+    int rc = get_msm_ws(c, n, &ws);
+    if (rc) return rc;
+    uint32_t nwin = 0, cw = 0;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, msm_run(ws, d_scalars, d_bases, n, c->stream, c->host_wsum, &nwin, &cw));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipEventElapsedTime(&c->last_ms[ZK_T_MSM], c->ev0, c->ev1);
+    *out = msm_finish_host(c->host_wsum, nwin, cw);
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------ C ABI --
+
+extern "C" {
+
+int zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* zk_strerror(int code) {
+    switch (code) {
+        case ZK_OK: return "ok";
+        case ZK_EINVAL: return "invalid argument";
+        case ZK_ENOMEM: return "out of memory";
+        case ZK_EHIP: return "HIP runtime error";
+        case ZK_ENODEV: return "no usable gfx950 device";
+        case ZK_ESTATE: return "missing prerequisite (SRS / key not loaded)";
+        default: return "unknown error";
+    }
+}
+
+int zk_ctx_create(int device_id, zk_ctx** out) {
+    if (!out) return ZK_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ENODEV;
+    if (device_id < 0 || device_id >= ndev) return ZK_EINVAL;
+    zk_ctx* c = new (std::nothrow) zk_ctx();
+    if (!c) return ZK_ENOMEM;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipHostMalloc(&c->host_wsum, 64 * sizeof(G1X)) != hipSuccess ||
+        hipHostMalloc(&c->host_small, 8 * sizeof(Fr)) != hipSuccess ||
+        hipMalloc(&c->small, (2048 + 8) * sizeof(Fr)) != hipSuccess) {
+        zk_ctx_destroy(c);
+        return ZK_EHIP;
+    }
+    c->zeta = fr_zeta();
+    c->zeta2 = fe_sqr(c->zeta);
+    *out = c;
+    return ZK_OK;
+}
+
+void zk_ctx_destroy(zk_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& kv : c->twiddles) hipFree(kv.second);
+    for (auto& kv : c->polys) hipFree(kv.second.ptr);
+    if (c->g) hipFree(c->g);
+    if (c->g_lagrange) hipFree(c->g_lagrange);
+    if (c->msm_ws) msm_workspace_destroy(c->msm_ws);
+    if (c->host_wsum) hipHostFree(c->host_wsum);
+    if (c->host_small) hipHostFree(c->host_small);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->small) hipFree(c->small);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int zk_last_hip_error(const zk_ctx* c) { return c ? c->last_hip : 0; }
+
+int zk_sync(zk_ctx* c) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
+    if (!c || !out_ms || which < 0 || which >= ZK_T_COUNT) return ZK_EINVAL;
+    *out_ms = c->last_ms[which];
+    return ZK_OK;
+}
+
+// ---- fine-grained seam -------------------------------------------------------
+
+int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out[12]) {
+    if (!c || !out || (n && (!scalars || !bases))) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = bind(c);
+    if (rc) return rc;
+    G1Jac res;
+    if (n == 0) {
+        res.x = Fq::one();
+        res.y = Fq::one();
+        res.z = Fq::zero();
+        memcpy(out, &res, 96);
+        return ZK_OK;
+    }
+    Fr* d_s = nullptr;
+    G1Affine* d_b = nullptr;
+    if (hipMalloc(&d_s, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    if (hipMalloc(&d_b, n * sizeof(G1Affine)) != hipSuccess) {
+        hipFree(d_s);
+        return ZK_ENOMEM;
+    }
+    rc = ZK_OK;
+    if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = ZK_EHIP;
+    if (rc == ZK_OK) rc = msm_device(c, d_s, d_b, n, &res);
+    hipStreamSynchronize(c->stream);
+    hipFree(d_s);
+    hipFree(d_b);
+    if (rc == ZK_OK) memcpy(out, &res, 96);
+    return rc;
+}
+
+int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+    if (!c || !a || !omega || log_n > 26) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = bind(c);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log_n;
+    Fr w;
+    memcpy(&w, omega, 32);
+    // the standard root or its inverse use the cached table; anything else gets a one-off table
+    const Fr std_w = fr_omega(log_n);
+    const Fr* tw = nullptr;
+    Fr* own_tw = nullptr;
+    uint32_t inverse = 0;
+    if (w == std_w) {
+        rc = get_twiddles(c, log_n, &tw);
+    } else if (fe_mul(w, std_w) == Fr::one()) {
+        rc = get_twiddles(c, log_n, &tw);
+        inverse = 1;
+    } else {
+        if (hipMalloc(&own_tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+        launch_twiddles(own_tw, w, (uint32_t)n, c->stream);
+        tw = own_tw;
+    }
+    if (rc) return rc;
+    Fr *d_a = nullptr, *d_t = nullptr;
+    if (hipMalloc(&d_a, n * sizeof(Fr)) != hipSuccess || hipMalloc(&d_t, n * sizeof(Fr)) != hipSuccess) {
+        hipFree(d_a);
+        hipFree(own_tw);
+        return ZK_ENOMEM;
+    }
+    rc = ZK_OK;
+    NttJob job;
+    memset(&job, 0, sizeof(job));
+    job.src = d_a;
+    job.dst = d_a;
+    job.tmp = d_t;
+    job.tw = tw;
+    job.log_n = log_n;
+    job.inverse = inverse;
+    job.n_in = job.n_out = (uint32_t)n;
+    if (hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
+    if (rc == ZK_OK) {
+        hipEventRecord(c->ev0, c->stream);
+        hipError_t e = ntt_run(job, c->stream);
+        hipEventRecord(c->ev1, c->stream);
+        if (e != hipSuccess) {
+            c->last_hip = (int)e;
+            rc = ZK_EHIP;
+        }
+    }
+    std::vector<uint64_t> tmp;
+    if (rc == ZK_OK) {
+        // stage through a temporary so the caller's buffer is untouched on error
+        tmp.resize(n * 4);
+        if (hipMemcpyAsync(tmp.data(), d_a, n * sizeof(Fr), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = ZK_EHIP;
+    }
+    hipStreamSynchronize(c->stream);
+    if (rc == ZK_OK) {
+        hipEventElapsedTime(&c->last_ms[ZK_T_NTT], c->ev0, c->ev1);
+        memcpy(a, tmp.data(), n * sizeof(Fr));
+    }
+    hipFree(d_a);
+    hipFree(d_t);
+    hipFree(own_tw);
+    return rc;
+}
+
+// ---- SRS ---------------------------------------------------------------------
+
+static int srs_alloc(zk_ctx* c, uint32_t k) {
+    if (k < 1 || k > 24) return ZK_EINVAL;
+    const size_t n = (size_t)1 << k;
+    if (c->g) hipFree(c->g);
+    if (c->g_lagrange) hipFree(c->g_lagrange);
+    c->g = c->g_lagrange = nullptr;
+    c->srs_k = -1;
+    if (hipMalloc(&c->g, n * sizeof(G1Affine)) != hipSuccess || hipMalloc(&c->g_lagrange, n * sizeof(G1Affine)) != hipSuccess)
+        return ZK_ENOMEM;
+    return ZK_OK;
+}
+
+int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
+    if (!c || !seed) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
+    const uint32_t n = 1u << k;
+    ChaCha20Rng rng(seed);
+    const Fr s = rng.next_fr();
+    // window-8 table of the generator on the host: table[w*256 + d] = [d * 256^w] G1
+    std::vector<G1Affine> table(32 * 256);
+    {
+        std::vector<G1X> acc(32 * 256);
+        G1X base;
+        base.x = Fq::one();
+        base.y = fe_add(Fq::one(), Fq::one());
+        base.zz = Fq::one();
+        base.zzz = Fq::one();
+        for (int w = 0; w < 32; w++) {
+            G1X cur = G1X::identity();
+            acc[w * 256] = cur;
+            for (int d = 1; d < 256; d++) {
+                g1x_add(cur, base);
+                acc[w * 256 + d] = cur;
+            }
+            g1x_add(cur, base);
+            base = cur;
+        }
+        // batch normalisation: invert all ZZZ at once
+        std::vector<Fq> pref(acc.size() + 1);
+        pref[0] = Fq::one();
+        for (size_t i = 0; i < acc.size(); i++) pref[i + 1] = acc[i].is_identity() ? pref[i] : fe_mul(pref[i], acc[i].zzz);
+        Fq inv = fe_inv(pref[acc.size()]);
+        for (size_t i = acc.size(); i-- > 0;) {
+            if (acc[i].is_identity()) {
+                table[i].x = Fq::zero();
+                table[i].y = Fq::zero();
+                continue;
+            }
+            const Fq t = fe_mul(inv, pref[i]);
+            inv = fe_mul(inv, acc[i].zzz);
+            const Fq u = fe_mul(acc[i].zz, t);
+            table[i].x = fe_mul(acc[i].x, fe_sqr(u));
+            table[i].y = fe_mul(acc[i].y, t);
+        }
+    }
+    G1Affine* d_table = nullptr;
+    Fr* d_sc = nullptr;
+    if (hipMalloc(&d_table, table.size() * sizeof(G1Affine)) != hipSuccess || hipMalloc(&d_sc, (size_t)n * sizeof(Fr)) != hipSuccess) {
+        hipFree(d_table);
+        return ZK_ENOMEM;
+    }
+    rc = ZK_OK;
+    const Fr* tw = nullptr;
+    if (hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
+    if (rc == ZK_OK) rc = get_twiddles(c, k, &tw);
+    if (rc == ZK_OK) {
+        // g[i] = [s^i] G
+        launch_twiddles(d_sc, s, n, c->stream);
+        launch_srs_fixed_base(d_sc, n, d_table, c->g, c->stream);
+        // g_lagrange[i] = [L_i(s)] G,  L_i(s) = w^i (s^n - 1) / (n (s - w^i))
+        Fr sn = s;
+        for (uint32_t i = 0; i < k; i++) sn = fe_sqr(sn);
+        const Fr cst = fe_mul(fe_sub(sn, Fr::one()), fe_inv(fr_from_u64(n)));
+        launch_srs_lagrange_scalars(tw, n, s, cst, d_sc, c->stream);
+        launch_srs_fixed_base(d_sc, n, d_table, c->g_lagrange, c->stream);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            c->last_hip = (int)e;
+            rc = ZK_EHIP;
+        }
+    }
+    hipFree(d_table);
+    hipFree(d_sc);
+    if (rc == ZK_OK) c->srs_k = (int)k;
+    return rc;
+}
+
+int zk_srs_load(zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl) {
+    if (!c || !g || !gl) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
+    const size_t bytes = ((size_t)1 << k) * sizeof(G1Affine);
+    HIPCHK(c, hipMemcpy(c->g, g, bytes, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->g_lagrange, gl, bytes, hipMemcpyHostToDevice));
+    c->srs_k = (int)k;
+    return ZK_OK;
+}
+
+int zk_srs_export(zk_ctx* c, int basis, uint64_t* out, size_t first, size_t count) {
+    if (!c || !out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->srs_k < 0) return ZK_ESTATE;
+    const size_t n = (size_t)1 << c->srs_k;
+    if (first > n || count > n - first) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    const G1Affine* src = basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g;
+    HIPCHK(c, hipMemcpy(out, src + first, count * sizeof(G1Affine), hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+
+int zk_srs_k(const zk_ctx* c) { return c ? c->srs_k : -1; }
+
+// ---- resident polynomials ----------------------------------------------------
+
+static PolyRec* find_poly(zk_ctx* c, zk_poly h) {
+    auto it = c->polys.find(h);
+    return it == c->polys.end() ? nullptr : &it->second;
+}
+
+int zk_poly_alloc(zk_ctx* c, size_t n, zk_poly* out) {
+    if (!c || !out || n == 0) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = bind(c);
+    if (rc) return rc;
+    Fr* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    const uint64_t h = c->next_handle++;
+    c->polys[h] = PolyRec{p, n};
+    *out = h;
+    return ZK_OK;
+}
+
+int zk_poly_free(zk_ctx* c, zk_poly h) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r) return ZK_EINVAL;
+    bind(c);
+    hipStreamSynchronize(c->stream);
+    hipFree(r->ptr);
+    c->polys.erase(h);
+    return ZK_OK;
+}
+
+int zk_poly_len(zk_ctx* c, zk_poly h, size_t* out) {
+    if (!c || !out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r) return ZK_EINVAL;
+    *out = r->n;
+    return ZK_OK;
+}
+
+int zk_poly_upload(zk_ctx* c, zk_poly h, const uint64_t* host, size_t n) {
+    if (!c || !host) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r || n > r->n) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(r->ptr, host, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+    if (n < r->n) HIPCHK(c, hipMemsetAsync(r->ptr + n, 0, (r->n - n) * sizeof(Fr), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_poly_download(zk_ctx* c, zk_poly h, uint64_t* host, size_t n) {
+    if (!c || !host) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r || n > r->n) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(host, r->ptr, n * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_poly_copy(zk_ctx* c, zk_poly dst, zk_poly src) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec *d = find_poly(c, dst), *s = find_poly(c, src);
+    if (!d || !s || d->n < s->n) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(d->ptr, s->ptr, s->n * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
+    if (d->n > s->n) HIPCHK(c, hipMemsetAsync(d->ptr + s->n, 0, (d->n - s->n) * sizeof(Fr), c->stream));
+    return ZK_OK;
+}
+
+int zk_commit(zk_ctx* c, zk_poly h, int basis, uint64_t out[8]) {
+    if (!c || !out || (basis != ZK_BASIS_MONOMIAL && basis != ZK_BASIS_LAGRANGE)) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->srs_k < 0) return ZK_ESTATE;
+    PolyRec* r = find_poly(c, h);
+    const size_t n = (size_t)1 << c->srs_k;
+    if (!r || r->n > n) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    G1Jac j;
+    rc = msm_device(c, r->ptr, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, r->n, &j);
+    if (rc) return rc;
+    const G1Affine a = g1_jac_to_affine_host(j);
+    memcpy(out, &a, 64);
+    return ZK_OK;
+}
+
+static int ntt_resident(zk_ctx* c, PolyRec* src, PolyRec* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
+    const size_t N = (size_t)1 << log_n;
+    int rc = ensure_scratch(c, N);
+    if (rc) return rc;
+    const Fr* tw;
+    if ((rc = get_twiddles(c, log_n, &tw)) != ZK_OK) return rc;
+    NttJob job;
+    memset(&job, 0, sizeof(job));
+    job.src = src->ptr;
+    job.dst = dst->ptr;
+    job.tmp = c->scratch;
+    job.tw = tw;
+    job.log_n = log_n;
+    job.inverse = inverse ? 1 : 0;
+    job.n_in = (uint32_t)(src->n < N ? src->n : N);
+    job.n_out = (uint32_t)n_out;
+    if (!inverse && coset) {  // coeff_to_extended: a_i *= zeta^(i mod 3)
+        job.has_pre = 1;
+        job.pre[0] = Fr::one();
+        job.pre[1] = c->zeta;
+        job.pre[2] = c->zeta2;
+    }
+    if (inverse) {  // x 1/N, and for the coset also zeta^-(i mod 3) = {1, zeta^2, zeta}
+        const Fr ninv = fe_inv(fr_from_u64(N));
+        job.has_post = 1;
+        job.post[0] = ninv;
+        job.post[1] = coset ? fe_mul(ninv, c->zeta2) : ninv;
+        job.post[2] = coset ? fe_mul(ninv, c->zeta) : ninv;
+    }
+    hipEventRecord(c->ev0, c->stream);
+    hipError_t e = ntt_run(job, c->stream);
+    hipEventRecord(c->ev1, c->stream);
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        return ZK_EHIP;
+    }
+    return ZK_OK;
+}
+
+static uint32_t log2_exact(size_t n) {
+    uint32_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return ((size_t)1 << l) == n ? l : 0xffffffffu;
+}
+
+int zk_lagrange_to_coeff(zk_ctx* c, zk_poly h) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r) return ZK_EINVAL;
+    const uint32_t lg = log2_exact(r->n);
+    if (lg > 26) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    return ntt_resident(c, r, r, lg, true, false, r->n);
+}
+
+int zk_coeff_to_lagrange(zk_ctx* c, zk_poly h) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r) return ZK_EINVAL;
+    const uint32_t lg = log2_exact(r->n);
+    if (lg > 26) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    return ntt_resident(c, r, r, lg, false, false, r->n);
+}
+
+int zk_coeff_to_extended(zk_ctx* c, zk_poly src, zk_poly dst) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec *s = find_poly(c, src), *d = find_poly(c, dst);
+    if (!s || !d || s == d) return ZK_EINVAL;
+    const uint32_t lg = log2_exact(d->n);
+    if (lg > 26 || s->n > d->n) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    return ntt_resident(c, s, d, lg, false, true, d->n);
+}
+
+int zk_extended_to_coeff(zk_ctx* c, zk_poly ext, size_t n_out) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, ext);
+    if (!r || n_out > r->n) return ZK_EINVAL;
+    const uint32_t lg = log2_exact(r->n);
+    if (lg > 26) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    return ntt_resident(c, r, r, lg, true, true, n_out);
+}
+
+int zk_eval(zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]) {
+    if (!c || !x || !out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r || r->n > 0xffffffffu) return ZK_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    Fr xx;
+    memcpy(&xx, x, 32);
+    const uint32_t blocks = eval_blocks((uint32_t)r->n);
+    hipEventRecord(c->ev0, c->stream);
+    launch_eval(r->ptr, (uint32_t)r->n, xx, c->small, c->stream);
+    hipEventRecord(c->ev1, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->host_small, c->small + blocks, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipEventElapsedTime(&c->last_ms[ZK_T_EVAL], c->ev0, c->ev1);
+    memcpy(out, c->host_small, 32);
+    return ZK_OK;
+}
+
+}  // extern "C"

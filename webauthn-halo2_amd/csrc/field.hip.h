@@ -1,0 +1,239 @@
+// field.hip.h — BN254 Fr / Fq arithmetic for gfx950 device code.
+//
+// Device twin of halo2curves `bn256::{Fr,Fq}` (4 x u64-limb Montgomery, R = 2^256;
+// reached from the reference through halo2_proofs at
+// halo2-circuits/src/ecc/ecdsa_p256.rs:366-373,416-423 — SURVEY.md §8a a10).
+// CDNA4 has no 64-bit integer multiplier: an element is 8 x 32-bit limbs in
+// VGPRs (same little-endian memory image as 4 x u64) and products go through
+// v_mad_u64_u32 (32x32+64 -> 64).  Values are kept fully reduced ([0, p)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zk {
+
+struct FrParams {
+    static constexpr uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t INV = 0xefffffffu;  // -p^{-1} mod 2^32
+    static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                        0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                       0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+};
+
+struct FqParams {
+    static constexpr uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t INV = 0xe4866389u;
+    static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                        0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                       0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+};
+
+template <class PRM>
+struct alignas(16) Fe {
+    uint32_t v[8];
+
+    __host__ __device__ __forceinline__ static Fe zero() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = 0;
+        return r;
+    }
+    __host__ __device__ __forceinline__ static Fe one() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = PRM::ONE[i];
+        return r;
+    }
+    __host__ __device__ __forceinline__ static Fe r2() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = PRM::R2[i];
+        return r;
+    }
+    __host__ __device__ __forceinline__ bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= v[i];
+        return o == 0;
+    }
+    __host__ __device__ __forceinline__ bool operator==(const Fe& b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= v[i] ^ b.v[i];
+        return o == 0;
+    }
+    __host__ __device__ __forceinline__ bool operator!=(const Fe& b) const { return !(*this == b); }
+};
+
+// r = a - p if a >= p (a < 2p assumed)
+template <class PRM>
+__host__ __device__ __forceinline__ void reduce_once(Fe<PRM>& a) {
+    uint32_t t[8];
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a.v[i] - (int64_t)PRM::P[i];
+        t[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    if (c == 0) {  // no borrow: a >= p
+#pragma unroll
+        for (int i = 0; i < 8; i++) a.v[i] = t[i];
+    }
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_add(const Fe<PRM>& a, const Fe<PRM>& b) {
+    Fe<PRM> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    reduce_once(r);  // p < 2^254: no carry out of 256 bits
+    return r;
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_sub(const Fe<PRM>& a, const Fe<PRM>& b) {
+    Fe<PRM> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a.v[i] - (int64_t)b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    if (c != 0) {  // borrow: add p back
+        uint64_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            d += (uint64_t)r.v[i] + PRM::P[i];
+            r.v[i] = (uint32_t)d;
+            d >>= 32;
+        }
+    }
+    return r;
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_neg(const Fe<PRM>& a) {
+    if (a.is_zero()) return a;
+    Fe<PRM> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)PRM::P[i] - (int64_t)a.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_dbl(const Fe<PRM>& a) { return fe_add(a, a); }
+
+// CIOS Montgomery product, 8 x 32-bit limbs.  p < 2^254 so the running value
+// stays below 2p * 2^32 and the 10th limb of the textbook algorithm is always 0.
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_mul(const Fe<PRM>& a, const Fe<PRM>& b) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)a.v[j] * bi + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        const uint32_t t8 = t[8] + (uint32_t)c;
+        const uint32_t m = t[0] * PRM::INV;
+        c = (uint64_t)m * PRM::P[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (uint64_t)m * PRM::P[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t8;
+        t[7] = (uint32_t)c;
+        t[8] = (uint32_t)(c >> 32);
+    }
+    Fe<PRM> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    reduce_once(r);
+    return r;
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_sqr(const Fe<PRM>& a) { return fe_mul(a, a); }
+
+// Montgomery -> canonical integer (multiply by 1)
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_from_mont(const Fe<PRM>& a) {
+    Fe<PRM> one = Fe<PRM>::zero();
+    one.v[0] = 1;
+    return fe_mul(a, one);
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_to_mont(const Fe<PRM>& a) { return fe_mul(a, Fe<PRM>::r2()); }
+
+// a^e, e given as 8 LE 32-bit words (canonical integer)
+template <class PRM>
+__host__ __device__ inline Fe<PRM> fe_pow(const Fe<PRM>& a, const uint32_t e[8]) {
+    Fe<PRM> acc = Fe<PRM>::one();
+    bool started = false;
+    for (int i = 255; i >= 0; i--) {
+        if (started) acc = fe_sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) {
+            acc = started ? fe_mul(acc, a) : a;
+            started = true;
+        }
+    }
+    return acc;
+}
+
+template <class PRM>
+__host__ __device__ inline Fe<PRM> fe_inv(const Fe<PRM>& a) {
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = PRM::P[i];
+    e[0] -= 2;  // p - 2 (low limb of both moduli is > 2)
+    return fe_pow(a, e);
+}
+
+using Fr = Fe<FrParams>;
+using Fq = Fe<FqParams>;
+
+// 32-byte global loads/stores as two 16-byte accesses
+template <class PRM>
+__device__ __forceinline__ Fe<PRM> fe_load(const Fe<PRM>* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    Fe<PRM> r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+
+template <class PRM>
+__device__ __forceinline__ void fe_store(Fe<PRM>* p, const Fe<PRM>& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+}  // namespace zk

@@ -1,0 +1,213 @@
+"""ctypes binding of libzkmi355.so (include/zkmi355.h) — the only way Python
+reaches the engine.  There is no CPU fallback: a missing library or a missing
+gfx950 device raises `ZkError`.
+
+Arrays are numpy uint64 with the Rust memory images (Fr/Fq: 4 LE limbs,
+Montgomery; G1Affine: 8 limbs; G1 Jacobian: 12 limbs).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ZK_BASIS_MONOMIAL = 0
+ZK_BASIS_LAGRANGE = 1
+ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL = 0, 1, 2, 3
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code, what, hip=0):
+        self.code = code
+        self.hip = hip
+        super().__init__(f"{what}: zk error {code}" + (f" (hipError_t {hip})" if hip else ""))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libzkmi355.so")
+
+
+def load_library():
+    """Load libzkmi355.so; raises if it has not been built (./build.sh)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ZkError(-4, f"{p} is missing — run ./build.sh (no CPU fallback exists)")
+    L = ctypes.CDLL(p)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    vp = ctypes.c_void_p
+    sz = ctypes.c_size_t
+    u32 = ctypes.c_uint32
+    sig = {
+        "zk_device_count": ([], ctypes.c_int),
+        "zk_ctx_create": ([ctypes.c_int, ctypes.POINTER(vp)], ctypes.c_int),
+        "zk_ctx_destroy": ([vp], None),
+        "zk_strerror": ([ctypes.c_int], ctypes.c_char_p),
+        "zk_last_hip_error": ([vp], ctypes.c_int),
+        "zk_sync": ([vp], ctypes.c_int),
+        "zk_msm_bn254": ([vp, u64p, u64p, sz, u64p], ctypes.c_int),
+        "zk_ntt_bn254_fr": ([vp, u64p, u64p, u32], ctypes.c_int),
+        "zk_srs_setup": ([vp, u32, ctypes.c_char_p], ctypes.c_int),
+        "zk_srs_load": ([vp, u32, u64p, u64p], ctypes.c_int),
+        "zk_srs_export": ([vp, ctypes.c_int, u64p, sz, sz], ctypes.c_int),
+        "zk_srs_k": ([vp], ctypes.c_int),
+        "zk_poly_alloc": ([vp, sz, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_poly_free": ([vp, ctypes.c_uint64], ctypes.c_int),
+        "zk_poly_len": ([vp, ctypes.c_uint64, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_poly_upload": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
+        "zk_poly_download": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
+        "zk_poly_copy": ([vp, ctypes.c_uint64, ctypes.c_uint64], ctypes.c_int),
+        "zk_commit": ([vp, ctypes.c_uint64, ctypes.c_int, u64p], ctypes.c_int),
+        "zk_lagrange_to_coeff": ([vp, ctypes.c_uint64], ctypes.c_int),
+        "zk_coeff_to_lagrange": ([vp, ctypes.c_uint64], ctypes.c_int),
+        "zk_coeff_to_extended": ([vp, ctypes.c_uint64, ctypes.c_uint64], ctypes.c_int),
+        "zk_extended_to_coeff": ([vp, ctypes.c_uint64, sz], ctypes.c_int),
+        "zk_eval": ([vp, ctypes.c_uint64, u64p, u64p], ctypes.c_int),
+        "zk_last_kernel_ms": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = res
+    _LIB = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def _arr(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.size % cols:
+        raise ValueError("bad array shape")
+    return a.reshape(-1, cols)
+
+
+class Poly:
+    """Handle of a device-resident vector of Fr."""
+
+    def __init__(self, eng, handle, n):
+        self.eng, self.h, self.n = eng, handle, n
+
+    def free(self):
+        if self.h:
+            self.eng._chk(self.eng.L.zk_poly_free(self.eng.ctx, self.h), "zk_poly_free")
+            self.h = 0
+
+
+class Engine:
+    """One zk_ctx = one HIP device + stream."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        ctx = ctypes.c_void_p()
+        rc = self.L.zk_ctx_create(device, ctypes.byref(ctx))
+        if rc != 0:
+            raise ZkError(rc, "zk_ctx_create: " + self.L.zk_strerror(rc).decode())
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.zk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise ZkError(rc, what + ": " + self.L.zk_strerror(rc).decode(), self.L.zk_last_hip_error(self.ctx))
+
+    # ---- fine-grained seam ----------------------------------------------------
+    def msm(self, scalars_mont, bases_mont):
+        s = _arr(scalars_mont, 4)
+        b = _arr(bases_mont, 8)
+        if s.shape[0] != b.shape[0]:
+            raise ValueError("scalars / bases length mismatch")
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.zk_msm_bn254(self.ctx, _p(s), _p(b), s.shape[0], _p(out)), "zk_msm_bn254")
+        return out
+
+    def ntt(self, a_mont, omega_mont, log_n):
+        a = _arr(a_mont, 4).copy()
+        if a.shape[0] != (1 << log_n):
+            raise ValueError("length != 2^log_n")
+        w = np.ascontiguousarray(omega_mont, dtype=np.uint64).reshape(4)
+        self._chk(self.L.zk_ntt_bn254_fr(self.ctx, _p(a), _p(w), log_n), "zk_ntt_bn254_fr")
+        return a
+
+    # ---- SRS ----------------------------------------------------------------------
+    def srs_setup(self, k, seed=bytes(32)):
+        self._chk(self.L.zk_srs_setup(self.ctx, k, seed), "zk_srs_setup")
+
+    def srs_load(self, k, g, g_lagrange):
+        g, gl = _arr(g, 8), _arr(g_lagrange, 8)
+        if g.shape[0] != (1 << k) or gl.shape[0] != (1 << k):
+            raise ValueError("SRS arrays must hold 2^k points")
+        self._chk(self.L.zk_srs_load(self.ctx, k, _p(g), _p(gl)), "zk_srs_load")
+
+    def srs_export(self, basis, first, count):
+        out = np.zeros((count, 8), dtype=np.uint64)
+        self._chk(self.L.zk_srs_export(self.ctx, basis, _p(out), first, count), "zk_srs_export")
+        return out
+
+    # ---- resident polynomials ---------------------------------------------------
+    def poly(self, n, data=None):
+        h = ctypes.c_uint64()
+        self._chk(self.L.zk_poly_alloc(self.ctx, n, ctypes.byref(h)), "zk_poly_alloc")
+        p = Poly(self, h.value, n)
+        if data is not None:
+            self.upload(p, data)
+        return p
+
+    def upload(self, p, data):
+        d = _arr(data, 4)
+        self._chk(self.L.zk_poly_upload(self.ctx, p.h, _p(d), d.shape[0]), "zk_poly_upload")
+
+    def download(self, p, n=None):
+        n = p.n if n is None else n
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(self.L.zk_poly_download(self.ctx, p.h, _p(out), n), "zk_poly_download")
+        return out
+
+    def copy(self, dst, src):
+        self._chk(self.L.zk_poly_copy(self.ctx, dst.h, src.h), "zk_poly_copy")
+
+    def commit(self, p, basis):
+        out = np.zeros(8, dtype=np.uint64)
+        self._chk(self.L.zk_commit(self.ctx, p.h, basis, _p(out)), "zk_commit")
+        return out
+
+    def lagrange_to_coeff(self, p):
+        self._chk(self.L.zk_lagrange_to_coeff(self.ctx, p.h), "zk_lagrange_to_coeff")
+
+    def coeff_to_lagrange(self, p):
+        self._chk(self.L.zk_coeff_to_lagrange(self.ctx, p.h), "zk_coeff_to_lagrange")
+
+    def coeff_to_extended(self, src, dst):
+        self._chk(self.L.zk_coeff_to_extended(self.ctx, src.h, dst.h), "zk_coeff_to_extended")
+
+    def extended_to_coeff(self, ext, n_out):
+        self._chk(self.L.zk_extended_to_coeff(self.ctx, ext.h, n_out), "zk_extended_to_coeff")
+
+    def eval(self, p, x_mont):
+        x = np.ascontiguousarray(x_mont, dtype=np.uint64).reshape(4)
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(self.L.zk_eval(self.ctx, p.h, _p(x), _p(out)), "zk_eval")
+        return out
+
+    def sync(self):
+        self._chk(self.L.zk_sync(self.ctx), "zk_sync")
+
+    def last_ms(self, which):
+        v = ctypes.c_float()
+        self._chk(self.L.zk_last_kernel_ms(self.ctx, which, ctypes.byref(v)), "zk_last_kernel_ms")
+        return v.value
