@@ -104,6 +104,7 @@ int zk_eval(zk_ctx* ctx, zk_poly p, const uint64_t x_mont[4], uint64_t out_mont[
 #define ZK_T_NTT 1
 #define ZK_T_QUOTIENT 2
 #define ZK_T_EVAL 3
+#define ZK_T_MSM_ACCUM 4 /* the bucket-accumulation kernel of the last MSM alone */
 #define ZK_T_COUNT 8
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
 

@@ -41,7 +41,7 @@ uint32_t msm_auto_window(size_t n);
 // ws->window_sums (device) and are copied to `host_window_sums` (pinned or
 // pageable, nwin * 128 B) asynchronously.  Returns the number of windows.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
-                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out);
+                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events = nullptr);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).
 G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
 

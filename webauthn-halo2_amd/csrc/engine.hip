@@ -65,8 +65,8 @@ struct zk_ctx {
     // constants
     Fr zeta, zeta2;
     // timing
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms[ZK_T_COUNT] = {0};
+    hipEvent_t ev[ZK_T_COUNT][2] = {};
+    bool ev_valid[ZK_T_COUNT] = {false};
 };
 
 #define HIPCHK(ctx, x)                 \
@@ -147,11 +147,12 @@ static int msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, s
     int rc = get_msm_ws(c, n, &ws);
     if (rc) return rc;
     uint32_t nwin = 0, cw = 0;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, msm_run(ws, d_scalars, d_bases, n, c->stream, c->host_wsum, &nwin, &cw));
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[ZK_T_MSM][0], c->stream));
+    HIPCHK(c, msm_run(ws, d_scalars, d_bases, n, c->stream, c->host_wsum, &nwin, &cw, c->ev[ZK_T_MSM_ACCUM]));
+    HIPCHK(c, hipEventRecord(c->ev[ZK_T_MSM][1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipEventElapsedTime(&c->last_ms[ZK_T_MSM], c->ev0, c->ev1);
+    c->ev_valid[ZK_T_MSM] = true;
+    c->ev_valid[ZK_T_MSM_ACCUM] = n > 0;
     *out = msm_finish_host(c->host_wsum, nwin, cw);
     return ZK_OK;
 }
@@ -187,13 +188,17 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     if (!c) return ZK_ENOMEM;
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipHostMalloc(&c->host_wsum, 64 * sizeof(G1X)) != hipSuccess ||
         hipHostMalloc(&c->host_small, 8 * sizeof(Fr)) != hipSuccess ||
         hipMalloc(&c->small, (2048 + 8) * sizeof(Fr)) != hipSuccess) {
         zk_ctx_destroy(c);
         return ZK_EHIP;
     }
+    for (int i = 0; i < ZK_T_COUNT; i++)
+        if (hipEventCreate(&c->ev[i][0]) != hipSuccess || hipEventCreate(&c->ev[i][1]) != hipSuccess) {
+            zk_ctx_destroy(c);
+            return ZK_EHIP;
+        }
     c->zeta = fr_zeta();
     c->zeta2 = fe_sqr(c->zeta);
     *out = c;
@@ -213,8 +218,9 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->host_small) hipHostFree(c->host_small);
     if (c->scratch) hipFree(c->scratch);
     if (c->small) hipFree(c->small);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (int i = 0; i < ZK_T_COUNT; i++)
+        for (int j = 0; j < 2; j++)
+            if (c->ev[i][j]) hipEventDestroy(c->ev[i][j]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -232,7 +238,15 @@ int zk_sync(zk_ctx* c) {
 
 int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
     if (!c || !out_ms || which < 0 || which >= ZK_T_COUNT) return ZK_EINVAL;
-    *out_ms = c->last_ms[which];
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->ev_valid[which]) {
+        *out_ms = 0.f;
+        return ZK_OK;
+    }
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
+    HIPCHK(c, hipEventElapsedTime(out_ms, c->ev[which][0], c->ev[which][1]));
     return ZK_OK;
 }
 
@@ -312,9 +326,10 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
     job.n_in = job.n_out = (uint32_t)n;
     if (hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     if (rc == ZK_OK) {
-        hipEventRecord(c->ev0, c->stream);
+        hipEventRecord(c->ev[ZK_T_NTT][0], c->stream);
         hipError_t e = ntt_run(job, c->stream);
-        hipEventRecord(c->ev1, c->stream);
+        hipEventRecord(c->ev[ZK_T_NTT][1], c->stream);
+        c->ev_valid[ZK_T_NTT] = true;
         if (e != hipSuccess) {
             c->last_hip = (int)e;
             rc = ZK_EHIP;
@@ -329,10 +344,7 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
             rc = ZK_EHIP;
     }
     hipStreamSynchronize(c->stream);
-    if (rc == ZK_OK) {
-        hipEventElapsedTime(&c->last_ms[ZK_T_NTT], c->ev0, c->ev1);
-        memcpy(a, tmp.data(), n * sizeof(Fr));
-    }
+    if (rc == ZK_OK) memcpy(a, tmp.data(), n * sizeof(Fr));
     hipFree(d_a);
     hipFree(d_t);
     hipFree(own_tw);
@@ -584,9 +596,10 @@ static int ntt_resident(zk_ctx* c, PolyRec* src, PolyRec* dst, uint32_t log_n, b
         job.post[1] = coset ? fe_mul(ninv, c->zeta2) : ninv;
         job.post[2] = coset ? fe_mul(ninv, c->zeta) : ninv;
     }
-    hipEventRecord(c->ev0, c->stream);
+    hipEventRecord(c->ev[ZK_T_NTT][0], c->stream);
     hipError_t e = ntt_run(job, c->stream);
-    hipEventRecord(c->ev1, c->stream);
+    hipEventRecord(c->ev[ZK_T_NTT][1], c->stream);
+    c->ev_valid[ZK_T_NTT] = true;
     if (e != hipSuccess) {
         c->last_hip = (int)e;
         return ZK_EHIP;
@@ -658,12 +671,12 @@ int zk_eval(zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]) {
     Fr xx;
     memcpy(&xx, x, 32);
     const uint32_t blocks = eval_blocks((uint32_t)r->n);
-    hipEventRecord(c->ev0, c->stream);
+    hipEventRecord(c->ev[ZK_T_EVAL][0], c->stream);
     launch_eval(r->ptr, (uint32_t)r->n, xx, c->small, c->stream);
-    hipEventRecord(c->ev1, c->stream);
+    hipEventRecord(c->ev[ZK_T_EVAL][1], c->stream);
+    c->ev_valid[ZK_T_EVAL] = true;
     HIPCHK(c, hipMemcpyAsync(c->host_small, c->small + blocks, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipEventElapsedTime(&c->last_ms[ZK_T_EVAL], c->ev0, c->ev1);
     memcpy(out, c->host_small, 32);
     return ZK_OK;
 }

@@ -369,7 +369,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
 }
 
 hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
-                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out) {
+                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events) {
     if (n > ws->max_n) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const uint32_t nbt = nwin * nb;
@@ -388,9 +388,11 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
         // level 0
         size_t worst = (size_t)n * nwin;  // worst-case entry count
         size_t threads = (worst + ws->seg0 - 1) / ws->seg0;
+        if (accum_events) hipEventRecord(accum_events[0], st);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
                            bases, ws->counts, ws->seg0, ws->bucket_sum, ws->slot_bucket[0], ws->slot_pt[0],
                            ws->counts + 1);
+        if (accum_events) hipEventRecord(accum_events[1], st);
         size_t count = 2 * threads;  // worst-case slot count
         int cur = 0, level = 1;
         while (count > 256 && level < 14) {
