@@ -50,6 +50,13 @@ def test_unsatisfied_witness_is_caught():
     pk, asg = build("k19like")
     adv = [list(c) for c in asg.advice]
     adv[0][3] = (adv[0][3] + 1) % zk.circuit.R  # break gate 0: d != a + b*c
+    # degree-5 shape: h fills the whole extended domain, so the prover cannot notice; the verifier does
+    proof = prover.create_proof(pk, adv, ChaCha20Rng(bytes(32)), "evm")
+    assert not plonk.verify(pk.vk, proof, "evm")
+    # degree-4 shapes: the quotient spills past (d-1)*n coefficients and the prover itself asserts
+    pk, asg = build("k17like")
+    adv = [list(c) for c in asg.advice]
+    adv[1][3] = (adv[1][3] + 1) % zk.circuit.R
     with pytest.raises(AssertionError):
         prover.create_proof(pk, adv, ChaCha20Rng(bytes(32)), "evm")
 
