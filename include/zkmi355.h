@@ -42,6 +42,8 @@ extern "C" {
 #define ZK_EHIP (-3)     /* HIP runtime error (zk_last_hip_error) */
 #define ZK_ENODEV (-4)   /* no usable gfx950 device */
 #define ZK_ESTATE (-5)   /* missing prerequisite (SRS / key not loaded) */
+#define ZK_EWITNESS (-6) /* witness violates the circuit (lookup input not in table): halo2's
+                            Error::ConstraintSystemFailure */
 
 typedef struct zk_ctx zk_ctx;
 typedef uint64_t zk_poly; /* opaque device-resident vector of Fr; 0 is never valid */
@@ -97,6 +99,44 @@ int zk_coeff_to_extended(zk_ctx* ctx, zk_poly src, zk_poly dst_ext);
 int zk_extended_to_coeff(zk_ctx* ctx, zk_poly ext, size_t n_out);
 /* replaces arithmetic::eval_polynomial(poly, x) */
 int zk_eval(zk_ctx* ctx, zk_poly p, const uint64_t x_mont[4], uint64_t out_mont[4]);
+
+/* ---- keygen / create_proof ---------------------------------------------------
+ * The config row that selects the column shape: reference CircuitParams
+ * (halo2-circuits/src/ecc/ecdsa_p256.rs:44-55; rows in src/configs/bench_ecdsa.config). */
+typedef struct {
+    uint32_t k;                 /* "degree" */
+    uint32_t num_advice;
+    uint32_t num_lookup_advice;
+    uint32_t num_fixed;
+    uint32_t lookup_bits;
+} zk_circuit_params;
+typedef uint64_t zk_pk; /* opaque: proving key + verifying key + prover workspace, device resident */
+
+#define ZK_TRANSCRIPT_BLAKE2B 0 /* Blake2bWrite<_, G1Affine, Challenge255<_>>  (ecdsa_p256.rs:415) */
+#define ZK_TRANSCRIPT_EVM 1     /* snark-verifier EvmTranscript (Keccak-256)   (ecdsa_p256.rs:365) */
+#define ZK_SCHEME_DEFAULT 0     /* SHPLONK for Blake2b, GWC for EVM — the reference's pairings */
+#define ZK_SCHEME_GWC 1         /* ProverGWC     (ecdsa_p256.rs:368) */
+#define ZK_SCHEME_SHPLONK 2     /* ProverSHPLONK (ecdsa_p256.rs:418) */
+
+/* replaces keygen_vk + keygen_pk (ecdsa_p256.rs:259-260) for a synthesized circuit: `fixed_canonical`
+ * holds the fixed columns (n_fix x n x 4 limbs, canonical integers, column order: constants, range
+ * table, selectors); `copies` the copy constraints as (perm_col_a, row_a, perm_col_b, row_b) with
+ * permutation columns ordered [constants..., gate advice..., lookup advice...].  Needs the SRS of k. */
+int zk_keygen(zk_ctx* ctx, const zk_circuit_params* params, const uint64_t* fixed_canonical,
+              const uint32_t* copies, size_t n_copies, zk_pk* out);
+int zk_pk_free(zk_ctx* ctx, zk_pk pk);
+/* the VerifyingKey half: commitments (affine Montgomery) and transcript_repr; counts = {n_fixed, n_perm} */
+int zk_vk_export(zk_ctx* ctx, zk_pk pk, uint64_t* fixed_commitments, uint64_t* perm_commitments,
+                 uint64_t transcript_repr[4], uint32_t counts[2]);
+/* replaces plonk::create_proof (ecdsa_p256.rs:366-373, 416-423, 555-562) for one circuit with no
+ * instances.  `advice` are resident columns (Lagrange values, Montgomery, n rows each; the last 7 rows
+ * are overwritten by blinding in a private copy).  Randomness: ChaCha20Rng::from_seed(rng_seed), one
+ * 64-byte block per Fr::random in halo2's draw order.  Returns the proof bytes the transcript writer
+ * would hold after `finalize()`.  proof_out == NULL: only *proof_len is set. */
+int zk_prove(zk_ctx* ctx, zk_pk pk, const zk_poly* advice, size_t n_advice, const uint8_t rng_seed[32],
+             int transcript, int scheme, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* upload canonical (non-Montgomery) integers and convert on the device */
+int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canonical, size_t n);
 
 /* ---- timing of the last call of each kind, measured with HIP events on the
  *      context stream (ms); used by bench.py for the roofline figures ---------- */

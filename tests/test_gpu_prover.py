@@ -1,0 +1,121 @@
+"""GPU proof-level parity: the device prover (zk_keygen / zk_prove through the C-ABI)
+produces, from the same witness and the same ChaCha20 stream, byte-identical proofs to
+the oracle's restated create_proof, for every BASELINE column shape (scaled to small
+k), both transcripts; at k=17 / k=19 the proofs are checked by the oracle verifier that
+the reference's golden proof pins."""
+import numpy as np
+import pytest
+
+import webauthn_halo2_amd as zk
+from webauthn_halo2_amd import engine as E
+from zkoracle import cops, plonk, prover
+from zkoracle.hashes import ChaCha20Rng
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "k19like": (1, 1, 1, 7, 6),
+    "k17like": (4, 1, 1, 7, 5),
+    "k18like": (2, 1, 1, 6, 4),
+    "wide": (3, 2, 2, 8, 6),
+}
+KIND = {"evm": E.ZK_TRANSCRIPT_EVM, "blake2b": E.ZK_TRANSCRIPT_BLAKE2B}
+
+
+def setup(engine, A, L, F, k, lb, seed=0x5EED0019, worst=False):
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    asg = zk.circuit.synthesize(p, seed, worst_case=worst)
+    engine.srs_setup(k)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    pk = engine.keygen(p, fixed, asg.copies)
+    polys = []
+    for col in asg.advice:
+        h = engine.poly(1 << k)
+        engine.upload_canonical(h, asg.to_limbs(col))
+        polys.append(h)
+    return p, asg, pk, polys
+
+
+def product_vk(engine, pk, shape):
+    fc, pc, tr = engine.vk_export(pk)
+    return plonk.VerifyingKey(shape, cops.affine_arr_to_ints(fc), cops.affine_arr_to_ints(pc), cops.fr_ints(tr.reshape(1, 4))[0])
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_proofs_byte_identical_to_oracle(engine, name):
+    A, L, F, k, lb = SHAPES[name]
+    p, asg, pk, polys = setup(engine, A, L, F, k, lb)
+    sh = plonk.Shape(k, A, L, F, lb)
+    opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
+    vk = product_vk(engine, pk, sh)
+    # keygen parity: commitments (MSM on device vs tau-oracle) and transcript_repr
+    assert vk.fixed_commitments == opk.vk.fixed_commitments
+    assert vk.permutation_commitments == opk.vk.permutation_commitments
+    assert vk.transcript_repr == opk.vk.transcript_repr
+    seed = bytes(range(32))
+    for kind in ("evm", "blake2b"):
+        for scheme in (E.ZK_SCHEME_DEFAULT,):
+            got = engine.prove(pk, polys, seed, KIND[kind], scheme)
+            want = prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), kind)
+            assert got == want, (name, kind)
+            assert plonk.verify(vk, got, kind)
+    # the two non-reference pairings too
+    got = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM, E.ZK_SCHEME_SHPLONK)
+    assert got == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), "evm", "shplonk")
+    got = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_BLAKE2B, E.ZK_SCHEME_GWC)
+    assert got == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), "blake2b", "gwc")
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
+
+
+def test_worst_case_witness_and_second_seed(engine):
+    A, L, F, k, lb = SHAPES["k17like"]
+    p, asg, pk, polys = setup(engine, A, L, F, k, lb, seed=0x5EED0019 + 3, worst=True)
+    sh = plonk.Shape(k, A, L, F, lb)
+    opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
+    seed = b"\x42" * 32
+    got = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
+    assert got == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), "evm")
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
+
+
+def test_lookup_violation_is_reported(engine):
+    A, L, F, k, lb = SHAPES["k19like"]
+    p, asg, pk, polys = setup(engine, A, L, F, k, lb)
+    # put an out-of-table value under q_lookup
+    row = asg.fixed[asg.layout.fx_qlookup].index(1)
+    col = list(asg.advice[0])
+    col[row] = 1 << 40
+    engine.upload_canonical(polys[0], asg.to_limbs(col))
+    with pytest.raises(zk.ZkError) as e:
+        engine.prove(pk, polys, bytes(32), E.ZK_TRANSCRIPT_EVM)
+    assert e.value.code == -6  # ZK_EWITNESS
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
+
+
+@pytest.mark.parametrize("cfg", ["K17", "K19"])
+def test_baseline_shapes_verify(engine, cfg):
+    """BASELINE configs[1]/[2]: full-size proofs, sizes as published (K6), accepted by the pinned verifier."""
+    p = getattr(zk.circuit, cfg)
+    A, L, F, k, lb = p.num_advice, p.num_lookup_advice, p.num_fixed, p.degree, p.lookup_bits
+    _, asg, pk, polys = setup(engine, A, L, F, k, lb)
+    sh = plonk.Shape(k, A, L, F, lb)
+    vk = product_vk(engine, pk, sh)
+    want = {"K17": (1920, 2720), "K19": (960, 1536)}[cfg]
+    pf = engine.prove(pk, polys, b"\x01" * 32, E.ZK_TRANSCRIPT_BLAKE2B)
+    assert len(pf) == want[0]  # halo2-circuits/src/results/ecdsa_bench.csv:2,4
+    assert plonk.verify(vk, pf, "blake2b")
+    pe = engine.prove(pk, polys, b"\x01" * 32, E.ZK_TRANSCRIPT_EVM)
+    assert len(pe) == want[1]
+    assert plonk.verify(vk, pe, "evm")
+    bad = bytearray(pe)
+    bad[100] ^= 1
+    assert not plonk.verify(vk, bytes(bad), "evm")
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)

@@ -1,0 +1,68 @@
+// ctx.h — the engine context shared by engine.hip (C-ABI) and prover.hip.
+#pragma once
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/zkmi355.h"
+#include "engine.h"
+#include "hostutil.h"
+
+using namespace zk;
+
+struct zk_pk_rec;
+
+struct PolyRec {
+    Fr* ptr;
+    size_t n;
+};
+
+struct zk_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    std::mutex mu;
+    std::map<uint32_t, Fr*> twiddles;  // log_n -> w_{2^log_n}^i table
+    // SRS
+    int srs_k = -1;
+    G1Affine* g = nullptr;
+    G1Affine* g_lagrange = nullptr;
+    // MSM
+    MsmWorkspace* msm_ws = nullptr;
+    G1X* host_wsum = nullptr;  // pinned
+    // scratch
+    Fr* scratch = nullptr;
+    size_t scratch_n = 0;
+    Fr* small = nullptr;  // 2048 + 8 elements for reductions
+    Fr* host_small = nullptr;  // pinned, 8 elements
+    // polys
+    std::unordered_map<uint64_t, PolyRec> polys;
+    uint64_t next_handle = 1;
+    // constants
+    Fr zeta, zeta2;
+    // proving keys
+    std::unordered_map<uint64_t, zk_pk_rec*> pks;
+    // timing
+    hipEvent_t ev[ZK_T_COUNT][2] = {};
+    bool ev_valid[ZK_T_COUNT] = {false};
+};
+
+#define HIPCHK(ctx, x)                 \
+    do {                               \
+        hipError_t _e = (x);           \
+        if (_e != hipSuccess) {        \
+            (ctx)->last_hip = (int)_e; \
+            return ZK_EHIP;            \
+        }                              \
+    } while (0)
+
+
+int ctx_bind(zk_ctx* c);
+int ctx_ensure_scratch(zk_ctx* c, size_t n);
+int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);
+// MSM of device-resident scalars against device-resident bases -> Jacobian on host (synchronises)
+int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out);
+// NTT between device buffers: inverse => x 1/N; coset => zeta scaling (coeff_to_extended / extended_to_coeff)
+int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out);
+void pk_destroy_all(zk_ctx* c);

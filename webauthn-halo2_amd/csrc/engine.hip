@@ -1,16 +1,9 @@
 // engine.hip — context, device memory and the C ABI of libzkmi355.so
 // (declarations and the reference routines each entry point replaces:
 // include/zkmi355.h).
-#include "../../include/zkmi355.h"
-
-#include <map>
-#include <mutex>
 #include <new>
-#include <unordered_map>
-#include <vector>
 
-#include "engine.h"
-#include "hostutil.h"
+#include "ctx.h"
 
 namespace zk {
 // poly.hip
@@ -34,51 +27,7 @@ G1Affine g1_jac_to_affine_host(const G1Jac& p) {
 }
 }  // namespace zk
 
-using namespace zk;
-
-struct PolyRec {
-    Fr* ptr;
-    size_t n;
-};
-
-struct zk_ctx {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    int last_hip = 0;
-    std::mutex mu;
-    std::map<uint32_t, Fr*> twiddles;  // log_n -> w_{2^log_n}^i table
-    // SRS
-    int srs_k = -1;
-    G1Affine* g = nullptr;
-    G1Affine* g_lagrange = nullptr;
-    // MSM
-    MsmWorkspace* msm_ws = nullptr;
-    G1X* host_wsum = nullptr;  // pinned
-    // scratch
-    Fr* scratch = nullptr;
-    size_t scratch_n = 0;
-    Fr* small = nullptr;  // 2048 + 8 elements for reductions
-    Fr* host_small = nullptr;  // pinned, 8 elements
-    // polys
-    std::unordered_map<uint64_t, PolyRec> polys;
-    uint64_t next_handle = 1;
-    // constants
-    Fr zeta, zeta2;
-    // timing
-    hipEvent_t ev[ZK_T_COUNT][2] = {};
-    bool ev_valid[ZK_T_COUNT] = {false};
-};
-
-#define HIPCHK(ctx, x)                 \
-    do {                               \
-        hipError_t _e = (x);           \
-        if (_e != hipSuccess) {        \
-            (ctx)->last_hip = (int)_e; \
-            return ZK_EHIP;            \
-        }                              \
-    } while (0)
-
-static int bind(zk_ctx* c) {
+int ctx_bind(zk_ctx* c) {
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) {
         c->last_hip = (int)e;
@@ -87,7 +36,7 @@ static int bind(zk_ctx* c) {
     return ZK_OK;
 }
 
-static int ensure_scratch(zk_ctx* c, size_t n) {
+int ctx_ensure_scratch(zk_ctx* c, size_t n) {
     if (c->scratch_n >= n) return ZK_OK;
     if (c->scratch) hipFree(c->scratch);
     c->scratch = nullptr;
@@ -101,7 +50,7 @@ static int ensure_scratch(zk_ctx* c, size_t n) {
     return ZK_OK;
 }
 
-static int get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
+int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
     auto it = c->twiddles.find(log_n);
     if (it != c->twiddles.end()) {
         *out = it->second;
@@ -142,7 +91,7 @@ static int get_msm_ws(zk_ctx* c, size_t n, MsmWorkspace** out) {
 }
 
 // MSM of device-resident scalars against device-resident bases -> Jacobian on host
-static int msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out) {
+int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out) {
     MsmWorkspace* ws;
     int rc = get_msm_ws(c, n, &ws);
     if (rc) return rc;
@@ -210,6 +159,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
+    pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
     if (c->g) hipFree(c->g);
     if (c->g_lagrange) hipFree(c->g_lagrange);
@@ -230,7 +180,7 @@ int zk_last_hip_error(const zk_ctx* c) { return c ? c->last_hip : 0; }
 int zk_sync(zk_ctx* c) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ZK_OK;
@@ -243,7 +193,7 @@ int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
         *out_ms = 0.f;
         return ZK_OK;
     }
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
     HIPCHK(c, hipEventElapsedTime(out_ms, c->ev[which][0], c->ev[which][1]));
@@ -255,7 +205,7 @@ int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
 int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out[12]) {
     if (!c || !out || (n && (!scalars || !bases))) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     G1Jac res;
     if (n == 0) {
@@ -276,7 +226,7 @@ int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size
     if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess)
         rc = ZK_EHIP;
-    if (rc == ZK_OK) rc = msm_device(c, d_s, d_b, n, &res);
+    if (rc == ZK_OK) rc = ctx_msm_device(c, d_s, d_b, n, &res);
     hipStreamSynchronize(c->stream);
     hipFree(d_s);
     hipFree(d_b);
@@ -287,7 +237,7 @@ int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size
 int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
     if (!c || !a || !omega || log_n > 26) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     const size_t n = (size_t)1 << log_n;
     Fr w;
@@ -298,9 +248,9 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
     Fr* own_tw = nullptr;
     uint32_t inverse = 0;
     if (w == std_w) {
-        rc = get_twiddles(c, log_n, &tw);
+        rc = ctx_get_twiddles(c, log_n, &tw);
     } else if (fe_mul(w, std_w) == Fr::one()) {
-        rc = get_twiddles(c, log_n, &tw);
+        rc = ctx_get_twiddles(c, log_n, &tw);
         inverse = 1;
     } else {
         if (hipMalloc(&own_tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
@@ -368,7 +318,7 @@ static int srs_alloc(zk_ctx* c, uint32_t k) {
 int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
     if (!c || !seed) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
     const uint32_t n = 1u << k;
@@ -420,7 +370,7 @@ int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
     rc = ZK_OK;
     const Fr* tw = nullptr;
     if (hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
-    if (rc == ZK_OK) rc = get_twiddles(c, k, &tw);
+    if (rc == ZK_OK) rc = ctx_get_twiddles(c, k, &tw);
     if (rc == ZK_OK) {
         // g[i] = [s^i] G
         launch_twiddles(d_sc, s, n, c->stream);
@@ -447,7 +397,7 @@ int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
 int zk_srs_load(zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl) {
     if (!c || !g || !gl) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
     const size_t bytes = ((size_t)1 << k) * sizeof(G1Affine);
@@ -463,7 +413,7 @@ int zk_srs_export(zk_ctx* c, int basis, uint64_t* out, size_t first, size_t coun
     if (c->srs_k < 0) return ZK_ESTATE;
     const size_t n = (size_t)1 << c->srs_k;
     if (first > n || count > n - first) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     const G1Affine* src = basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g;
     HIPCHK(c, hipMemcpy(out, src + first, count * sizeof(G1Affine), hipMemcpyDeviceToHost));
@@ -482,7 +432,7 @@ static PolyRec* find_poly(zk_ctx* c, zk_poly h) {
 int zk_poly_alloc(zk_ctx* c, size_t n, zk_poly* out) {
     if (!c || !out || n == 0) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     Fr* p = nullptr;
     if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
@@ -497,7 +447,7 @@ int zk_poly_free(zk_ctx* c, zk_poly h) {
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
     if (!r) return ZK_EINVAL;
-    bind(c);
+    ctx_bind(c);
     hipStreamSynchronize(c->stream);
     hipFree(r->ptr);
     c->polys.erase(h);
@@ -518,7 +468,7 @@ int zk_poly_upload(zk_ctx* c, zk_poly h, const uint64_t* host, size_t n) {
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
     if (!r || n > r->n) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(r->ptr, host, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
     if (n < r->n) HIPCHK(c, hipMemsetAsync(r->ptr + n, 0, (r->n - n) * sizeof(Fr), c->stream));
@@ -531,7 +481,7 @@ int zk_poly_download(zk_ctx* c, zk_poly h, uint64_t* host, size_t n) {
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
     if (!r || n > r->n) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(host, r->ptr, n * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -543,7 +493,7 @@ int zk_poly_copy(zk_ctx* c, zk_poly dst, zk_poly src) {
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec *d = find_poly(c, dst), *s = find_poly(c, src);
     if (!d || !s || d->n < s->n) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(d->ptr, s->ptr, s->n * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
     if (d->n > s->n) HIPCHK(c, hipMemsetAsync(d->ptr + s->n, 0, (d->n - s->n) * sizeof(Fr), c->stream));
@@ -557,31 +507,33 @@ int zk_commit(zk_ctx* c, zk_poly h, int basis, uint64_t out[8]) {
     PolyRec* r = find_poly(c, h);
     const size_t n = (size_t)1 << c->srs_k;
     if (!r || r->n > n) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     G1Jac j;
-    rc = msm_device(c, r->ptr, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, r->n, &j);
+    rc = ctx_msm_device(c, r->ptr, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, r->n, &j);
     if (rc) return rc;
     const G1Affine a = g1_jac_to_affine_host(j);
     memcpy(out, &a, 64);
     return ZK_OK;
 }
 
-static int ntt_resident(zk_ctx* c, PolyRec* src, PolyRec* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
+}  // extern "C"
+
+int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
     const size_t N = (size_t)1 << log_n;
-    int rc = ensure_scratch(c, N);
+    int rc = ctx_ensure_scratch(c, N);
     if (rc) return rc;
     const Fr* tw;
-    if ((rc = get_twiddles(c, log_n, &tw)) != ZK_OK) return rc;
+    if ((rc = ctx_get_twiddles(c, log_n, &tw)) != ZK_OK) return rc;
     NttJob job;
     memset(&job, 0, sizeof(job));
-    job.src = src->ptr;
-    job.dst = dst->ptr;
+    job.src = src;
+    job.dst = dst;
     job.tmp = c->scratch;
     job.tw = tw;
     job.log_n = log_n;
     job.inverse = inverse ? 1 : 0;
-    job.n_in = (uint32_t)(src->n < N ? src->n : N);
+    job.n_in = (uint32_t)(src_n < N ? src_n : N);
     job.n_out = (uint32_t)n_out;
     if (!inverse && coset) {  // coeff_to_extended: a_i *= zeta^(i mod 3)
         job.has_pre = 1;
@@ -607,6 +559,12 @@ static int ntt_resident(zk_ctx* c, PolyRec* src, PolyRec* dst, uint32_t log_n, b
     return ZK_OK;
 }
 
+static int ntt_resident(zk_ctx* c, PolyRec* src, PolyRec* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
+    return ctx_ntt(c, src->ptr, src->n, dst->ptr, log_n, inverse, coset, n_out);
+}
+
+extern "C" {
+
 static uint32_t log2_exact(size_t n) {
     uint32_t l = 0;
     while (((size_t)1 << l) < n) l++;
@@ -620,7 +578,7 @@ int zk_lagrange_to_coeff(zk_ctx* c, zk_poly h) {
     if (!r) return ZK_EINVAL;
     const uint32_t lg = log2_exact(r->n);
     if (lg > 26) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     return ntt_resident(c, r, r, lg, true, false, r->n);
 }
@@ -632,7 +590,7 @@ int zk_coeff_to_lagrange(zk_ctx* c, zk_poly h) {
     if (!r) return ZK_EINVAL;
     const uint32_t lg = log2_exact(r->n);
     if (lg > 26) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     return ntt_resident(c, r, r, lg, false, false, r->n);
 }
@@ -644,7 +602,7 @@ int zk_coeff_to_extended(zk_ctx* c, zk_poly src, zk_poly dst) {
     if (!s || !d || s == d) return ZK_EINVAL;
     const uint32_t lg = log2_exact(d->n);
     if (lg > 26 || s->n > d->n) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     return ntt_resident(c, s, d, lg, false, true, d->n);
 }
@@ -656,7 +614,7 @@ int zk_extended_to_coeff(zk_ctx* c, zk_poly ext, size_t n_out) {
     if (!r || n_out > r->n) return ZK_EINVAL;
     const uint32_t lg = log2_exact(r->n);
     if (lg > 26) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     return ntt_resident(c, r, r, lg, true, true, n_out);
 }
@@ -666,7 +624,7 @@ int zk_eval(zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]) {
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
     if (!r || r->n > 0xffffffffu) return ZK_EINVAL;
-    int rc = bind(c);
+    int rc = ctx_bind(c);
     if (rc) return rc;
     Fr xx;
     memcpy(&xx, x, 32);

@@ -1,0 +1,89 @@
+// prover.h — internal declarations of the device prover (prover_kernels.hip,
+// quotient.hip, prover.hip).  Not part of the public C-ABI.
+#pragma once
+#include "engine.h"
+
+namespace zk {
+
+static constexpr uint32_t MAX_LC = 40;       // inputs of one linear combination
+static constexpr uint32_t MAX_CHUNK = 3;     // permutation columns per grand product (degree - 2)
+static constexpr uint32_t MAX_ADV = 40;
+static constexpr uint32_t MAX_FIX = 48;
+static constexpr uint32_t MAX_PERM = 48;
+static constexpr uint32_t MAX_CHUNKS = 24;
+static constexpr uint32_t MAX_LOOKUPS = 8;
+static constexpr uint32_t BLINDING_FACTORS = 6;  // max(3, 4 queries per gate column) + 2
+
+struct LincombArgs {
+    Fr* out;
+    uint32_t n, count, accumulate, sub0;
+    Fr sub0_val;  // subtracted from coefficient 0
+    const Fr* in[MAX_LC];
+    uint32_t len[MAX_LC];
+    uint32_t unit[MAX_LC];  // coefficient is 1
+    Fr c[MAX_LC];
+};
+
+struct ChaChaKey {
+    uint32_t w[8];
+};
+
+struct LookupScratch {
+    uint32_t *hist, *present, *absent, *off, *dex, *aex, *err;  // T + 1 entries each (err: 1)
+};
+
+struct PermArgs {
+    uint32_t n, ncols;
+    const Fr* values[MAX_CHUNK];
+    const Fr* sigma[MAX_CHUNK];
+    Fr delta[MAX_CHUNK];  // delta^(global column index)
+    const Fr* tw;         // w^i
+    Fr beta, gamma;
+    Fr *num, *den;
+};
+
+// one thread per row of the extended coset (expressions pinned by
+// reference proving-server/P256Verifier.yul:406-552)
+struct QuotientArgs {
+    uint32_t log_ext, n_gate, n_adv, n_chunks, chunk_len, n_perm, n_lookups, single;
+    int32_t last_rot;     // -(blinding_factors + 1)
+    uint32_t fx_table, fx_qlookup;
+    const Fr* adv[MAX_ADV];       // extended cosets
+    const Fr* fix[MAX_FIX];
+    uint32_t fx_sel[MAX_ADV];
+    const Fr* sigma[MAX_PERM];
+    const Fr* perm_val[MAX_PERM]; // coset of the column each permutation column refers to
+    const Fr* z[MAX_CHUNKS];
+    const Fr* lk_z[MAX_LOOKUPS];
+    const Fr* lk_a[MAX_LOOKUPS];
+    const Fr* lk_s[MAX_LOOKUPS];
+    const Fr* lk_in[MAX_LOOKUPS]; // A >= 2: lookup advice coset; A == 1: unused (q_lookup * adv[0])
+    const Fr *l0, *l_last, *l_active;
+    const Fr* tw_ext;             // w_ext^i
+    Fr zeta, beta, gamma, y;
+    Fr delta_pow[MAX_PERM];       // beta * delta^c  (times x on the fly)
+    Fr t_inv[4];                  // 1 / ((zeta w_ext^i)^n - 1), period 4
+    Fr* out;
+};
+
+void launch_to_mont(Fr* a, uint32_t n, hipStream_t st);
+void launch_mul(Fr* out, const Fr* a, const Fr* b, uint32_t n, hipStream_t st);
+void launch_lincomb(const LincombArgs& a, hipStream_t st);
+void launch_scale(Fr* a, const Fr& c, uint32_t n, hipStream_t st);
+void launch_chacha_fr(const ChaChaKey& key, uint64_t start_block, Fr* out, uint32_t count, hipStream_t st);
+void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t st);
+void launch_lookup_permute(const Fr* inp, uint32_t usable, uint32_t T, LookupScratch& s, Fr* ap, Fr* sp, hipStream_t st);
+void launch_perm_numden(const PermArgs& a, hipStream_t st);
+void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, const Fr& beta, const Fr& gamma, Fr* num,
+                      Fr* den, uint32_t n, hipStream_t st);
+void launch_frac(const Fr* num, const Fr* den, Fr* frac, uint32_t n, hipStream_t st);
+void launch_prefix_product(const Fr* f, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_local,
+                           Fr* tmp_tot, hipStream_t st);
+void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st);
+void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
+
+// poly.hip
+uint32_t eval_blocks(uint32_t n);
+void launch_eval(const Fr* c, uint32_t n, const Fr& x, Fr* scratch, hipStream_t st);
+
+}  // namespace zk

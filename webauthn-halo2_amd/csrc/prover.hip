@@ -1,0 +1,1028 @@
+// prover.hip — keygen and create_proof on the device-resident engine.
+//
+// Host orchestration (C++) of the kernels in msm.hip / ntt.hip / quotient.hip /
+// prover_kernels.hip / poly.hip, mirroring halo2_proofs `plonk::keygen_vk`,
+// `keygen_pk` and `plonk::create_proof` as the reference calls them:
+//   keygen        halo2-circuits/src/ecc/ecdsa_p256.rs:259-260
+//   create_proof  halo2-circuits/src/ecc/ecdsa_p256.rs:366-373 (EvmTranscript + ProverGWC)
+//                 halo2-circuits/src/ecc/ecdsa_p256.rs:416-423 (Blake2bWrite + ProverSHPLONK)
+// Phase structure, transcript order and RNG draw order: SURVEY.md §3.3 / App. A.3
+// (the test oracle restates the same flow in Python; proofs are byte-compared against it).
+// Polynomials never leave HBM: the host sees commitments (64 B), evaluations
+// (32 B) and challenges only.  Randomness is a ChaCha20 stream (rand_chacha's
+// ChaCha20Rng layout): one 64-byte block per Fr::random, drawn on the host for
+// the handful of blinding rows and on the device for the n-coefficient random
+// polynomial — the engine's kernels themselves consume no randomness.
+#include <algorithm>
+
+#include "ctx.h"
+#include "prover.h"
+#include "transcript.h"
+
+using namespace zk;
+
+namespace {
+
+struct Col {
+    int fixed;  // 1 = fixed column, 0 = advice
+    uint32_t idx;
+};
+
+struct Layout {
+    uint32_t k, n, A, L, F, lookup_bits;
+    bool single;
+    uint32_t n_gate, n_lookup_cols, n_adv, fx_table, fx_qlookup, n_fix;
+    std::vector<uint32_t> fx_sel;
+    std::vector<Col> perm_cols;
+    uint32_t n_lookups, degree, chunk_len, n_chunks, n_h, ext_k, usable;
+    int last_rot;
+    std::vector<std::pair<uint32_t, int>> advice_queries;
+
+    bool init(const zk_circuit_params& p) {
+        k = p.k; A = p.num_advice; L = p.num_lookup_advice; F = p.num_fixed; lookup_bits = p.lookup_bits;
+        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1) return false;
+        n = 1u << k;
+        single = A == 1;
+        n_gate = A;
+        n_lookup_cols = single ? 0 : L;
+        n_adv = A + n_lookup_cols;
+        fx_table = F;
+        fx_sel.clear();
+        if (single) {
+            fx_sel.push_back(F + 1);
+            fx_qlookup = F + 2;
+            n_fix = F + 3;
+        } else {
+            for (uint32_t j = 0; j < A; j++) fx_sel.push_back(F + 1 + j);
+            fx_qlookup = 0;
+            n_fix = F + 1 + A;
+        }
+        perm_cols.clear();
+        for (uint32_t f = 0; f < F; f++) perm_cols.push_back(Col{1, f});
+        for (uint32_t j = 0; j < n_adv; j++) perm_cols.push_back(Col{0, j});
+        n_lookups = single ? 1 : L;
+        degree = single ? 5 : 4;
+        chunk_len = degree - 2;
+        n_chunks = ((uint32_t)perm_cols.size() + chunk_len - 1) / chunk_len;
+        n_h = degree - 1;
+        ext_k = k + 2;
+        usable = n - (BLINDING_FACTORS + 1);
+        last_rot = -(int)(BLINDING_FACTORS + 1);
+        advice_queries.clear();
+        for (uint32_t j = 0; j < A; j++)
+            for (int r = 0; r < 4; r++) advice_queries.push_back({j, r});
+        for (uint32_t l = 0; l < n_lookup_cols; l++) advice_queries.push_back({A + l, 0});
+        if ((1u << lookup_bits) >= usable) return false;
+        return n_adv <= MAX_ADV && n_fix <= MAX_FIX && perm_cols.size() <= MAX_PERM && n_chunks <= MAX_CHUNKS &&
+               n_lookups <= MAX_LOOKUPS;
+    }
+};
+
+}  // namespace
+
+struct zk_pk_rec {
+    Layout lay;
+    std::vector<Fr*> dev;  // every device allocation (freed together)
+    std::vector<Fr*> fixed_val, fixed_poly, fixed_coset, sigma_val, sigma_poly, sigma_coset;
+    Fr *l0_coset = nullptr, *l_last_coset = nullptr, *l_active_coset = nullptr;
+    std::vector<G1Affine> fixed_commit, perm_commit;
+    Fr transcript_repr;
+    // prover workspace
+    std::vector<Fr*> adv_val, adv_poly, adv_coset;
+    std::vector<Fr*> z_val, z_poly, z_coset;
+    std::vector<Fr*> lk_in, lk_ap, lk_ap_poly, lk_ap_coset, lk_sp, lk_sp_poly, lk_sp_coset, lk_z, lk_z_poly, lk_z_coset,
+        lk_in_coset;
+    Fr *random_poly = nullptr, *h_ext = nullptr, *h_comb = nullptr;
+    Fr *t_num = nullptr, *t_den = nullptr, *t_frac = nullptr, *t_a = nullptr, *t_b = nullptr, *t_small = nullptr;
+    Fr* tail_host = nullptr;  // pinned staging for blinding rows / scalars
+    LookupScratch lks{};
+    uint32_t* lk_u32 = nullptr;
+    QuotientArgs* d_qargs = nullptr;
+};
+
+namespace {
+
+// ---------------------------------------------------------------- kernels ---
+__global__ void sigma_kernel(const uint2* __restrict__ map, const Fr* __restrict__ tw, const Fr* __restrict__ dpow,
+                             Fr* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 m = map[i];
+    fe_store(out + i, fe_mul(fe_load(dpow + m.x), fe_load(tw + m.y)));
+}
+
+// ------------------------------------------------------------ small utils ---
+struct Dev {
+    zk_ctx* c;
+    zk_pk_rec* pk;
+    int rc = ZK_OK;
+
+    Fr* alloc(size_t n) {
+        Fr* p = nullptr;
+        if (rc) return nullptr;
+        if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
+            rc = ZK_ENOMEM;
+            return nullptr;
+        }
+        pk->dev.push_back(p);
+        return p;
+    }
+};
+
+bool commit(zk_ctx* c, const Fr* poly, size_t len, int basis, G1Affine* out) {
+    G1Jac j;
+    if (ctx_msm_device(c, poly, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, len, &j) != ZK_OK) return false;
+    *out = g1_jac_to_affine_host(j);
+    return true;
+}
+
+Fr fr_pow(Fr a, uint64_t e) { return fe_pow_u64(a, e); }
+
+Fr fr_delta() {  // 7^(2^28): generator of the odd-order subgroup
+    Fr d = fr_from_u64(7);
+    for (int i = 0; i < 28; i++) d = fe_sqr(d);
+    return d;
+}
+
+void fr_to_le_bytes(const Fr& mont, uint8_t out[32]) {
+    const Fr c = fe_from_mont(mont);
+    memcpy(out, c.v, 32);
+}
+
+// Integer order of canonical values (halo2curves Fr: Ord)
+bool fr_less(const Fr& a_mont, const Fr& b_mont) {
+    const Fr a = fe_from_mont(a_mont), b = fe_from_mont(b_mont);
+    for (int i = 7; i >= 0; i--) {
+        if (a.v[i] != b.v[i]) return a.v[i] < b.v[i];
+    }
+    return false;
+}
+
+std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evals) {
+    const size_t m = pts.size();
+    std::vector<Fr> coeffs(m, Fr::zero());
+    for (size_t j = 0; j < m; j++) {
+        std::vector<Fr> num(1, Fr::one());
+        Fr den = Fr::one();
+        for (size_t i = 0; i < m; i++) {
+            if (i == j) continue;
+            std::vector<Fr> nn(num.size() + 1, Fr::zero());
+            for (size_t t = 0; t < num.size(); t++) {
+                nn[t + 1] = fe_add(nn[t + 1], num[t]);
+                nn[t] = fe_sub(nn[t], fe_mul(pts[i], num[t]));
+            }
+            num.swap(nn);
+            den = fe_mul(den, fe_sub(pts[j], pts[i]));
+        }
+        const Fr sc = fe_mul(evals[j], fe_inv(den));
+        for (size_t t = 0; t < m; t++) coeffs[t] = fe_add(coeffs[t], fe_mul(num[t], sc));
+    }
+    return coeffs;
+}
+
+Fr eval_small(const std::vector<Fr>& c, const Fr& x) {
+    Fr acc = Fr::zero();
+    for (size_t i = c.size(); i-- > 0;) acc = fe_add(fe_mul(acc, x), c[i]);
+    return acc;
+}
+
+Fr vanishing_eval(const std::vector<Fr>& pts, const Fr& x) {
+    Fr acc = Fr::one();
+    for (const Fr& p : pts) acc = fe_mul(acc, fe_sub(x, p));
+    return acc;
+}
+
+}  // namespace
+
+void pk_destroy(zk_pk_rec* pk) {
+    if (!pk) return;
+    for (Fr* p : pk->dev) hipFree(p);
+    if (pk->tail_host) hipHostFree(pk->tail_host);
+    if (pk->lk_u32) hipFree(pk->lk_u32);
+    if (pk->d_qargs) hipFree(pk->d_qargs);
+    delete pk;
+}
+
+void pk_destroy_all(zk_ctx* c) {
+    for (auto& kv : c->pks) pk_destroy(kv.second);
+    c->pks.clear();
+}
+
+// =================================================================== keygen ==
+
+extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint64_t* fixed_canonical,
+                         const uint32_t* copies, size_t n_copies, zk_pk* out) {
+    if (!c || !params || !fixed_canonical || !out || (n_copies && !copies)) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    Layout lay;
+    if (!lay.init(*params)) return ZK_EINVAL;
+    if (c->srs_k != (int)lay.k) return ZK_ESTATE;
+    const uint32_t n = lay.n, N = 4 * n, T = 1u << lay.lookup_bits;
+    // the lookup path is specialised to halo2-lib's range table: 0..T-1 then zeros
+    {
+        const uint64_t* tab = fixed_canonical + (size_t)lay.fx_table * n * 4;
+        for (uint32_t r = 0; r < n; r++) {
+            const uint64_t want = r < T ? r : 0;
+            if (tab[4 * r] != want || tab[4 * r + 1] || tab[4 * r + 2] || tab[4 * r + 3]) return ZK_EINVAL;
+        }
+    }
+    const uint32_t m = (uint32_t)lay.perm_cols.size();
+    for (size_t i = 0; i < n_copies; i++) {
+        const uint32_t* e = copies + 4 * i;
+        if (e[0] >= m || e[2] >= m || e[1] >= lay.usable || e[3] >= lay.usable) return ZK_EINVAL;
+    }
+    zk_pk_rec* pk = new (std::nothrow) zk_pk_rec();
+    if (!pk) return ZK_ENOMEM;
+    pk->lay = lay;
+    Dev d{c, pk};
+    hipStream_t st = c->stream;
+    const Fr* tw = nullptr;
+    const Fr* tw_ext = nullptr;
+    if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) {
+        pk_destroy(pk);
+        return rc;
+    }
+    auto fail = [&](int code) {
+        hipStreamSynchronize(st);
+        pk_destroy(pk);
+        return code;
+    };
+
+    // ---- fixed columns: values -> commitment, coefficients, extended coset
+    for (uint32_t f = 0; f < lay.n_fix; f++) {
+        Fr *v = d.alloc(n), *p = d.alloc(n), *e = d.alloc(N);
+        if (d.rc) return fail(d.rc);
+        pk->fixed_val.push_back(v);
+        pk->fixed_poly.push_back(p);
+        pk->fixed_coset.push_back(e);
+        hipMemcpyAsync(v, fixed_canonical + (size_t)f * n * 4, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st);
+        launch_to_mont(v, n, st);
+    }
+    // ---- permutation: halo2 permutation::keygen::Assembly (cycle merging), then sigma = delta^c' w^r'
+    {
+        std::vector<uint2> mapping((size_t)m * n), aux((size_t)m * n);
+        std::vector<uint32_t> sizes((size_t)m * n, 1);
+        for (uint32_t col = 0; col < m; col++)
+            for (uint32_t r = 0; r < n; r++) mapping[(size_t)col * n + r] = aux[(size_t)col * n + r] = make_uint2(col, r);
+        auto at = [&](uint2 p) { return (size_t)p.x * n + p.y; };
+        auto same = [](uint2 a, uint2 b) { return a.x == b.x && a.y == b.y; };
+        for (size_t i = 0; i < n_copies; i++) {
+            uint2 l = make_uint2(copies[4 * i], copies[4 * i + 1]), r = make_uint2(copies[4 * i + 2], copies[4 * i + 3]);
+            uint2 lc = aux[at(l)], rc2 = aux[at(r)];
+            if (same(lc, rc2)) continue;
+            if (sizes[at(lc)] < sizes[at(rc2)]) {
+                std::swap(lc, rc2);
+                std::swap(l, r);
+            }
+            sizes[at(lc)] += sizes[at(rc2)];
+            uint2 it = rc2;
+            for (;;) {
+                aux[at(it)] = lc;
+                it = mapping[at(it)];
+                if (same(it, rc2)) break;
+            }
+            std::swap(mapping[at(l)], mapping[at(r)]);
+        }
+        std::vector<Fr> dpow(m);
+        Fr dl = Fr::one();
+        const Fr delta = fr_delta();
+        for (uint32_t col = 0; col < m; col++) {
+            dpow[col] = dl;
+            dl = fe_mul(dl, delta);
+        }
+        uint2* d_map = nullptr;
+        Fr* d_dpow = d.alloc(m);
+        if (d.rc || hipMalloc(&d_map, (size_t)n * sizeof(uint2)) != hipSuccess) return fail(ZK_ENOMEM);
+        hipMemcpyAsync(d_dpow, dpow.data(), m * sizeof(Fr), hipMemcpyHostToDevice, st);
+        for (uint32_t col = 0; col < m; col++) {
+            Fr *v = d.alloc(n), *p = d.alloc(n), *e = d.alloc(N);
+            if (d.rc) {
+                hipFree(d_map);
+                return fail(d.rc);
+            }
+            pk->sigma_val.push_back(v);
+            pk->sigma_poly.push_back(p);
+            pk->sigma_coset.push_back(e);
+            hipMemcpyAsync(d_map, &mapping[(size_t)col * n], (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, st);
+            hipLaunchKernelGGL(sigma_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_map, tw, d_dpow, v, n);
+            hipStreamSynchronize(st);  // d_map is reused
+        }
+        hipFree(d_map);
+    }
+    // ---- commitments (vk) and polynomial forms (pk)
+    auto finish_col = [&](Fr* v, Fr* p, Fr* e, G1Affine* cm) -> int {
+        if (!commit(c, v, n, ZK_BASIS_LAGRANGE, cm)) return ZK_EHIP;
+        hipMemcpyAsync(p, v, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
+        int r2 = ctx_ntt(c, p, n, p, lay.k, true, false, n);
+        if (r2) return r2;
+        return ctx_ntt(c, p, n, e, lay.ext_k, false, true, N);
+    };
+    pk->fixed_commit.resize(lay.n_fix);
+    pk->perm_commit.resize(m);
+    for (uint32_t f = 0; f < lay.n_fix; f++)
+        if ((rc = finish_col(pk->fixed_val[f], pk->fixed_poly[f], pk->fixed_coset[f], &pk->fixed_commit[f]))) return fail(rc);
+    for (uint32_t col = 0; col < m; col++)
+        if ((rc = finish_col(pk->sigma_val[col], pk->sigma_poly[col], pk->sigma_coset[col], &pk->perm_commit[col]))) return fail(rc);
+    // ---- l_0, l_last, l_active (= 1 - l_last - l_blind) cosets
+    {
+        std::vector<Fr> tmp(n, Fr::zero());
+        Fr* scratch_n = d.alloc(n);
+        pk->l0_coset = d.alloc(N);
+        pk->l_last_coset = d.alloc(N);
+        pk->l_active_coset = d.alloc(N);
+        if (d.rc) return fail(d.rc);
+        auto make = [&](Fr* dst) -> int {
+            hipMemcpyAsync(scratch_n, tmp.data(), (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);
+            int r2 = ctx_ntt(c, scratch_n, n, scratch_n, lay.k, true, false, n);
+            if (r2) return r2;
+            return ctx_ntt(c, scratch_n, n, dst, lay.ext_k, false, true, N);
+        };
+        tmp[0] = Fr::one();
+        if ((rc = make(pk->l0_coset))) return fail(rc);
+        tmp[0] = Fr::zero();
+        tmp[lay.usable] = Fr::one();  // row n - (bf + 1)
+        if ((rc = make(pk->l_last_coset))) return fail(rc);
+        for (uint32_t r = 0; r < n; r++) tmp[r] = r < lay.usable ? Fr::one() : Fr::zero();
+        if ((rc = make(pk->l_active_coset))) return fail(rc);
+    }
+    // ---- transcript_repr: stand-in for halo2's pinned-vk hash (same rule as the oracle's keygen)
+    {
+        Blake2b h("zkmi355-vk-repr");
+        const uint8_t hdr[5] = {(uint8_t)lay.k, (uint8_t)lay.A, (uint8_t)lay.L, (uint8_t)lay.F, (uint8_t)lay.lookup_bits};
+        h.update(hdr, 5);
+        auto absorb = [&](const G1Affine& p) {
+            const Fq x = fe_from_mont(p.x), y = fe_from_mont(p.y);
+            h.update((const uint8_t*)x.v, 32);
+            h.update((const uint8_t*)y.v, 32);
+        };
+        for (auto& p : pk->fixed_commit) absorb(p);
+        for (auto& p : pk->perm_commit) absorb(p);
+        uint8_t dg[64];
+        h.finalize_copy(dg);
+        pk->transcript_repr = fr_from_u512_le(dg);
+    }
+    // ---- prover workspace
+    for (uint32_t j = 0; j < lay.n_adv; j++) {
+        pk->adv_val.push_back(d.alloc(n));
+        pk->adv_poly.push_back(d.alloc(n));
+        pk->adv_coset.push_back(d.alloc(N));
+    }
+    for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+        pk->z_val.push_back(d.alloc(n));
+        pk->z_poly.push_back(d.alloc(n));
+        pk->z_coset.push_back(d.alloc(N));
+    }
+    for (uint32_t l = 0; l < lay.n_lookups; l++) {
+        pk->lk_in.push_back(lay.single ? d.alloc(n) : nullptr);
+        pk->lk_ap.push_back(d.alloc(n));
+        pk->lk_ap_poly.push_back(d.alloc(n));
+        pk->lk_ap_coset.push_back(d.alloc(N));
+        pk->lk_sp.push_back(d.alloc(n));
+        pk->lk_sp_poly.push_back(d.alloc(n));
+        pk->lk_sp_coset.push_back(d.alloc(N));
+        pk->lk_z.push_back(d.alloc(n));
+        pk->lk_z_poly.push_back(d.alloc(n));
+        pk->lk_z_coset.push_back(d.alloc(N));
+    }
+    pk->random_poly = d.alloc(n);
+    pk->h_ext = d.alloc(N);
+    pk->h_comb = d.alloc(n);
+    pk->t_num = d.alloc(n);
+    pk->t_den = d.alloc(n);
+    pk->t_frac = d.alloc(n);
+    pk->t_a = d.alloc(n);
+    pk->t_b = d.alloc(n);
+    pk->t_small = d.alloc(n / 16 + 4096);
+    if (d.rc) return fail(d.rc);
+    if (hipHostMalloc(&pk->tail_host, 64 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipMalloc(&pk->lk_u32, (size_t)(T + 2) * 6 * 4 + 16) != hipSuccess) return fail(ZK_ENOMEM);
+    {
+        uint32_t* b = pk->lk_u32;
+        pk->lks.hist = b;
+        pk->lks.present = b + (T + 2);
+        pk->lks.absent = b + 2 * (T + 2);
+        pk->lks.off = b + 3 * (T + 2);
+        pk->lks.dex = b + 4 * (T + 2);
+        pk->lks.aex = b + 5 * (T + 2);
+        pk->lks.err = b + 6 * (T + 2);
+    }
+    if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
+    const uint64_t h = c->next_handle++;
+    c->pks[h] = pk;
+    *out = h;
+    return ZK_OK;
+}
+
+extern "C" int zk_pk_free(zk_ctx* c, zk_pk h) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    ctx_bind(c);
+    hipStreamSynchronize(c->stream);
+    pk_destroy(it->second);
+    c->pks.erase(it);
+    return ZK_OK;
+}
+
+extern "C" int zk_vk_export(zk_ctx* c, zk_pk h, uint64_t* fixed_commitments, uint64_t* perm_commitments,
+                            uint64_t transcript_repr[4], uint32_t counts[2]) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    zk_pk_rec* pk = it->second;
+    if (counts) {
+        counts[0] = (uint32_t)pk->fixed_commit.size();
+        counts[1] = (uint32_t)pk->perm_commit.size();
+    }
+    if (fixed_commitments) memcpy(fixed_commitments, pk->fixed_commit.data(), pk->fixed_commit.size() * sizeof(G1Affine));
+    if (perm_commitments) memcpy(perm_commitments, pk->perm_commit.data(), pk->perm_commit.size() * sizeof(G1Affine));
+    if (transcript_repr) memcpy(transcript_repr, &pk->transcript_repr, 32);
+    return ZK_OK;
+}
+
+// ==================================================================== prove ==
+
+namespace {
+
+struct Prover {
+    zk_ctx* c;
+    zk_pk_rec* pk;
+    const Layout& lay;
+    hipStream_t st;
+    ChaCha20Rng rng;
+    Transcript* tr;
+    uint32_t n, N;
+    const Fr *tw, *tw_ext;
+    Fr omega, omega_inv;
+    int rc = ZK_OK;
+
+    Prover(zk_ctx* c_, zk_pk_rec* pk_, const uint8_t seed[32], Transcript* t)
+        : c(c_), pk(pk_), lay(pk_->lay), st(c_->stream), rng(seed), tr(t), n(pk_->lay.n), N(4 * pk_->lay.n) {}
+
+    bool ok() const { return rc == ZK_OK; }
+    void fail(int code) {
+        if (rc == ZK_OK) rc = code;
+    }
+
+    // ---- device helpers
+    void set_rows(Fr* col, uint32_t first, const std::vector<Fr>& vals) {
+        memcpy(pk->tail_host, vals.data(), vals.size() * sizeof(Fr));
+        if (hipMemcpyAsync(col + first, pk->tail_host, vals.size() * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            fail(ZK_EHIP);
+    }
+    std::vector<Fr> draw(uint32_t count) {
+        std::vector<Fr> v(count);
+        for (auto& x : v) x = rng.next_fr();
+        return v;
+    }
+    void commit_write(const Fr* poly, size_t len, int basis) {
+        if (!ok()) return;
+        G1Affine p;
+        if (!commit(c, poly, len, basis, &p)) return fail(ZK_EHIP);
+        if (!tr->write_point(p)) fail(ZK_EINVAL);  // identity commitment: halo2 refuses to write it
+    }
+    void to_coeff(const Fr* val, Fr* poly) {
+        if (!ok()) return;
+        hipMemcpyAsync(poly, val, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
+        int r = ctx_ntt(c, poly, n, poly, lay.k, true, false, n);
+        if (r) fail(r);
+    }
+    void to_coset(const Fr* poly, Fr* coset) {
+        if (!ok()) return;
+        int r = ctx_ntt(c, poly, n, coset, lay.ext_k, false, true, N);
+        if (r) fail(r);
+    }
+    Fr eval(const Fr* poly, uint32_t len, const Fr& x) {
+        if (!ok()) return Fr::zero();
+        const uint32_t blocks = eval_blocks(len);
+        launch_eval(poly, len, x, c->small, st);
+        if (hipMemcpyAsync(c->host_small, c->small + blocks, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            fail(ZK_EHIP);
+            return Fr::zero();
+        }
+        return *c->host_small;
+    }
+    Fr xrot(const Fr& x, int r) const {
+        Fr w = r >= 0 ? omega : omega_inv;
+        return fe_mul(x, fr_pow(w, (uint64_t)(r >= 0 ? r : -r)));
+    }
+    const Fr* col_val(const Col& col) const { return col.fixed ? pk->fixed_val[col.idx] : pk->adv_val[col.idx]; }
+    const Fr* col_coset(const Col& col) const { return col.fixed ? pk->fixed_coset[col.idx] : pk->adv_coset[col.idx]; }
+
+    // ------------------------------------------------------------------ run ---
+    int run(const Fr* const* advice_dev, int scheme) {
+        if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
+        omega = fr_omega(lay.k);
+        omega_inv = fe_inv(omega);
+        const uint32_t bf = BLINDING_FACTORS, usable = lay.usable;
+        tr->common_scalar(pk->transcript_repr);
+
+        // -- 1. advice
+        for (uint32_t j = 0; j < lay.n_adv; j++) {
+            hipMemcpyAsync(pk->adv_val[j], advice_dev[j], (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
+            set_rows(pk->adv_val[j], usable, draw(bf + 1));
+        }
+        draw(lay.n_adv);  // advice blinds (unused by KZG, still drawn)
+        for (uint32_t j = 0; j < lay.n_adv && ok(); j++) commit_write(pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+        if (!ok()) return rc;
+        const Fr theta = tr->squeeze();
+        (void)theta;  // single-expression lookups: theta-compression is the identity
+
+        // -- 2. lookups: permuted input / table
+        const uint32_t T = 1u << lay.lookup_bits;
+        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
+            const Fr* inp;
+            if (lay.single) {
+                launch_mul(pk->lk_in[l], pk->fixed_val[lay.fx_qlookup], pk->adv_val[0], n, st);
+                inp = pk->lk_in[l];
+            } else {
+                inp = pk->adv_val[lay.n_gate + l];
+            }
+            launch_lookup_permute(inp, usable, T, pk->lks, pk->lk_ap[l], pk->lk_sp[l], st);
+            uint32_t err = 0;
+            if (hipMemcpyAsync(&err, pk->lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return ZK_EHIP;
+            if (err) return ZK_EWITNESS;  // lookup input not in table (halo2: ConstraintSystemFailure)
+            set_rows(pk->lk_ap[l], usable, draw(bf + 1));
+            set_rows(pk->lk_sp[l], usable, draw(bf + 1));
+            draw(2);
+            commit_write(pk->lk_ap[l], n, ZK_BASIS_LAGRANGE);
+            commit_write(pk->lk_sp[l], n, ZK_BASIS_LAGRANGE);
+        }
+        if (!ok()) return rc;
+        const Fr beta = tr->squeeze();
+        const Fr gamma = tr->squeeze();
+
+        // -- 3. permutation grand products
+        {
+            const Fr delta = fr_delta();
+            Fr dcur = Fr::one();
+            for (uint32_t ci = 0; ci < lay.n_chunks && ok(); ci++) {
+                PermArgs a;
+                memset(&a, 0, sizeof(a));
+                a.n = n;
+                const uint32_t lo = ci * lay.chunk_len, hi = std::min<uint32_t>((uint32_t)lay.perm_cols.size(), lo + lay.chunk_len);
+                a.ncols = hi - lo;
+                for (uint32_t p = lo; p < hi; p++) {
+                    a.values[p - lo] = col_val(lay.perm_cols[p]);
+                    a.sigma[p - lo] = pk->sigma_val[p];
+                    a.delta[p - lo] = dcur;
+                    dcur = fe_mul(dcur, delta);
+                }
+                a.tw = tw;
+                a.beta = beta;
+                a.gamma = gamma;
+                a.num = pk->t_num;
+                a.den = pk->t_den;
+                launch_perm_numden(a, st);
+                launch_frac(pk->t_num, pk->t_den, pk->t_frac, n, st);
+                // z[0] = previous chunk's z at row `usable` (or 1)
+                const Fr* init_dev = ci ? pk->z_val[ci - 1] + usable : nullptr;
+                launch_prefix_product(pk->t_frac, pk->z_val[ci], n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
+                set_rows(pk->z_val[ci], n - bf, draw(bf));
+                draw(1);
+                commit_write(pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
+            }
+        }
+        // -- 4. lookup grand products
+        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
+            const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
+            launch_lk_numden(pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], beta, gamma, pk->t_num, pk->t_den, n, st);
+            launch_frac(pk->t_num, pk->t_den, pk->t_frac, n, st);
+            launch_prefix_product(pk->t_frac, pk->lk_z[l], n, nullptr, Fr::one(), pk->t_a, pk->t_small, st);
+            set_rows(pk->lk_z[l], n - bf, draw(bf));
+            draw(1);
+            commit_write(pk->lk_z[l], n, ZK_BASIS_LAGRANGE);
+        }
+        if (!ok()) return rc;
+
+        // -- 5. vanishing argument: random polynomial (n draws, generated on the device from the same stream)
+        {
+            ChaChaKey key;
+            memcpy(key.w, rng.key, 32);
+            launch_chacha_fr(key, rng.block, pk->random_poly, n, st);
+            rng.block += n;
+            draw(1);
+            commit_write(pk->random_poly, n, ZK_BASIS_MONOMIAL);
+        }
+        if (!ok()) return rc;
+        const Fr y = tr->squeeze();
+
+        // -- 6. quotient
+        for (uint32_t j = 0; j < lay.n_adv && ok(); j++) {
+            to_coeff(pk->adv_val[j], pk->adv_poly[j]);
+            to_coset(pk->adv_poly[j], pk->adv_coset[j]);
+        }
+        for (uint32_t ci = 0; ci < lay.n_chunks && ok(); ci++) {
+            to_coeff(pk->z_val[ci], pk->z_poly[ci]);
+            to_coset(pk->z_poly[ci], pk->z_coset[ci]);
+        }
+        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
+            to_coeff(pk->lk_ap[l], pk->lk_ap_poly[l]);
+            to_coset(pk->lk_ap_poly[l], pk->lk_ap_coset[l]);
+            to_coeff(pk->lk_sp[l], pk->lk_sp_poly[l]);
+            to_coset(pk->lk_sp_poly[l], pk->lk_sp_coset[l]);
+            to_coeff(pk->lk_z[l], pk->lk_z_poly[l]);
+            to_coset(pk->lk_z_poly[l], pk->lk_z_coset[l]);
+        }
+        if (!ok()) return rc;
+        {
+            QuotientArgs q;
+            memset(&q, 0, sizeof(q));
+            q.log_ext = lay.ext_k;
+            q.n_gate = lay.n_gate;
+            q.n_adv = lay.n_adv;
+            q.n_chunks = lay.n_chunks;
+            q.chunk_len = lay.chunk_len;
+            q.n_perm = (uint32_t)lay.perm_cols.size();
+            q.n_lookups = lay.n_lookups;
+            q.single = lay.single ? 1 : 0;
+            q.last_rot = lay.last_rot;
+            q.fx_table = lay.fx_table;
+            q.fx_qlookup = lay.fx_qlookup;
+            for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = pk->adv_coset[j];
+            for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
+            for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.fx_sel[j];
+            const Fr delta = fr_delta();
+            Fr dcur = beta;
+            for (uint32_t p = 0; p < q.n_perm; p++) {
+                q.sigma[p] = pk->sigma_coset[p];
+                q.perm_val[p] = col_coset(lay.perm_cols[p]);
+                q.delta_pow[p] = dcur;
+                dcur = fe_mul(dcur, delta);
+            }
+            for (uint32_t ci = 0; ci < lay.n_chunks; ci++) q.z[ci] = pk->z_coset[ci];
+            for (uint32_t l = 0; l < lay.n_lookups; l++) {
+                q.lk_z[l] = pk->lk_z_coset[l];
+                q.lk_a[l] = pk->lk_ap_coset[l];
+                q.lk_s[l] = pk->lk_sp_coset[l];
+                q.lk_in[l] = lay.single ? nullptr : pk->adv_coset[lay.n_gate + l];
+            }
+            q.l0 = pk->l0_coset;
+            q.l_last = pk->l_last_coset;
+            q.l_active = pk->l_active_coset;
+            q.tw_ext = tw_ext;
+            q.zeta = c->zeta;
+            q.beta = beta;
+            q.gamma = gamma;
+            q.y = y;
+            // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
+            const Fr zn = fr_pow(c->zeta, n);
+            const Fr w4 = fr_pow(fr_omega(lay.ext_k), n);
+            Fr cur = zn;
+            for (int i = 0; i < 4; i++) {
+                q.t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
+                cur = fe_mul(cur, w4);
+            }
+            q.out = pk->h_ext;
+            hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
+            hipMemcpyAsync(pk->d_qargs, &q, sizeof(q), hipMemcpyHostToDevice, st);
+            launch_quotient_dev(pk->d_qargs, lay.ext_k, st);
+            hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
+            c->ev_valid[ZK_T_QUOTIENT] = true;
+            int r = ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
+            if (r) return r;
+        }
+        draw(lay.n_h);  // h-piece blinds
+        for (uint32_t i = 0; i < lay.n_h && ok(); i++) commit_write(pk->h_ext + (size_t)i * n, n, ZK_BASIS_MONOMIAL);
+        if (!ok()) return rc;
+        const Fr x = tr->squeeze();
+
+        // -- 7. evaluations
+        struct Q {
+            const Fr* poly;
+            int rot;
+            Fr eval;
+        };
+        std::vector<Q> queries;  // prover query order (== verifier's)
+        std::vector<Q> adv_q, fix_q, sig_q, z_q, lk_q;
+        for (auto& aq : lay.advice_queries) {
+            Q qq{pk->adv_poly[aq.first], aq.second, eval(pk->adv_poly[aq.first], n, xrot(x, aq.second))};
+            tr->write_scalar(qq.eval);
+            adv_q.push_back(qq);
+        }
+        for (uint32_t f = 0; f < lay.n_fix; f++) {
+            Q qq{pk->fixed_poly[f], 0, eval(pk->fixed_poly[f], n, x)};
+            tr->write_scalar(qq.eval);
+            fix_q.push_back(qq);
+        }
+        // h(X) = sum x^(n i) h_i(X)
+        const Fr xn = fr_pow(x, n);
+        {
+            LincombArgs a;
+            memset(&a, 0, sizeof(a));
+            a.out = pk->h_comb;
+            a.n = n;
+            a.count = lay.n_h;
+            Fr p = Fr::one();
+            for (uint32_t i = 0; i < lay.n_h; i++) {
+                a.in[i] = pk->h_ext + (size_t)i * n;
+                a.len[i] = n;
+                a.c[i] = p;
+                a.unit[i] = i == 0;
+                p = fe_mul(p, xn);
+            }
+            launch_lincomb(a, st);
+        }
+        const Q rand_q{pk->random_poly, 0, eval(pk->random_poly, n, x)};
+        tr->write_scalar(rand_q.eval);
+        for (uint32_t p = 0; p < lay.perm_cols.size(); p++) {
+            Q qq{pk->sigma_poly[p], 0, eval(pk->sigma_poly[p], n, x)};
+            tr->write_scalar(qq.eval);
+            sig_q.push_back(qq);
+        }
+        std::vector<Q> z_last_q(lay.n_chunks);
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+            Q q0{pk->z_poly[ci], 0, eval(pk->z_poly[ci], n, x)};
+            Q q1{pk->z_poly[ci], 1, eval(pk->z_poly[ci], n, xrot(x, 1))};
+            tr->write_scalar(q0.eval);
+            tr->write_scalar(q1.eval);
+            z_q.push_back(q0);
+            z_q.push_back(q1);
+            if (ci != lay.n_chunks - 1) {
+                Q q2{pk->z_poly[ci], lay.last_rot, eval(pk->z_poly[ci], n, xrot(x, lay.last_rot))};
+                tr->write_scalar(q2.eval);
+                z_last_q[ci] = q2;
+            }
+        }
+        for (uint32_t l = 0; l < lay.n_lookups; l++) {
+            Q zq{pk->lk_z_poly[l], 0, eval(pk->lk_z_poly[l], n, x)};
+            Q zn_{pk->lk_z_poly[l], 1, eval(pk->lk_z_poly[l], n, xrot(x, 1))};
+            Q aq{pk->lk_ap_poly[l], 0, eval(pk->lk_ap_poly[l], n, x)};
+            Q am{pk->lk_ap_poly[l], -1, eval(pk->lk_ap_poly[l], n, xrot(x, -1))};
+            Q sq{pk->lk_sp_poly[l], 0, eval(pk->lk_sp_poly[l], n, x)};
+            tr->write_scalar(zq.eval);
+            tr->write_scalar(zn_.eval);
+            tr->write_scalar(aq.eval);
+            tr->write_scalar(am.eval);
+            tr->write_scalar(sq.eval);
+            // query order: zL@x, a'@x, s'@x, a'@w^-1 x, zL@wx
+            lk_q.push_back(zq);
+            lk_q.push_back(aq);
+            lk_q.push_back(sq);
+            lk_q.push_back(am);
+            lk_q.push_back(zn_);
+        }
+        if (!ok()) return rc;
+        const Q h_q{pk->h_comb, 0, eval(pk->h_comb, n, x)};
+        queries = adv_q;
+        queries.insert(queries.end(), z_q.begin(), z_q.end());
+        for (int ci = (int)lay.n_chunks - 2; ci >= 0; ci--) queries.push_back(z_last_q[ci]);
+        queries.insert(queries.end(), lk_q.begin(), lk_q.end());
+        queries.insert(queries.end(), fix_q.begin(), fix_q.end());
+        queries.insert(queries.end(), sig_q.begin(), sig_q.end());
+        queries.push_back(h_q);
+        queries.push_back(rand_q);
+        if (!ok()) return rc;
+
+        // -- 8. multi-open
+        if (scheme == ZK_SCHEME_GWC) {
+            const Fr v = tr->squeeze();
+            std::vector<std::pair<int, std::vector<Q>>> sets;
+            for (auto& qq : queries) {
+                bool found = false;
+                for (auto& s : sets)
+                    if (s.first == qq.rot) {
+                        s.second.push_back(qq);
+                        found = true;
+                        break;
+                    }
+                if (!found) sets.push_back({qq.rot, {qq}});
+            }
+            for (auto& s : sets) {
+                if (s.second.size() > MAX_LC) return ZK_EINVAL;
+                LincombArgs a;
+                memset(&a, 0, sizeof(a));
+                a.out = pk->t_a;
+                a.n = n;
+                a.count = (uint32_t)s.second.size();
+                Fr pv = Fr::one(), eb = Fr::zero();
+                for (uint32_t j = 0; j < a.count; j++) {
+                    a.in[j] = s.second[j].poly;
+                    a.len[j] = n;
+                    a.c[j] = pv;
+                    a.unit[j] = j == 0;
+                    eb = fe_add(eb, fe_mul(pv, s.second[j].eval));
+                    pv = fe_mul(pv, v);
+                }
+                a.sub0 = 1;
+                a.sub0_val = eb;
+                launch_lincomb(a, st);
+                launch_kate_division(pk->t_a, pk->t_b, n, xrot(x, s.first), pk->t_small, pk->t_small + (n / 32 + 8), st);
+                commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
+                if (!ok()) return rc;
+            }
+        } else {
+            // SHPLONK: group commitments by their set of rotations
+            struct CR {
+                const Fr* poly;
+                std::vector<int> rots;
+                std::vector<Fr> evals;
+            };
+            std::vector<CR> com;
+            for (auto& qq : queries) {
+                CR* hit = nullptr;
+                for (auto& cr : com)
+                    if (cr.poly == qq.poly) hit = &cr;
+                if (!hit) {
+                    com.push_back(CR{qq.poly, {}, {}});
+                    hit = &com.back();
+                }
+                hit->rots.push_back(qq.rot);
+                hit->evals.push_back(qq.eval);
+            }
+            auto pt_less = [&](int ra, int rb) { return fr_less(xrot(x, ra), xrot(x, rb)); };
+            struct RS {
+                std::vector<int> rots;  // sorted by point value (BTreeSet<Fr>)
+                std::vector<CR*> coms;
+            };
+            std::vector<RS> rsets;
+            std::vector<int> all_rots;
+            for (auto& cr : com) {
+                // sort this commitment's (rot, eval) pairs by point
+                std::vector<size_t> order(cr.rots.size());
+                for (size_t i = 0; i < order.size(); i++) order[i] = i;
+                std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pt_less(cr.rots[a], cr.rots[b]); });
+                std::vector<int> r2;
+                std::vector<Fr> e2;
+                for (size_t i : order) {
+                    r2.push_back(cr.rots[i]);
+                    e2.push_back(cr.evals[i]);
+                }
+                cr.rots = r2;
+                cr.evals = e2;
+                for (int r : cr.rots)
+                    if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
+                RS* hit = nullptr;
+                for (auto& rs : rsets)
+                    if (rs.rots == cr.rots) hit = &rs;
+                if (!hit) {
+                    rsets.push_back(RS{cr.rots, {}});
+                    hit = &rsets.back();
+                }
+                hit->coms.push_back(&cr);
+            }
+            std::sort(all_rots.begin(), all_rots.end(), pt_less);
+            const Fr yc = tr->squeeze();
+            const Fr v = tr->squeeze();
+            std::vector<std::vector<Fr>> low(com.size());
+            auto com_index = [&](CR* p) { return (size_t)(p - &com[0]); };
+            // h(X) = sum_i v^i * ( sum_j y^j (P_ij - R_ij) ) / Z_i
+            Fr pv = Fr::one();
+            Fr* hx = pk->t_frac;  // accumulates h(X)
+            bool first_set = true;
+            for (auto& rs : rsets) {
+                std::vector<Fr> pts;
+                for (int r : rs.rots) pts.push_back(xrot(x, r));
+                if (rs.coms.size() > MAX_LC) return ZK_EINVAL;
+                LincombArgs a;
+                memset(&a, 0, sizeof(a));
+                a.out = pk->t_a;
+                a.n = n;
+                a.count = (uint32_t)rs.coms.size();
+                std::vector<Fr> rsum(pts.size(), Fr::zero());
+                Fr py = Fr::one();
+                for (uint32_t j = 0; j < a.count; j++) {
+                    CR* cr = rs.coms[j];
+                    low[com_index(cr)] = lagrange_interpolate(pts, cr->evals);
+                    a.in[j] = cr->poly;
+                    a.len[j] = n;
+                    a.c[j] = py;
+                    a.unit[j] = j == 0;
+                    for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
+                    py = fe_mul(py, yc);
+                }
+                launch_lincomb(a, st);
+                // subtract sum_j y^j R_j(X) (degree < |set|) from the low coefficients
+                std::vector<Fr> lowc(pts.size());
+                if (hipMemcpyAsync(pk->tail_host, pk->t_a, pts.size() * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return ZK_EHIP;
+                for (size_t t = 0; t < pts.size(); t++) lowc[t] = fe_sub(pk->tail_host[t], rsum[t]);
+                set_rows(pk->t_a, 0, lowc);
+                Fr* src = pk->t_a;
+                Fr* dst = pk->t_b;
+                for (const Fr& z : pts) {
+                    launch_kate_division(src, dst, n, z, pk->t_small, pk->t_small + (n / 32 + 8), st);
+                    std::swap(src, dst);
+                }
+                LincombArgs acc;
+                memset(&acc, 0, sizeof(acc));
+                acc.out = hx;
+                acc.n = n;
+                acc.count = 1;
+                acc.accumulate = first_set ? 0 : 1;
+                acc.in[0] = src;
+                acc.len[0] = n;
+                acc.c[0] = pv;
+                acc.unit[0] = first_set ? 1 : 0;
+                launch_lincomb(acc, st);
+                first_set = false;
+                pv = fe_mul(pv, v);
+            }
+            commit_write(hx, n, ZK_BASIS_MONOMIAL);
+            if (!ok()) return rc;
+            const Fr u = tr->squeeze();
+            // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
+            LincombArgs a;
+            memset(&a, 0, sizeof(a));
+            a.out = pk->t_a;
+            a.n = n;
+            Fr sub = Fr::zero();
+            pv = Fr::one();
+            std::vector<Fr> z_diffs;
+            uint32_t cnt = 0;
+            for (auto& rs : rsets) {
+                std::vector<Fr> diffs;
+                for (int r : all_rots)
+                    if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(xrot(x, r));
+                const Fr zi = vanishing_eval(diffs, u);
+                z_diffs.push_back(zi);
+                Fr py = Fr::one();
+                for (CR* cr : rs.coms) {
+                    if (cnt + 1 >= MAX_LC) return ZK_EINVAL;
+                    const Fr coef = fe_mul(fe_mul(pv, zi), py);
+                    a.in[cnt] = cr->poly;
+                    a.len[cnt] = n;
+                    a.c[cnt] = coef;
+                    cnt++;
+                    sub = fe_add(sub, fe_mul(coef, eval_small(low[com_index(cr)], u)));
+                    py = fe_mul(py, yc);
+                }
+                pv = fe_mul(pv, v);
+            }
+            std::vector<Fr> all_pts;
+            for (int r : all_rots) all_pts.push_back(xrot(x, r));
+            const Fr zt = vanishing_eval(all_pts, u);
+            a.in[cnt] = hx;
+            a.len[cnt] = n;
+            a.c[cnt] = fe_neg(zt);
+            cnt++;
+            a.count = cnt;
+            a.sub0 = 1;
+            a.sub0_val = sub;
+            launch_lincomb(a, st);
+            launch_kate_division(pk->t_a, pk->t_b, n, u, pk->t_small, pk->t_small + (n / 32 + 8), st);
+            launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
+            commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
+        }
+        return rc;
+    }
+};
+
+}  // namespace
+
+extern "C" int zk_prove(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, const uint8_t rng_seed[32],
+                        int transcript, int scheme, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    if (!c || !advice || !rng_seed || !proof_len) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    zk_pk_rec* pk = it->second;
+    const Layout& lay = pk->lay;
+    if (n_advice != lay.n_adv || c->srs_k != (int)lay.k) return ZK_EINVAL;
+    if (transcript != ZK_TRANSCRIPT_BLAKE2B && transcript != ZK_TRANSCRIPT_EVM) return ZK_EINVAL;
+    if (scheme == ZK_SCHEME_DEFAULT) scheme = transcript == ZK_TRANSCRIPT_EVM ? ZK_SCHEME_GWC : ZK_SCHEME_SHPLONK;
+    if (scheme != ZK_SCHEME_GWC && scheme != ZK_SCHEME_SHPLONK) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    std::vector<const Fr*> adv(n_advice);
+    for (size_t j = 0; j < n_advice; j++) {
+        auto pit = c->polys.find(advice[j]);
+        if (pit == c->polys.end() || pit->second.n != lay.n) return ZK_EINVAL;
+        adv[j] = pit->second.ptr;
+    }
+    EvmTranscript evm;
+    Blake2bTranscript b2;
+    Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
+    Prover p(c, pk, rng_seed, tr);
+    rc = p.run(adv.data(), scheme);
+    hipStreamSynchronize(c->stream);
+    if (rc) return rc;
+    if (hipGetLastError() != hipSuccess) return ZK_EHIP;
+    *proof_len = tr->out.size();
+    if (!proof_out || proof_cap < tr->out.size()) return proof_out ? ZK_EINVAL : ZK_OK;
+    memcpy(proof_out, tr->out.data(), tr->out.size());
+    return ZK_OK;
+}
+
+extern "C" int zk_poly_upload_canonical(zk_ctx* c, zk_poly h, const uint64_t* host_canonical, size_t n) {
+    int rc = zk_poly_upload(c, h, host_canonical, n);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->polys.find(h);
+    if (it == c->polys.end()) return ZK_EINVAL;
+    if ((rc = ctx_bind(c))) return rc;
+    launch_to_mont(it->second.ptr, (uint32_t)n, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZK_EHIP;
+    return ZK_OK;
+}

@@ -1,0 +1,436 @@
+// prover_kernels.hip — the streaming / scan kernels between the MSMs and NTTs of
+// create_proof: Montgomery conversion, ChaCha20 field sampling, lookup
+// permutation (range table), permutation / lookup grand products (batch
+// inversion + prefix product), linear combinations and Kate division for the
+// multi-open argument.
+//
+// Device replacements for the host loops of halo2_proofs
+// `plonk/lookup/prover.rs` (permute_expression_pair, commit_product),
+// `plonk/permutation/prover.rs` (commit), `plonk/vanishing/prover.rs` (random
+// poly), `arithmetic::kate_division` and the polynomial sums in
+// `poly/kzg/multiopen/{gwc,shplonk}/prover.rs` (SURVEY.md §8a a9, §8f-2, §8f-3;
+// reached from halo2-circuits/src/ecc/ecdsa_p256.rs:366-373,416-423).
+#include "prover.h"
+
+namespace zk {
+
+// ------------------------------------------------------------ elementwise ---
+
+__global__ void to_mont_kernel(Fr* a, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(a + i, fe_to_mont(fe_load(a + i)));
+}
+void launch_to_mont(Fr* a, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(to_mont_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, n);
+}
+
+__global__ void mul_kernel(Fr* out, const Fr* a, const Fr* b, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(out + i, fe_mul(fe_load(a + i), fe_load(b + i)));
+}
+void launch_mul(Fr* out, const Fr* a, const Fr* b, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, a, b, n);
+}
+
+// out[i] = sum_j c[j] * in[j][i]  (+ out[i] if accumulate); in[j] may be shorter than n (zero-padded)
+__global__ void lincomb_kernel(LincombArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    Fr acc = a.accumulate ? fe_load(a.out + i) : Fr::zero();
+    for (uint32_t j = 0; j < a.count; j++) {
+        if (i < a.len[j]) {
+            const Fr v = fe_load(a.in[j] + i);
+            acc = fe_add(acc, a.unit[j] ? v : fe_mul(v, a.c[j]));
+        }
+    }
+    if (i == 0 && a.sub0) acc = fe_sub(acc, a.sub0_val);
+    fe_store(a.out + i, acc);
+}
+void launch_lincomb(const LincombArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(lincomb_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+}
+
+__global__ void scale_kernel(Fr* a, Fr c, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(a + i, fe_mul(fe_load(a + i), c));
+}
+void launch_scale(Fr* a, const Fr& c, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, c, n);
+}
+
+// -------------------------------------------------------------- ChaCha20 ----
+// out[i] = Fr::from_u512(keystream block (start + i)) — one Fr::random per 64-byte block.
+__device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define QR(a, b, c, d)                 \
+    a += b; d ^= a; d = rotl(d, 16);   \
+    c += d; b ^= c; b = rotl(b, 12);   \
+    a += b; d ^= a; d = rotl(d, 8);    \
+    c += d; b ^= c; b = rotl(b, 7);
+
+__global__ void chacha_fr_kernel(ChaChaKey key, uint64_t start_block, Fr* out, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t ctr = start_block + i;
+    uint32_t s[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[4 + k] = key.w[k];
+    s[12] = (uint32_t)ctr;
+    s[13] = (uint32_t)(ctr >> 32);
+    s[14] = 0;
+    s[15] = 0;
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = s[k];
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        QR(w[0], w[4], w[8], w[12]) QR(w[1], w[5], w[9], w[13]) QR(w[2], w[6], w[10], w[14]) QR(w[3], w[7], w[11], w[15])
+        QR(w[0], w[5], w[10], w[15]) QR(w[1], w[6], w[11], w[12]) QR(w[2], w[7], w[8], w[13]) QR(w[3], w[4], w[9], w[14])
+    }
+    Fr lo, hi;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo.v[k] = w[k] + s[k];
+        hi.v[k] = w[8 + k] + s[8 + k];
+    }
+    const Fr r2 = Fr::r2();
+    const Fr r3 = fe_mul(r2, r2);
+    fe_store(out + i, fe_add(fe_mul(r2, lo), fe_mul(r3, hi)));
+}
+void launch_chacha_fr(const ChaChaKey& key, uint64_t start_block, Fr* out, uint32_t count, hipStream_t st) {
+    hipLaunchKernelGGL(chacha_fr_kernel, dim3((count + 255) / 256), dim3(256), 0, st, key, start_block, out, count);
+}
+
+// ------------------------------------------------------------- u32 scans ----
+// exclusive scan of in[0..m) -> out[0..m], out[m] = total.  One block; m up to a few million.
+__global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t m) {
+    __shared__ uint32_t part[1024];
+    const uint32_t chunk = (m + 1023) / 1024;
+    const uint32_t lo = min(m, threadIdx.x * chunk), hi = min(m, lo + chunk);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += in[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= d) ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t h = in[i];
+        out[i] = run;
+        run += h;
+    }
+    if (threadIdx.x == 1023) out[m] = part[1023];
+}
+void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t st) {
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, out, m);
+}
+
+// ------------------------------------------------ lookup permutation --------
+// Range-table specialisation of permute_expression_pair: table column = 0..T-1 in
+// rows 0..T-1 and zeros up to the usable rows (halo2-lib RangeConfig; known answer
+// K2).  hist[v] = multiplicity of v in the first `usable` input rows; err set if an
+// input is not a table element (halo2: Error::ConstraintSystemFailure).
+__global__ void lk_hist_kernel(const Fr* __restrict__ inp, uint32_t usable, uint32_t T, uint32_t* __restrict__ hist,
+                               uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= usable) return;
+    const Fr v = fe_from_mont(fe_load(inp + i));
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) hi |= v.v[k];
+    if (hi || v.v[0] >= T) {
+        atomicOr(err, 1u);
+        return;
+    }
+    atomicAdd(&hist[v.v[0]], 1u);
+}
+
+// present[v] = hist[v] > 0 ; absent[v] = (v >= 1 && hist[v] == 0)
+__global__ void lk_flags_kernel(const uint32_t* __restrict__ hist, uint32_t T, uint32_t* __restrict__ present,
+                                uint32_t* __restrict__ absent) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= T) return;
+    const uint32_t h = hist[v];
+    present[v] = h > 0;
+    absent[v] = (v >= 1 && h == 0);
+}
+
+__device__ __forceinline__ Fr small_to_mont(uint32_t v) {
+    Fr a = Fr::zero();
+    a.v[0] = v;
+    return fe_to_mont(a);
+}
+
+// off: exclusive scan of hist (T+1); dex: exclusive scan of present (T+1); aex: exclusive scan of absent (T+1)
+__global__ void lk_fill_kernel(uint32_t usable, uint32_t T, const uint32_t* __restrict__ hist,
+                               const uint32_t* __restrict__ off, const uint32_t* __restrict__ dex,
+                               const uint32_t* __restrict__ aex, Fr* __restrict__ ap, Fr* __restrict__ sp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= usable) return;
+    // largest v with off[v] <= p
+    uint32_t lo = 0, hi = T - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t v = lo;
+    fe_store(ap + p, small_to_mont(v));
+    if (p == off[v]) {
+        fe_store(sp + p, small_to_mont(v));
+        return;
+    }
+    // repeated row: index j among repeated rows (ascending) = p - (#present values <= v)
+    const uint32_t D = dex[v] + 1;           // present values <= v (v itself is present)
+    const uint32_t j = p - D;
+    const uint32_t m = usable - dex[T];      // number of repeated rows = number of leftover table cells
+    const uint32_t q = m - 1 - j;            // leftovers ascending are handed to repeated rows descending
+    const uint32_t c0 = (usable - T + 1) - (hist[0] > 0 ? 1u : 0u);  // leftover zeros
+    if (q < c0) {
+        fe_store(sp + p, Fr::zero());
+        return;
+    }
+    const uint32_t t = q - c0 + 1;           // t-th absent value (1-based) among 1..T-1
+    // smallest v' with (#absent in [0..v']) >= t, i.e. aex[v'+1] >= t
+    uint32_t a = 1, b = T - 1;
+    while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (aex[mid + 1] >= t) b = mid; else a = mid + 1;
+    }
+    fe_store(sp + p, small_to_mont(a));
+}
+
+void launch_lookup_permute(const Fr* inp, uint32_t usable, uint32_t T, LookupScratch& s, Fr* ap, Fr* sp, hipStream_t st) {
+    hipMemsetAsync(s.hist, 0, (T + 1) * 4, st);
+    hipMemsetAsync(s.err, 0, 4, st);
+    hipLaunchKernelGGL(lk_hist_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, inp, usable, T, s.hist, s.err);
+    hipLaunchKernelGGL(lk_flags_kernel, dim3((T + 255) / 256), dim3(256), 0, st, s.hist, T, s.present, s.absent);
+    launch_scan_u32(s.hist, s.off, T, st);
+    launch_scan_u32(s.present, s.dex, T, st);
+    launch_scan_u32(s.absent, s.aex, T, st);
+    hipLaunchKernelGGL(lk_fill_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, usable, T, s.hist, s.off, s.dex, s.aex, ap, sp);
+}
+
+// -------------------------------------------------------- grand products ----
+
+// den[i] = prod_c (v_c[i] + beta*sigma_c[i] + gamma);  num[i] = prod_c (v_c[i] + delta_c * w^i * beta + gamma)
+__global__ void perm_numden_kernel(PermArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const Fr wi_beta = fe_mul(fe_load(a.tw + i), a.beta);
+    Fr num = Fr::one(), den = Fr::one();
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        const Fr v = fe_load(a.values[c] + i);
+        const Fr vg = fe_add(v, a.gamma);
+        den = fe_mul(den, fe_add(vg, fe_mul(a.beta, fe_load(a.sigma[c] + i))));
+        num = fe_mul(num, fe_add(vg, fe_mul(wi_beta, a.delta[c])));
+    }
+    fe_store(a.num + i, num);
+    fe_store(a.den + i, den);
+}
+void launch_perm_numden(const PermArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(perm_numden_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+}
+
+// den = (a' + beta)(s' + gamma); num = (in + beta)(tab + gamma)
+__global__ void lk_numden_kernel(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, Fr beta, Fr gamma, Fr* num,
+                                 Fr* den, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store(den + i, fe_mul(fe_add(fe_load(ap + i), beta), fe_add(fe_load(sp + i), gamma)));
+    fe_store(num + i, fe_mul(fe_add(fe_load(inp + i), beta), fe_add(fe_load(tab + i), gamma)));
+}
+void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, const Fr& beta, const Fr& gamma, Fr* num,
+                      Fr* den, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(lk_numden_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ap, sp, inp, tab, beta, gamma, num, den, n);
+}
+
+// frac[i] = num[i] / den[i]  (Montgomery's trick over 8 elements per thread; 0 -> 0 like batch_invert)
+__global__ void frac_kernel(const Fr* __restrict__ num, const Fr* __restrict__ den, Fr* __restrict__ frac, uint32_t n) {
+    constexpr int E = 8;
+    const uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) * E;
+    if (base >= n) return;
+    Fr d[E], pre[E];
+    Fr acc = Fr::one();
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        d[k] = (base + k < n) ? fe_load(den + base + k) : Fr::one();
+        pre[k] = acc;
+        if (!d[k].is_zero()) acc = fe_mul(acc, d[k]);
+    }
+    Fr inv = fe_inv(acc);
+#pragma unroll
+    for (int k = E - 1; k >= 0; k--) {
+        if (base + k < n) {
+            Fr r = Fr::zero();
+            if (!d[k].is_zero()) {
+                r = fe_mul(inv, pre[k]);
+                inv = fe_mul(inv, d[k]);
+            }
+            fe_store(frac + base + k, fe_mul(r, fe_load(num + base + k)));
+        }
+    }
+}
+void launch_frac(const Fr* num, const Fr* den, Fr* frac, uint32_t n, hipStream_t st) {
+    const uint32_t threads = (n + 7) / 8;
+    hipLaunchKernelGGL(frac_kernel, dim3((threads + 127) / 128), dim3(128), 0, st, num, den, frac, n);
+}
+
+// Prefix product: z[0] = init, z[i+1] = z[i] * f[i] for i < n-1.
+// pass 1: block-local inclusive products (2048 elements per block) + block totals
+// pass 2: one block turns the totals into exclusive block offsets (times init)
+// pass 3: z[i+1] = offset[block] * local[i]
+static constexpr uint32_t PP_E = 8, PP_T = 256, PP_B = PP_E * PP_T;
+
+__global__ __launch_bounds__(PP_T) void pp_local_kernel(const Fr* __restrict__ f, Fr* __restrict__ local, Fr* __restrict__ tot, uint32_t n) {
+    __shared__ Fr sh[PP_T];
+    const uint32_t base = blockIdx.x * PP_B + threadIdx.x * PP_E;
+    Fr v[PP_E];
+    Fr acc = Fr::one();
+#pragma unroll
+    for (uint32_t k = 0; k < PP_E; k++) {
+        if (base + k < n) acc = fe_mul(acc, fe_load(f + base + k));
+        v[k] = acc;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < PP_T; d <<= 1) {
+        Fr o = Fr::one();
+        const bool has = threadIdx.x >= d;
+        if (has) o = sh[threadIdx.x - d];
+        __syncthreads();
+        if (has) sh[threadIdx.x] = fe_mul(sh[threadIdx.x], o);
+        __syncthreads();
+    }
+    const Fr excl = threadIdx.x ? sh[threadIdx.x - 1] : Fr::one();
+#pragma unroll
+    for (uint32_t k = 0; k < PP_E; k++)
+        if (base + k < n) fe_store(local + base + k, fe_mul(v[k], excl));
+    if (threadIdx.x == PP_T - 1) fe_store(tot + blockIdx.x, sh[PP_T - 1]);
+}
+
+__global__ __launch_bounds__(1024) void pp_offsets_kernel(Fr* __restrict__ tot, uint32_t nblocks, const Fr* __restrict__ init_ptr, Fr init_val) {
+    // sequential per thread chunk + block scan; nblocks <= 1024 * 64
+    __shared__ Fr sh[1024];
+    const Fr init = init_ptr ? fe_load(init_ptr) : init_val;
+    const uint32_t chunk = (nblocks + 1023) / 1024;
+    const uint32_t lo = min(nblocks, threadIdx.x * chunk), hi = min(nblocks, lo + chunk);
+    Fr acc = Fr::one();
+    for (uint32_t i = lo; i < hi; i++) acc = fe_mul(acc, fe_load(tot + i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        Fr o = Fr::one();
+        const bool has = threadIdx.x >= d;
+        if (has) o = sh[threadIdx.x - d];
+        __syncthreads();
+        if (has) sh[threadIdx.x] = fe_mul(sh[threadIdx.x], o);
+        __syncthreads();
+    }
+    Fr run = fe_mul(init, threadIdx.x ? sh[threadIdx.x - 1] : Fr::one());
+    for (uint32_t i = lo; i < hi; i++) {
+        const Fr t = fe_load(tot + i);
+        fe_store(tot + i, run);  // exclusive offset (includes init)
+        run = fe_mul(run, t);
+    }
+}
+
+__global__ __launch_bounds__(PP_T) void pp_apply_kernel(const Fr* __restrict__ local, const Fr* __restrict__ offs, Fr* __restrict__ z, uint32_t n) {
+    const uint32_t i = blockIdx.x * PP_T + threadIdx.x;
+    if (i >= n) return;
+    const Fr off = fe_load(offs + i / PP_B);
+    if (i == 0) fe_store(z, off);  // = init
+    if (i + 1 < n) fe_store(z + i + 1, fe_mul(off, fe_load(local + i)));
+}
+
+void launch_prefix_product(const Fr* f, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_local, Fr* tmp_tot, hipStream_t st) {
+    const uint32_t nblocks = (n + PP_B - 1) / PP_B;
+    hipLaunchKernelGGL(pp_local_kernel, dim3(nblocks), dim3(PP_T), 0, st, f, tmp_local, tmp_tot, n);
+    hipLaunchKernelGGL(pp_offsets_kernel, dim3(1), dim3(1024), 0, st, tmp_tot, nblocks, init_dev, init_val);
+    hipLaunchKernelGGL(pp_apply_kernel, dim3((n + PP_T - 1) / PP_T), dim3(PP_T), 0, st, tmp_local, tmp_tot, z, n);
+}
+
+// ---------------------------------------------------------- Kate division ---
+// q = (p - p(z)) / (X - z):  q[i-1] = p[i] + z*q[i], q[n-1] = 0.  Chunks of KD_L
+// coefficients per thread: (1) chunk value c_t = sum_i p[tL+i] z^i, (2) suffix Horner
+// over chunks carry_t = c_{t+1} + z^L carry_{t+1}, (3) replay each chunk from its carry.
+static constexpr uint32_t KD_L = 32;
+
+__global__ void kd_chunk_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, Fr* __restrict__ cval) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t base = t * KD_L;
+    if (base >= n) return;
+    const uint32_t top = min(n, base + KD_L);
+    Fr acc = Fr::zero();
+    for (uint32_t i = top; i-- > base;) acc = fe_add(fe_mul(acc, z), fe_load(p + i));
+    fe_store(cval + t, acc);
+}
+
+// carry[t] = sum_{s > t} c_s * Z^(s - t - 1)   (single block, suffix scan of affine maps x -> Z^len x + c)
+__global__ __launch_bounds__(1024) void kd_carry_kernel(const Fr* __restrict__ cval, uint32_t m, Fr Z, Fr* __restrict__ carry) {
+    __shared__ Fr sm[1024];  // multiplier of the composed map of this thread's chunk-range and everything after
+    __shared__ Fr sa[1024];  // additive part
+    const uint32_t chunk = (m + 1023) / 1024;
+    // thread T owns chunk indices [lo, hi) counted from the top: process descending s
+    const uint32_t r = 1023 - threadIdx.x;  // reverse so that "earlier in scan" = higher index
+    const uint32_t lo = min(m, r * chunk), hi = min(m, lo + chunk);
+    // value entering below this thread's range given x entering from above: x -> Zpow * x + add
+    Fr zp = Fr::one(), add = Fr::zero();
+    for (uint32_t s = hi; s-- > lo;) {  // descending
+        add = fe_add(fe_mul(add, Z), fe_load(cval + s));
+        zp = fe_mul(zp, Z);
+    }
+    sm[threadIdx.x] = zp;
+    sa[threadIdx.x] = add;
+    __syncthreads();
+    // inclusive scan in thread order (thread 0 = topmost range): compose with predecessors
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        Fr pm = Fr::one(), pa = Fr::zero();
+        const bool has = threadIdx.x >= d;
+        if (has) {
+            pm = sm[threadIdx.x - d];
+            pa = sa[threadIdx.x - d];
+        }
+        __syncthreads();
+        if (has) {
+            // predecessor (above) applied first: x -> m*(pm*x + pa) + a
+            const Fr m0 = sm[threadIdx.x], a0 = sa[threadIdx.x];
+            sm[threadIdx.x] = fe_mul(m0, pm);
+            sa[threadIdx.x] = fe_add(fe_mul(m0, pa), a0);
+        }
+        __syncthreads();
+    }
+    // value entering this thread's range from above (x = 0 at the very top)
+    Fr x = threadIdx.x ? sa[threadIdx.x - 1] : Fr::zero();
+    for (uint32_t s = hi; s-- > lo;) {
+        fe_store(carry + s, x);  // carry into chunk s = contribution of all chunks above it
+        x = fe_add(fe_mul(x, Z), fe_load(cval + s));
+    }
+}
+
+__global__ void kd_apply_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, const Fr* __restrict__ carry, Fr* __restrict__ q) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t base = t * KD_L;
+    if (base >= n) return;
+    const uint32_t top = min(n, base + KD_L);
+    Fr run = fe_load(carry + t);  // = q[top - 1] contribution from above, i.e. sum_{j >= top} p[j] z^(j - top)
+    // q[i-1] = p[i] + z*q[i]; with run = q[top-1]... walk down
+    for (uint32_t i = top; i-- > base;) {
+        // run currently equals sum_{j > i} p[j] z^(j-i-1) = q[i]
+        fe_store(q + i, run);
+        run = fe_add(fe_mul(run, z), fe_load(p + i));
+    }
+}
+
+void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st) {
+    const uint32_t m = (n + KD_L - 1) / KD_L;
+    Fr Z = z;
+    for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^32
+    hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, tmp_c);
+    hipLaunchKernelGGL(kd_carry_kernel, dim3(1), dim3(1024), 0, st, tmp_c, m, Z, tmp_carry);
+    hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, tmp_carry, q);
+}
+
+}  // namespace zk

@@ -18,6 +18,15 @@ ZK_BASIS_LAGRANGE = 1
 ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM = 0, 1, 2, 3, 4
 
 
+ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
+ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
+
+
+class CircuitParamsC(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_uint32), ("num_advice", ctypes.c_uint32), ("num_lookup_advice", ctypes.c_uint32),
+                ("num_fixed", ctypes.c_uint32), ("lookup_bits", ctypes.c_uint32)]
+
+
 class ZkError(RuntimeError):
     def __init__(self, code, what, hip=0):
         self.code = code
@@ -68,6 +77,13 @@ def load_library():
         "zk_extended_to_coeff": ([vp, ctypes.c_uint64, sz], ctypes.c_int),
         "zk_eval": ([vp, ctypes.c_uint64, u64p, u64p], ctypes.c_int),
         "zk_last_kernel_ms": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
+        "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, ctypes.POINTER(ctypes.c_uint32), sz,
+                       ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_pk_free": ([vp, ctypes.c_uint64], ctypes.c_int),
+        "zk_vk_export": ([vp, ctypes.c_uint64, u64p, u64p, u64p, ctypes.POINTER(ctypes.c_uint32)], ctypes.c_int),
+        "zk_prove": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.c_char_p, ctypes.c_int,
+                      ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_poly_upload_canonical": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -203,6 +219,42 @@ class Engine:
         out = np.zeros(4, dtype=np.uint64)
         self._chk(self.L.zk_eval(self.ctx, p.h, _p(x), _p(out)), "zk_eval")
         return out
+
+    def upload_canonical(self, p, data):
+        d = _arr(data, 4)
+        self._chk(self.L.zk_poly_upload_canonical(self.ctx, p.h, _p(d), d.shape[0]), "zk_poly_upload_canonical")
+
+    # ---- keygen / create_proof -------------------------------------------------------
+    def keygen(self, params, fixed_canonical, copies):
+        """params: circuit.CircuitParams; fixed_canonical: (n_fix, n, 4) uint64 canonical limbs;
+        copies: iterable of ((perm_col, row), (perm_col, row))."""
+        cp = CircuitParamsC(params.degree, params.num_advice, params.num_lookup_advice, params.num_fixed, params.lookup_bits)
+        fx = np.ascontiguousarray(fixed_canonical, dtype=np.uint64)
+        cps = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], dtype=np.uint32).reshape(-1, 4))
+        h = ctypes.c_uint64()
+        self._chk(self.L.zk_keygen(self.ctx, ctypes.byref(cp), _p(fx), cps.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                   cps.shape[0], ctypes.byref(h)), "zk_keygen")
+        return h.value
+
+    def pk_free(self, pk):
+        self._chk(self.L.zk_pk_free(self.ctx, pk), "zk_pk_free")
+
+    def vk_export(self, pk):
+        counts = (ctypes.c_uint32 * 2)()
+        self._chk(self.L.zk_vk_export(self.ctx, pk, None, None, None, counts), "zk_vk_export")
+        fc = np.zeros((counts[0], 8), dtype=np.uint64)
+        pc = np.zeros((counts[1], 8), dtype=np.uint64)
+        tr = np.zeros(4, dtype=np.uint64)
+        self._chk(self.L.zk_vk_export(self.ctx, pk, _p(fc), _p(pc), _p(tr), counts), "zk_vk_export")
+        return fc, pc, tr
+
+    def prove(self, pk, advice_polys, seed=bytes(32), transcript=ZK_TRANSCRIPT_BLAKE2B, scheme=ZK_SCHEME_DEFAULT):
+        hs = (ctypes.c_uint64 * len(advice_polys))(*[p.h for p in advice_polys])
+        ln = ctypes.c_size_t()
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._chk(self.L.zk_prove(self.ctx, pk, hs, len(advice_polys), seed, transcript, scheme, buf, len(buf),
+                                  ctypes.byref(ln)), "zk_prove")
+        return buf.raw[:ln.value]
 
     def sync(self):
         self._chk(self.L.zk_sync(self.ctx), "zk_sync")
