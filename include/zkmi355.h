@@ -147,6 +147,9 @@ int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canoni
 #define ZK_T_MSM_ACCUM 4 /* the bucket-accumulation kernel of the last MSM alone */
 #define ZK_T_COUNT 8
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
+/* accumulated HIP-event time and launch count since the last reset (ZK_T_MSM, ZK_T_MSM_ACCUM) */
+int zk_timer_reset(zk_ctx* ctx);
+int zk_timer_stats(zk_ctx* ctx, int which, double* total_ms, uint64_t* count);
 
 #ifdef __cplusplus
 }

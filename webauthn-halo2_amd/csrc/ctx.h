@@ -46,6 +46,8 @@ struct zk_ctx {
     // timing
     hipEvent_t ev[ZK_T_COUNT][2] = {};
     bool ev_valid[ZK_T_COUNT] = {false};
+    double acc_ms[ZK_T_COUNT] = {0};   // accumulated over calls since zk_timer_reset (MSM kinds only)
+    uint64_t acc_n[ZK_T_COUNT] = {0};
 };
 
 #define HIPCHK(ctx, x)                 \

@@ -102,6 +102,17 @@ int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ev_valid[ZK_T_MSM] = true;
     c->ev_valid[ZK_T_MSM_ACCUM] = n > 0;
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[ZK_T_MSM][0], c->ev[ZK_T_MSM][1]) == hipSuccess) {
+            c->acc_ms[ZK_T_MSM] += ms;
+            c->acc_n[ZK_T_MSM]++;
+        }
+        if (n > 0 && hipEventElapsedTime(&ms, c->ev[ZK_T_MSM_ACCUM][0], c->ev[ZK_T_MSM_ACCUM][1]) == hipSuccess) {
+            c->acc_ms[ZK_T_MSM_ACCUM] += ms;
+            c->acc_n[ZK_T_MSM_ACCUM]++;
+        }
+    }
     *out = msm_finish_host(c->host_wsum, nwin, cw);
     return ZK_OK;
 }
@@ -197,6 +208,24 @@ int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
     if (rc) return rc;
     HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
     HIPCHK(c, hipEventElapsedTime(out_ms, c->ev[which][0], c->ev[which][1]));
+    return ZK_OK;
+}
+
+int zk_timer_reset(zk_ctx* c) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int i = 0; i < ZK_T_COUNT; i++) {
+        c->acc_ms[i] = 0;
+        c->acc_n[i] = 0;
+    }
+    return ZK_OK;
+}
+
+int zk_timer_stats(zk_ctx* c, int which, double* total_ms, uint64_t* count) {
+    if (!c || which < 0 || which >= ZK_T_COUNT || !total_ms || !count) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    *total_ms = c->acc_ms[which];
+    *count = c->acc_n[which];
     return ZK_OK;
 }
 

@@ -77,6 +77,8 @@ def load_library():
         "zk_extended_to_coeff": ([vp, ctypes.c_uint64, sz], ctypes.c_int),
         "zk_eval": ([vp, ctypes.c_uint64, u64p, u64p], ctypes.c_int),
         "zk_last_kernel_ms": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
+        "zk_timer_reset": ([vp], ctypes.c_int),
+        "zk_timer_stats": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, ctypes.POINTER(ctypes.c_uint32), sz,
                        ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_pk_free": ([vp, ctypes.c_uint64], ctypes.c_int),
@@ -258,6 +260,14 @@ class Engine:
 
     def sync(self):
         self._chk(self.L.zk_sync(self.ctx), "zk_sync")
+
+    def timer_reset(self):
+        self._chk(self.L.zk_timer_reset(self.ctx), "zk_timer_reset")
+
+    def timer_stats(self, which):
+        t, n = ctypes.c_double(), ctypes.c_uint64()
+        self._chk(self.L.zk_timer_stats(self.ctx, which, ctypes.byref(t), ctypes.byref(n)), "zk_timer_stats")
+        return t.value, n.value
 
     def last_ms(self, which):
         v = ctypes.c_float()
