@@ -28,6 +28,9 @@ struct zk_ctx {
     int srs_k = -1;
     G1Affine* g = nullptr;
     G1Affine* g_lagrange = nullptr;
+    G1Affine* g_table = nullptr;           // window multiples of g / g_lagrange (fixed-base MSM)
+    G1Affine* g_lagrange_table = nullptr;
+    uint32_t table_c = 0;
     // MSM
     MsmWorkspace* msm_ws = nullptr;
     G1X* host_wsum = nullptr;  // pinned

@@ -29,19 +29,20 @@ int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
 
 // ---- MSM (msm.hip) ---------------------------------------------------------
 struct MsmWorkspace;  // opaque, sized for a maximum n
-struct MsmConfig {
-    uint32_t c;        // window bits (signed digits), 0 = auto
-    uint32_t seg_len;  // entries per accumulate thread, 0 = default
-};
-size_t msm_workspace_bytes(size_t max_n, uint32_t c);
 MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err);
 void msm_workspace_destroy(MsmWorkspace* ws);
 uint32_t msm_auto_window(size_t n);
-// Launches the whole device pipeline on `st`; window sums (XYZZ) land in
-// ws->window_sums (device) and are copied to `host_window_sums` (pinned or
-// pageable, nwin * 128 B) asynchronously.  Returns the number of windows.
+uint32_t msm_num_windows(uint32_t c);
+size_t msm_ws_max_n(const MsmWorkspace* ws);
+uint32_t msm_ws_window(const MsmWorkspace* ws);
+// table[w * n + i] = 2^(c w) * bases[i] (affine), w < msm_num_windows(c)
+hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st);
+// Launches the whole device pipeline on `st`; window sums (XYZZ) are copied to
+// `host_window_sums` asynchronously.  `table` != nullptr selects the fixed-base mode
+// (one bucket set, *nwin_out = 1); otherwise *nwin_out windows need the host Horner.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
-                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events = nullptr);
+                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events = nullptr,
+                   const G1Affine* table = nullptr, uint32_t table_stride = 0);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).
 G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
 

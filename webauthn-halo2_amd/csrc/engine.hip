@@ -66,10 +66,6 @@ int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
     return ZK_OK;
 }
 
-namespace zk {
-size_t msm_ws_max_n(const MsmWorkspace* ws);
-}
-
 static int get_msm_ws(zk_ctx* c, size_t n, MsmWorkspace** out) {
     size_t want = 1;
     while (want < n) want <<= 1;
@@ -93,11 +89,20 @@ static int get_msm_ws(zk_ctx* c, size_t n, MsmWorkspace** out) {
 // MSM of device-resident scalars against device-resident bases -> Jacobian on host
 int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out) {
     MsmWorkspace* ws;
-    int rc = get_msm_ws(c, n, &ws);
+    // commits against the resident SRS use the precomputed window tables
+    const G1Affine* table = nullptr;
+    uint32_t stride = 0;
+    if (c->srs_k >= 0 && c->table_c) {
+        if (d_bases == c->g) table = c->g_table;
+        else if (d_bases == c->g_lagrange) table = c->g_lagrange_table;
+        stride = 1u << c->srs_k;
+    }
+    int rc = get_msm_ws(c, table ? (size_t)stride : n, &ws);
     if (rc) return rc;
+    if (table && msm_ws_window(ws) != c->table_c) table = nullptr;
     uint32_t nwin = 0, cw = 0;
     HIPCHK(c, hipEventRecord(c->ev[ZK_T_MSM][0], c->stream));
-    HIPCHK(c, msm_run(ws, d_scalars, d_bases, n, c->stream, c->host_wsum, &nwin, &cw, c->ev[ZK_T_MSM_ACCUM]));
+    HIPCHK(c, msm_run(ws, d_scalars, d_bases, n, c->stream, c->host_wsum, &nwin, &cw, c->ev[ZK_T_MSM_ACCUM], table, stride));
     HIPCHK(c, hipEventRecord(c->ev[ZK_T_MSM][1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ev_valid[ZK_T_MSM] = true;
@@ -148,7 +153,7 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     if (!c) return ZK_ENOMEM;
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipHostMalloc(&c->host_wsum, 64 * sizeof(G1X)) != hipSuccess ||
+        hipHostMalloc(&c->host_wsum, 2048 * sizeof(G1X)) != hipSuccess ||
         hipHostMalloc(&c->host_small, 8 * sizeof(Fr)) != hipSuccess ||
         hipMalloc(&c->small, (2048 + 8) * sizeof(Fr)) != hipSuccess) {
         zk_ctx_destroy(c);
@@ -174,6 +179,8 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
     if (c->g) hipFree(c->g);
     if (c->g_lagrange) hipFree(c->g_lagrange);
+    if (c->g_table) hipFree(c->g_table);
+    if (c->g_lagrange_table) hipFree(c->g_lagrange_table);
     if (c->msm_ws) msm_workspace_destroy(c->msm_ws);
     if (c->host_wsum) hipHostFree(c->host_wsum);
     if (c->host_small) hipHostFree(c->host_small);
@@ -332,12 +339,35 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
 
 // ---- SRS ---------------------------------------------------------------------
 
+// window-multiple tables of both bases for the fixed-base MSM (k >= 10; smaller SRS use the generic path)
+static int srs_build_tables(zk_ctx* c, uint32_t k) {
+    if (k < 10) return ZK_OK;
+    const uint32_t n = 1u << k;
+    const uint32_t cw = msm_auto_window(n);
+    const size_t cnt = (size_t)msm_num_windows(cw) * n;
+    if (hipMalloc(&c->g_table, cnt * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc(&c->g_lagrange_table, cnt * sizeof(G1Affine)) != hipSuccess)
+        return ZK_ENOMEM;
+    hipError_t e = msm_build_table(c->g, n, cw, c->g_table, c->stream);
+    if (e == hipSuccess) e = msm_build_table(c->g_lagrange, n, cw, c->g_lagrange_table, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        return ZK_EHIP;
+    }
+    c->table_c = cw;
+    return ZK_OK;
+}
+
 static int srs_alloc(zk_ctx* c, uint32_t k) {
     if (k < 1 || k > 24) return ZK_EINVAL;
     const size_t n = (size_t)1 << k;
     if (c->g) hipFree(c->g);
     if (c->g_lagrange) hipFree(c->g_lagrange);
-    c->g = c->g_lagrange = nullptr;
+    if (c->g_table) hipFree(c->g_table);
+    if (c->g_lagrange_table) hipFree(c->g_lagrange_table);
+    c->g = c->g_lagrange = c->g_table = c->g_lagrange_table = nullptr;
+    c->table_c = 0;
     c->srs_k = -1;
     if (hipMalloc(&c->g, n * sizeof(G1Affine)) != hipSuccess || hipMalloc(&c->g_lagrange, n * sizeof(G1Affine)) != hipSuccess)
         return ZK_ENOMEM;
@@ -419,6 +449,7 @@ int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
     }
     hipFree(d_table);
     hipFree(d_sc);
+    if (rc == ZK_OK) rc = srs_build_tables(c, k);
     if (rc == ZK_OK) c->srs_k = (int)k;
     return rc;
 }
@@ -432,6 +463,7 @@ int zk_srs_load(zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl) {
     const size_t bytes = ((size_t)1 << k) * sizeof(G1Affine);
     HIPCHK(c, hipMemcpy(c->g, g, bytes, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->g_lagrange, gl, bytes, hipMemcpyHostToDevice));
+    if ((rc = srs_build_tables(c, k)) != ZK_OK) return rc;
     c->srs_k = (int)k;
     return ZK_OK;
 }

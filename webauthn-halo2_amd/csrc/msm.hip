@@ -6,23 +6,30 @@
 // Any correct algorithm yields the same group element, so the result is
 // bit-identical to the reference's after affine normalisation.
 //
-// Pipeline (all on one stream, no host round trip until the W window sums):
-//   1. msm_digits<COUNT>   signed c-bit window recoding of every scalar, bucket histogram
-//   2. msm_scan            exclusive scan of the histogram -> bucket cursors
-//   3. msm_digits<SCATTER> counting-sort scatter of (bucket, +-point index) entries
-//   4. msm_accumulate      fixed-length segments of the sorted entry list, one
-//                          thread each, mixed XYZZ adds; runs that lie inside a
-//                          segment go straight to their bucket, the first/last
-//                          run of a segment becomes a "slot"
-//   5. msm_reduce_slots    the same segmented reduction over the slot list until
-//                          it is short, then msm_finalize_slots
-//   6. msm_bucket_reduce   bucket j -> (j+1) * B_j by double-and-add, LDS tree sum
-//   7. msm_window_reduce   per-window sum of the block partials
-//   8. host                Horner over the W window sums (W * c doublings; serial
-//                          work that a single GPU lane would take ~ms to do)
+// Two modes share one pipeline:
+//   generic   bases are arbitrary (the fine-grained `zk_msm_bn254` seam): W windows of
+//             c bits, W x 2^(c-1) buckets, host does the final W-window Horner;
+//   fixed     bases are the resident SRS (`zk_commit`): a table of window multiples
+//             2^(c w) P_i is precomputed once per basis, so every window's digits fall
+//             into ONE set of 2^(c-1) buckets — no per-window reduction, no Horner.
+//
+// Pipeline (one stream, no host round trip until the window sums):
+//   1. msm_recode        signed c-bit window recoding of every scalar -> digits[W][n]
+//   2. msm_sort<COUNT>   per (scalar chunk, window) workgroup: bucket histogram in LDS,
+//                        one returning atomicAdd per non-empty bucket reserves the
+//                        workgroup's range inside the bucket
+//   3. msm_scan          exclusive scan of bucket totals -> bucket starts
+//   4. msm_sort<SCATTER> same workgroups: LDS cursors = bucket start + reserved base,
+//                        counting-sort scatter of (bucket, +-base index) entries
+//   5. msm_accumulate    fixed-length segments (32 entries) of the sorted list, one lane
+//                        each, XYZZ mixed adds (8M + 2S); a bucket lying strictly inside
+//                        a segment is final, the first/last run of a segment is a "slot"
+//   6. msm_gather        one workgroup per (bucket, part): sums that bucket's slots
+//   7. msm_bitsum        sum_j j B_j = sum_t 2^t G_t, G_t = sum of buckets with bit t of j set:
+//                        c tree reductions per bucket set; the short Horner is done on the host
 // Load balance does not depend on the scalar distribution: witness columns are
-// dominated by zeros / small values (hot low buckets), and a segment is a fixed
-// number of entries whatever bucket they fall in.
+// dominated by zeros / small values (hot low buckets), and a segment is a fixed number
+// of entries whatever bucket they fall in.
 #include <string.h>
 #include <vector>
 
@@ -31,21 +38,23 @@
 namespace zk {
 
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
+static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
+static constexpr uint32_t SEG0 = 32;      // entries per accumulate lane
 
 struct MsmWorkspace {
     size_t max_n;
     uint32_t c, nwin, nb;       // window bits, windows, buckets per window
-    uint32_t seg0, seg1;        // entries per thread at level 0 / slot levels
-    uint32_t* hist;             // [nwin*nb + 1]
-    uint32_t* cursor;           // [nwin*nb + 1]
-    uint32_t* counts;           // [16] device-side list lengths per level (counts[0] = #entries)
+    uint32_t parts_fixed, parts_generic;
+    int32_t* digits;            // [nwin][max_n]
+    uint32_t* totals;           // [nwin*nb + 1]
+    uint32_t* bucket_start;     // [nwin*nb + 1]
+    uint32_t* blockbase;        // [nblk][nb]
+    uint32_t* counts;           // [4]
     uint2* entries;             // [max_n * nwin]
-    uint32_t* slot_bucket[2];
-    G1X* slot_pt[2];
-    size_t slot_cap;
-    G1X* bucket_sum;            // [nwin*nb]
-    G1X* block_sum;             // [nwin*nb/256]
-    G1X* window_sum;            // [nwin]
+    uint32_t* slot_bucket;      // [2 * threads]
+    G1X* slot_pt;
+    G1X* part;                  // [nbt * parts]
+    G1X* bit_sum;               // [nwin * c]
 };
 
 uint32_t msm_auto_window(size_t n) {
@@ -53,67 +62,99 @@ uint32_t msm_auto_window(size_t n) {
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = (int)lg - 6;
     if (c < 9) c = 9;
-    if (c > 14) c = 14;
+    if (c > 14) c = 14;  // 2^(c-1) u32 counters must fit the LDS histogram
     return (uint32_t)c;
 }
 
 static inline uint32_t nwin_for(uint32_t c) { return 254 / c + 1; }
-
+uint32_t msm_num_windows(uint32_t c) { return nwin_for(c); }
 size_t msm_ws_max_n(const MsmWorkspace* ws) { return ws->max_n; }
+uint32_t msm_ws_window(const MsmWorkspace* ws) { return ws->c; }
 
-// ---------------------------------------------------------------- digits ---
+// ---------------------------------------------------------------- recode ---
 
-template <bool SCATTER>
-__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, uint32_t c,
-                                                         uint32_t nwin, uint32_t* __restrict__ ctr,
-                                                         uint2* __restrict__ entries) {
-    __shared__ uint32_t limbs[256][9];  // canonical scalar per thread (+1 pad word, also breaks bank stride)
+__global__ __launch_bounds__(256) void msm_recode_kernel(const Fr* __restrict__ scalars, uint32_t n, uint32_t stride,
+                                                         uint32_t c, uint32_t nwin, int32_t* __restrict__ digits) {
+    __shared__ uint32_t limbs[256][9];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Fr s = fe_from_mont(fe_load(scalars + i));
+    const Fr s = fe_from_mont(fe_load(scalars + i));
     uint32_t* L = limbs[threadIdx.x];
 #pragma unroll
     for (int k = 0; k < 8; k++) L[k] = s.v[k];
     L[8] = 0;
-    if (s.is_zero()) return;
-    const uint32_t nb = 1u << (c - 1);
+    const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < nwin; w++) {
         const uint32_t bit = w * c, word = bit >> 5, off = bit & 31;
         uint32_t raw = 0;
         if (word < 8) {
-            uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
+            const uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
             raw = (uint32_t)(two >> off) & mask;
         }
         raw += carry;
-        uint32_t mag, neg;
-        if (raw > nb) {
-            mag = (1u << c) - raw;
-            neg = SIGN_BIT;
+        int32_t d;
+        if (raw > half) {
+            d = (int32_t)raw - (int32_t)(1u << c);
             carry = 1;
         } else {
-            mag = raw;
-            neg = 0;
+            d = (int32_t)raw;
             carry = 0;
         }
-        if (mag) {
-            const uint32_t bucket = w * nb + (mag - 1);
-            const uint32_t pos = atomicAdd(&ctr[bucket], 1u);
-            if (SCATTER) entries[pos] = make_uint2(bucket, i | neg);
+        digits[(size_t)w * stride + i] = d;
+    }
+}
+
+// ------------------------------------------------------- histogram / scatter ---
+// grid.x = nchunks * nwin; blk = w * nchunks + chunk.  slice = fixed ? 0 : w.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void msm_sort_kernel(const int32_t* __restrict__ digits, uint32_t n, uint32_t stride,
+                                                       uint32_t nchunks, uint32_t nb, uint32_t fixed,
+                                                       uint32_t table_stride, uint32_t* __restrict__ totals,
+                                                       const uint32_t* __restrict__ bucket_start,
+                                                       uint32_t* __restrict__ blockbase, uint2* __restrict__ entries) {
+    extern __shared__ uint32_t lds[];  // nb counters / cursors
+    const uint32_t blk = blockIdx.x;
+    const uint32_t w = blk / nchunks, chunk = blk - w * nchunks;
+    const uint32_t slice = fixed ? 0 : w;
+    const uint32_t lo = chunk * CHUNK, hi = min(n, lo + CHUNK);
+    const int32_t* dg = digits + (size_t)w * stride;
+    if (!SCATTER) {
+        for (uint32_t b = threadIdx.x; b < nb; b += 256) lds[b] = 0;
+    } else {
+        for (uint32_t b = threadIdx.x; b < nb; b += 256)
+            lds[b] = bucket_start[slice * nb + b] + blockbase[(size_t)blk * nb + b];
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int32_t d = dg[i];
+        if (d == 0) continue;
+        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+        const uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
+        if (SCATTER) {
+            const uint32_t idx = (fixed ? w * table_stride : 0) + i;
+            entries[pos] = make_uint2(slice * nb + mag - 1, idx | (d < 0 ? SIGN_BIT : 0));
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+            const uint32_t cnt = lds[b];
+            blockbase[(size_t)blk * nb + b] = cnt ? atomicAdd(&totals[slice * nb + b], cnt) : 0;
         }
     }
 }
 
-// exclusive scan of hist[0..m) into cursor[0..m], cursor[m] = total = counts[0]
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+// exclusive scan of in[0..m) into out[0..m], out[m] = total = counts[0]
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                         uint32_t m, uint32_t* __restrict__ counts) {
     __shared__ uint32_t part[1024];
     const uint32_t chunk = (m + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * chunk;
+    const uint32_t lo = min(m, threadIdx.x * chunk);
     const uint32_t hi = min(m, lo + chunk);
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += hist[i];
+    for (uint32_t i = lo; i < hi; i++) sum += in[i];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -124,37 +165,33 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t run = part[threadIdx.x] - sum;
     for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t h = hist[i];
-        cursor[i] = run;
+        const uint32_t h = in[i];
+        out[i] = run;
         run += h;
     }
     if (threadIdx.x == 1023) {
-        cursor[m] = part[1023];
+        out[m] = part[1023];
         counts[0] = part[1023];
     }
 }
 
 // ------------------------------------------------------------ accumulate ---
 
-// Level 0: entries are (bucket, +-base index).  Emits exactly two slots per
-// active thread: (first bucket, first-run sum) and (last bucket, last-run sum or
-// identity when the segment is a single run); runs strictly inside the segment
-// are complete buckets and are written directly.
+// Emits exactly two slots per active lane: (first bucket, first-run sum) and (last
+// bucket, last-run sum, or identity when the segment is a single run).  Runs strictly
+// inside the segment are complete buckets: they go to part[bucket * parts].
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint2* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
-                                                            const uint32_t* __restrict__ counts, uint32_t seg,
-                                                            G1X* __restrict__ bucket_sum,
-                                                            uint32_t* __restrict__ slot_bucket,
-                                                            G1X* __restrict__ slot_pt, uint32_t* __restrict__ counts_out) {
+                                                            const uint32_t* __restrict__ counts, uint32_t parts,
+                                                            G1X* __restrict__ part, uint32_t* __restrict__ slot_bucket,
+                                                            G1X* __restrict__ slot_pt) {
     const uint32_t total = counts[0];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nthreads = (total + seg - 1) / seg;
-    if (t == 0) *counts_out = 2 * nthreads;
+    const uint32_t nthreads = (total + SEG0 - 1) / SEG0;
     if (t >= nthreads) return;
-    const uint32_t beg = t * seg;
-    const uint32_t end = min(total, beg + seg);
-    const uint32_t first_b = entries[beg].x;
-    uint32_t cur = first_b;
+    const uint32_t beg = t * SEG0;
+    const uint32_t end = min(total, beg + SEG0);
+    uint32_t cur = entries[beg].x;
     G1X acc = G1X::identity();
     bool first_open = true;
     for (uint32_t pos = beg; pos < end; pos++) {
@@ -165,7 +202,7 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint2* __restr
                 g1x_store(slot_pt + 2 * t, acc);
                 first_open = false;
             } else {
-                g1x_store(bucket_sum + cur, acc);
+                g1x_store(part + (size_t)cur * parts, acc);
             }
             acc = G1X::identity();
             cur = e.x;
@@ -184,130 +221,203 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint2* __restr
     g1x_store(slot_pt + 2 * t + 1, acc);
 }
 
-// Slot levels: same segmented reduction with XYZZ + XYZZ adds.
-__global__ __launch_bounds__(64) void msm_reduce_slots_kernel(const uint32_t* __restrict__ in_bucket,
-                                                              const G1X* __restrict__ in_pt,
-                                                              const uint32_t* __restrict__ count_in, uint32_t seg,
-                                                              G1X* __restrict__ bucket_sum,
-                                                              uint32_t* __restrict__ out_bucket,
-                                                              G1X* __restrict__ out_pt, uint32_t* __restrict__ count_out) {
-    const uint32_t total = *count_in;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nthreads = (total + seg - 1) / seg;
-    if (t == 0) *count_out = 2 * nthreads;
-    if (t >= nthreads) return;
-    const uint32_t beg = t * seg;
-    const uint32_t end = min(total, beg + seg);
-    uint32_t cur = in_bucket[beg];
+__global__ void msm_clear_kernel(G1X* __restrict__ p, uint32_t m) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) g1x_store(p + i, G1X::identity());
+}
+
+// ---- "cold" group arithmetic for the low-parallelism reduction kernels: the field
+// product is an out-of-line call, which keeps these kernels at ~100 VGPRs (8 waves/SIMD,
+// no scratch) instead of 248 + spills when fourteen products are inlined per addition.
+__device__ __noinline__ Fq fq_mul_call(Fq a, Fq b) { return fe_mul(a, b); }
+
+__device__ void g1x_dbl_cold(G1X& p) {
+    if (p.is_identity()) return;
+    const Fq u = fe_dbl(p.y);
+    const Fq v = fq_mul_call(u, u);
+    const Fq w = fq_mul_call(u, v);
+    const Fq s = fq_mul_call(p.x, v);
+    const Fq xx = fq_mul_call(p.x, p.x);
+    const Fq m = fe_add(fe_dbl(xx), xx);
+    const Fq x3 = fe_sub(fq_mul_call(m, m), fe_dbl(s));
+    const Fq y3 = fe_sub(fq_mul_call(m, fe_sub(s, x3)), fq_mul_call(w, p.y));
+    p.zz = fq_mul_call(v, p.zz);
+    p.zzz = fq_mul_call(w, p.zzz);
+    p.x = x3;
+    p.y = y3;
+}
+
+__device__ void g1x_add_cold(G1X& acc, const G1X& b) {
+    if (b.is_identity()) return;
+    if (acc.is_identity()) {
+        acc = b;
+        return;
+    }
+    const Fq u1 = fq_mul_call(acc.x, b.zz);
+    const Fq u2 = fq_mul_call(b.x, acc.zz);
+    const Fq s1 = fq_mul_call(acc.y, b.zzz);
+    const Fq s2 = fq_mul_call(b.y, acc.zzz);
+    const Fq p = fe_sub(u2, u1);
+    const Fq r = fe_sub(s2, s1);
+    if (p.is_zero()) {
+        if (r.is_zero()) g1x_dbl_cold(acc);
+        else acc = G1X::identity();
+        return;
+    }
+    const Fq pp = fq_mul_call(p, p);
+    const Fq ppp = fq_mul_call(p, pp);
+    const Fq q = fq_mul_call(u1, pp);
+    const Fq x3 = fe_sub(fe_sub(fq_mul_call(r, r), ppp), fe_dbl(q));
+    const Fq y3 = fe_sub(fq_mul_call(r, fe_sub(q, x3)), fq_mul_call(s1, ppp));
+    acc.zz = fq_mul_call(fq_mul_call(acc.zz, b.zz), pp);
+    acc.zzz = fq_mul_call(fq_mul_call(acc.zzz, b.zzz), ppp);
+    acc.x = x3;
+    acc.y = y3;
+}
+
+__device__ __forceinline__ G1X g1x_shfl_down(const G1X& v, int off) {
+    G1X r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        r.x.v[k] = __shfl_down(v.x.v[k], off);
+        r.y.v[k] = __shfl_down(v.y.v[k], off);
+        r.zz.v[k] = __shfl_down(v.zz.v[k], off);
+        r.zzz.v[k] = __shfl_down(v.zzz.v[k], off);
+    }
+    return r;
+}
+
+// sum over aligned groups of `width` lanes (power of two <= 64); result in the group's lane 0
+__device__ __forceinline__ void group_sum(G1X& acc, int width) {
+#pragma unroll 1
+    for (int off = width >> 1; off > 0; off >>= 1) {
+        const G1X o = g1x_shfl_down(acc, off);
+        if ((int)(threadIdx.x & (width - 1)) < off) g1x_add_cold(acc, o);
+    }
+}
+
+// One 16-lane group per (bucket b, part p): sums the slots of bucket b that fall in the
+// p-th share of the bucket's slot range (lanes stride over the share, then a 4-step
+// shuffle tree).  A bucket uses ceil(slots / 128) parts (at most `parts`); the others stay
+// identity.  Buckets that were a strictly-inner run of a single accumulate lane are
+// already final in part[b * parts] and are skipped.
+static constexpr uint32_t GATHER_LANES = 16;
+__global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restrict__ bucket_start,
+                                                         const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ slot_bucket,
+                                                         const G1X* __restrict__ slot_pt, uint32_t parts, uint32_t ngroups,
+                                                         G1X* __restrict__ part) {
+    const uint32_t gid = (blockIdx.x * 256 + threadIdx.x) / GATHER_LANES;
+    const uint32_t lane = threadIdx.x & (GATHER_LANES - 1);
     G1X acc = G1X::identity();
-    bool first_open = true;
-    for (uint32_t pos = beg; pos < end; pos++) {
-        const uint32_t b = in_bucket[pos];
-        if (b != cur) {
-            if (first_open) {
-                out_bucket[2 * t] = cur;
-                g1x_store(out_pt + 2 * t, acc);
-                first_open = false;
-            } else {
-                g1x_store(bucket_sum + cur, acc);
+    bool active = false;
+    uint32_t b = 0, p = 0;
+    if (gid < ngroups) {
+        b = gid / parts;
+        p = gid - b * parts;
+        const uint32_t total = counts[0];
+        const uint32_t lo = bucket_start[b], hi = bucket_start[b + 1];
+        if (lo != hi) {
+            const uint32_t t_first = lo / SEG0, t_last = (hi - 1) / SEG0;
+            bool inner = false;
+            if (t_first == t_last) {
+                const uint32_t seg_beg = t_first * SEG0, seg_end = min(total, seg_beg + SEG0);
+                inner = lo != seg_beg && hi != seg_end;  // strictly inner run: already written
             }
-            acc = G1X::identity();
-            cur = b;
+            const uint32_t s0 = 2 * t_first, s1 = 2 * t_last + 2;
+            const uint32_t len = s1 - s0;
+            const uint32_t used = min(parts, (len + 127) / 128);
+            if (!inner && p < used) {
+                active = true;
+                const uint32_t share = (len + used - 1) / used;
+                const uint32_t a0 = s0 + p * share, a1 = min(s1, a0 + share);
+#pragma unroll 1
+                for (uint32_t s = a0 + lane; s < a1; s += GATHER_LANES) {
+                    if (slot_bucket[s] == b) {
+                        const G1X v = g1x_load(slot_pt + s);
+                        g1x_add_cold(acc, v);
+                    }
+                }
+            }
         }
-        const G1X p = g1x_load(in_pt + pos);
-        g1x_add(acc, p);
     }
-    if (first_open) {
-        out_bucket[2 * t] = cur;
-        g1x_store(out_pt + 2 * t, acc);
-        acc = G1X::identity();
-    }
-    out_bucket[2 * t + 1] = cur;
-    g1x_store(out_pt + 2 * t + 1, acc);
-}
-
-// Last level: one thread per run start walks its run serially.
-__global__ __launch_bounds__(64) void msm_finalize_slots_kernel(const uint32_t* __restrict__ in_bucket,
-                                                                const G1X* __restrict__ in_pt,
-                                                                const uint32_t* __restrict__ count_in,
-                                                                G1X* __restrict__ bucket_sum) {
-    const uint32_t total = *count_in;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t b = in_bucket[i];
-    if (i > 0 && in_bucket[i - 1] == b) return;
-    G1X acc = g1x_load(in_pt + i);
-    for (uint32_t k = i + 1; k < total && in_bucket[k] == b; k++) {
-        const G1X p = g1x_load(in_pt + k);
-        g1x_add(acc, p);
-    }
-    g1x_store(bucket_sum + b, acc);
-}
-
-__global__ void msm_clear_buckets_kernel(G1X* __restrict__ bucket_sum, uint32_t m) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) g1x_store(bucket_sum + i, G1X::identity());
+    group_sum(acc, GATHER_LANES);  // every lane of the wave takes part in the shuffles
+    if (active && lane == 0) g1x_store(part + (size_t)b * parts + p, acc);
 }
 
 // ---------------------------------------------------------------- reduce ---
-
-__device__ __forceinline__ void block_tree_sum(G1X* sh, G1X& mine, uint32_t nthreads) {
-    g1x_store(sh + threadIdx.x, mine);
+// sum_j j * B_j = sum_t 2^t * G_t with G_t = sum of the buckets whose multiplier j has
+// bit t set: c tree reductions per bucket set instead of 2^(c-1) scalar multiplications.
+// grid = slices * c * BITSUM_SPLIT workgroups, each covering a quarter of the buckets;
+// the host adds the BITSUM_SPLIT partials and runs the c-term Horner.
+static constexpr uint32_t BITSUM_SPLIT = 4;
+__global__ __launch_bounds__(256) void msm_bitsum_kernel(const G1X* __restrict__ part, uint32_t parts, uint32_t nb,
+                                                         uint32_t c, G1X* __restrict__ out) {
+    __shared__ G1X sh[4];
+    const uint32_t q = blockIdx.x % BITSUM_SPLIT;
+    const uint32_t st = blockIdx.x / BITSUM_SPLIT;
+    const uint32_t slice = st / c, t = st - slice * c;
+    G1X acc = G1X::identity();
+#pragma unroll 1
+    for (uint32_t j = q * 256 + threadIdx.x + 1; j <= nb; j += 256 * BITSUM_SPLIT) {
+        if (!((j >> t) & 1)) continue;
+        const G1X* src = part + ((size_t)slice * nb + (j - 1)) * parts;
+#pragma unroll 1
+        for (uint32_t k = 0; k < parts; k++) {
+            const G1X v = g1x_load(src + k);
+            g1x_add_cold(acc, v);
+        }
+    }
+    group_sum(acc, 64);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) g1x_store(sh + wave, acc);
     __syncthreads();
-    for (uint32_t s = nthreads >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            G1X a = g1x_load(sh + threadIdx.x);
-            const G1X b = g1x_load(sh + threadIdx.x + s);
-            g1x_add(a, b);
-            g1x_store(sh + threadIdx.x, a);
-        }
-        __syncthreads();
+    if (wave == 0) {
+        acc = (threadIdx.x < 4) ? g1x_load(sh + threadIdx.x) : G1X::identity();
+        group_sum(acc, 4);
+        if (threadIdx.x == 0) g1x_store(out + blockIdx.x, acc);
     }
-    mine = g1x_load(sh);
 }
 
-// block_sum[blk] = sum over the block's 256 buckets of (j+1) * B_j
-__global__ __launch_bounds__(256) void msm_bucket_reduce_kernel(const G1X* __restrict__ bucket_sum, uint32_t nb,
-                                                                G1X* __restrict__ block_sum) {
-    __shared__ G1X sh[256];
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t k = (g & (nb - 1)) + 1;  // multiplier
-    const G1X p = g1x_load(bucket_sum + g);
-    G1X acc = G1X::identity();
-    if (!p.is_identity()) {
-        acc = p;
-        int top = 31 - __clz(k);
-        for (int bit = top - 1; bit >= 0; bit--) {
-            acc = g1x_dbl(acc);
-            if ((k >> bit) & 1) g1x_add(acc, p);
+// ------------------------------------------------------ fixed-base tables ---
+// table[w][i] = 2^(c w) * P_i (affine).  One launch per window: c doublings + one inversion.
+__global__ __launch_bounds__(64) void msm_table_step_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next,
+                                                            uint32_t n, uint32_t c) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p = affine_load(prev + i);
+    G1Affine r;
+    if (affine_is_identity(p)) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+    } else {
+        G1X acc = g1x_dbl_affine(p.x, p.y);
+        for (uint32_t k = 1; k < c; k++) acc = g1x_dbl(acc);
+        if (acc.is_identity()) {  // cannot happen on a prime-order curve; kept for completeness
+            r.x = Fq::zero();
+            r.y = Fq::zero();
+        } else {
+            const Fq t = fe_inv(acc.zzz);
+            const Fq u = fe_mul(acc.zz, t);
+            r.x = fe_mul(acc.x, fe_sqr(u));
+            r.y = fe_mul(acc.y, t);
         }
     }
-    block_tree_sum(sh, acc, 256);
-    if (threadIdx.x == 0) g1x_store(block_sum + blockIdx.x, acc);
+    fe_store(&next[i].x, r.x);
+    fe_store(&next[i].y, r.y);
 }
 
-// window_sum[w] = sum of the window's block partials
-__global__ __launch_bounds__(256) void msm_window_reduce_kernel(const G1X* __restrict__ block_sum, uint32_t per_window,
-                                                                G1X* __restrict__ window_sum) {
-    __shared__ G1X sh[256];
-    G1X acc = G1X::identity();
-    for (uint32_t i = threadIdx.x; i < per_window; i += 256) {
-        const G1X p = g1x_load(block_sum + blockIdx.x * per_window + i);
-        g1x_add(acc, p);
-    }
-    block_tree_sum(sh, acc, 256);
-    if (threadIdx.x == 0) g1x_store(window_sum + blockIdx.x, acc);
+hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st) {
+    const uint32_t nwin = nwin_for(c);
+    hipError_t e = hipMemcpyAsync(table, bases, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+    for (uint32_t w = 1; w < nwin; w++)
+        hipLaunchKernelGGL(msm_table_step_kernel, dim3((n + 63) / 64), dim3(64), 0, st, table + (size_t)(w - 1) * n,
+                           table + (size_t)w * n, n, c);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ host ---
-
-size_t msm_workspace_bytes(size_t max_n, uint32_t c) {
-    const uint32_t nwin = nwin_for(c);
-    const size_t nbt = (size_t)nwin << (c - 1);
-    const size_t ent = max_n * nwin;
-    const size_t slots = 2 * ((ent + 31) / 32) + 64;
-    return ent * 8 + slots * (4 + sizeof(G1X)) * 2 + nbt * (8 + sizeof(G1X)) + (nbt / 256 + nwin) * sizeof(G1X);
-}
 
 #define MSM_TRY(x)                     \
     do {                               \
@@ -322,7 +432,7 @@ size_t msm_workspace_bytes(size_t max_n, uint32_t c) {
 MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     if (err) *err = hipSuccess;
     if (c == 0) c = msm_auto_window(max_n);
-    if (c < 9 || c > 16 || max_n == 0 || max_n > ((size_t)1 << 26)) {
+    if (c < 9 || c > 14 || max_n == 0 || max_n > ((size_t)1 << 26)) {
         if (err) *err = hipErrorInvalidValue;
         return nullptr;
     }
@@ -332,93 +442,95 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     ws->c = c;
     ws->nwin = nwin_for(c);
     ws->nb = 1u << (c - 1);
-    ws->seg0 = 32;
-    ws->seg1 = 16;
+    ws->parts_fixed = 8;
+    ws->parts_generic = 1;
     const size_t nbt = (size_t)ws->nwin * ws->nb;
     const size_t ent = max_n * ws->nwin;
-    ws->slot_cap = 2 * ((ent + ws->seg0 - 1) / ws->seg0) + 64;
-    MSM_TRY(hipMalloc(&ws->hist, (nbt + 1) * 4));
-    MSM_TRY(hipMalloc(&ws->cursor, (nbt + 1) * 4));
-    MSM_TRY(hipMalloc(&ws->counts, 16 * 4));
+    const size_t nchunks = (max_n + CHUNK - 1) / CHUNK;
+    const size_t threads = (ent + SEG0 - 1) / SEG0 + 1;
+    size_t part_n = nbt * ws->parts_generic;
+    if ((size_t)ws->nb * ws->parts_fixed > part_n) part_n = (size_t)ws->nb * ws->parts_fixed;
+    MSM_TRY(hipMalloc(&ws->digits, ent * sizeof(int32_t)));
+    MSM_TRY(hipMalloc(&ws->totals, (nbt + 1) * 4));
+    MSM_TRY(hipMalloc(&ws->bucket_start, (nbt + 1) * 4));
+    MSM_TRY(hipMalloc(&ws->blockbase, nchunks * ws->nwin * ws->nb * 4));
+    MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
     MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint2)));
-    for (int i = 0; i < 2; i++) {
-        const size_t cap = i == 0 ? ws->slot_cap : (2 * ((ws->slot_cap + ws->seg1 - 1) / ws->seg1) + 64);
-        MSM_TRY(hipMalloc(&ws->slot_bucket[i], cap * 4));
-        MSM_TRY(hipMalloc(&ws->slot_pt[i], cap * sizeof(G1X)));
-    }
-    MSM_TRY(hipMalloc(&ws->bucket_sum, nbt * sizeof(G1X)));
-    MSM_TRY(hipMalloc(&ws->block_sum, (nbt / 256) * sizeof(G1X)));
-    MSM_TRY(hipMalloc(&ws->window_sum, ws->nwin * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->slot_bucket, 2 * threads * 4));
+    MSM_TRY(hipMalloc(&ws->slot_pt, 2 * threads * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->bit_sum, (size_t)ws->nwin * c * BITSUM_SPLIT * sizeof(G1X)));
     return ws;
 }
 
 void msm_workspace_destroy(MsmWorkspace* ws) {
     if (!ws) return;
-    hipFree(ws->hist);
-    hipFree(ws->cursor);
+    hipFree(ws->digits);
+    hipFree(ws->totals);
+    hipFree(ws->bucket_start);
+    hipFree(ws->blockbase);
     hipFree(ws->counts);
     hipFree(ws->entries);
-    for (int i = 0; i < 2; i++) {
-        hipFree(ws->slot_bucket[i]);
-        hipFree(ws->slot_pt[i]);
-    }
-    hipFree(ws->bucket_sum);
-    hipFree(ws->block_sum);
-    hipFree(ws->window_sum);
+    hipFree(ws->slot_bucket);
+    hipFree(ws->slot_pt);
+    hipFree(ws->part);
+    hipFree(ws->bit_sum);
     delete ws;
 }
 
+// `table` != nullptr selects the fixed-base mode: table[w * table_stride + i] = 2^(c w) P_i.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
-                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events) {
+                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events,
+                   const G1Affine* table, uint32_t table_stride) {
     if (n > ws->max_n) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
-    const uint32_t nbt = nwin * nb;
-    *nwin_out = nwin;
+    const bool fixed = table != nullptr;
+    const uint32_t slices = fixed ? 1 : nwin;
+    const uint32_t nbt = slices * nb;
+    const uint32_t parts = fixed ? ws->parts_fixed : ws->parts_generic;
+    *nwin_out = slices;
     *c_out = c;
     hipError_t e;
-    if ((e = hipMemsetAsync(ws->hist, 0, (nbt + 1) * 4, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(msm_clear_buckets_kernel, dim3((nbt + 255) / 256), dim3(256), 0, st, ws->bucket_sum, nbt);
+    if ((e = hipMemsetAsync(ws->totals, 0, (nbt + 1) * 4, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ws->counts, 0, 16, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(msm_clear_kernel, dim3((nbt * parts + 255) / 256), dim3(256), 0, st, ws->part, nbt * parts);
     if (n > 0) {
-        const uint32_t nblk = (uint32_t)((n + 255) / 256);
-        hipLaunchKernelGGL(msm_digits_kernel<false>, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, nwin,
-                           ws->hist, (uint2*)nullptr);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->hist, ws->cursor, nbt, ws->counts);
-        hipLaunchKernelGGL(msm_digits_kernel<true>, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, nwin,
-                           ws->cursor, ws->entries);
-        // level 0
-        size_t worst = (size_t)n * nwin;  // worst-case entry count
-        size_t threads = (worst + ws->seg0 - 1) / ws->seg0;
+        const uint32_t n32 = (uint32_t)n;
+        const uint32_t stride = (uint32_t)ws->max_n;
+        const uint32_t nchunks = (n32 + CHUNK - 1) / CHUNK;
+        hipLaunchKernelGGL(msm_recode_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, scalars, n32, stride, c, nwin,
+                           ws->digits);
+        hipLaunchKernelGGL(msm_sort_kernel<false>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
+                           nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
+                           (uint2*)nullptr);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
+        hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
+                           nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
+                           ws->entries);
+        const size_t worst = (size_t)n * nwin;
+        const size_t threads = (worst + SEG0 - 1) / SEG0;
         if (accum_events) hipEventRecord(accum_events[0], st);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                           bases, ws->counts, ws->seg0, ws->bucket_sum, ws->slot_bucket[0], ws->slot_pt[0],
-                           ws->counts + 1);
+                           fixed ? table : bases, ws->counts, parts, ws->part, ws->slot_bucket, ws->slot_pt);
         if (accum_events) hipEventRecord(accum_events[1], st);
-        size_t count = 2 * threads;  // worst-case slot count
-        int cur = 0, level = 1;
-        while (count > 256 && level < 14) {
-            threads = (count + ws->seg1 - 1) / ws->seg1;
-            hipLaunchKernelGGL(msm_reduce_slots_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st,
-                               ws->slot_bucket[cur], ws->slot_pt[cur], ws->counts + level, ws->seg1, ws->bucket_sum,
-                               ws->slot_bucket[cur ^ 1], ws->slot_pt[cur ^ 1], ws->counts + level + 1);
-            count = 2 * threads;
-            cur ^= 1;
-            level++;
-        }
-        hipLaunchKernelGGL(msm_finalize_slots_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st,
-                           ws->slot_bucket[cur], ws->slot_pt[cur], ws->counts + level, ws->bucket_sum);
+        const uint32_t ngroups = nbt * parts;
+        hipLaunchKernelGGL(msm_gather_kernel, dim3((ngroups * GATHER_LANES + 255) / 256), dim3(256), 0, st,
+                           ws->bucket_start, ws->counts, ws->slot_bucket, ws->slot_pt, parts, ngroups, ws->part);
     }
-    hipLaunchKernelGGL(msm_bucket_reduce_kernel, dim3(nbt / 256), dim3(256), 0, st, ws->bucket_sum, nb, ws->block_sum);
-    hipLaunchKernelGGL(msm_window_reduce_kernel, dim3(nwin), dim3(256), 0, st, ws->block_sum, nb / 256,
-                       ws->window_sum);
+    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(256), 0, st, ws->part, parts, nb, c,
+                       ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return hipMemcpyAsync(host_window_sums, ws->window_sum, nwin * sizeof(G1X), hipMemcpyDeviceToHost, st);
+    return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * BITSUM_SPLIT * sizeof(G1X),
+                          hipMemcpyDeviceToHost, st);
 }
 
-G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c) {
+// bit_sums[(w * c + t) * BITSUM_SPLIT + q]: partials of G_{w,t};
+// result = sum_w 2^(c w) sum_t 2^t G_{w,t}  (Horner over all bit positions)
+G1Jac msm_finish_host(const G1X* bit_sums, uint32_t nwin, uint32_t c) {
     G1X acc = G1X::identity();
-    for (int w = (int)nwin - 1; w >= 0; w--) {
-        for (uint32_t i = 0; i < c; i++) acc = g1x_dbl(acc);
-        g1x_add(acc, window_sums[w]);
+    for (int q = (int)(nwin * c) - 1; q >= 0; q--) {
+        if (!acc.is_identity()) acc = g1x_dbl(acc);
+        for (uint32_t k = 0; k < BITSUM_SPLIT; k++) g1x_add(acc, bit_sums[(size_t)q * BITSUM_SPLIT + k]);
     }
     return g1x_to_jac(acc);
 }
