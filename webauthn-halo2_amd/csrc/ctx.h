@@ -31,9 +31,18 @@ struct zk_ctx {
     G1Affine* g_table = nullptr;           // window multiples of g / g_lagrange (fixed-base MSM)
     G1Affine* g_lagrange_table = nullptr;
     uint32_t table_c = 0;
-    // MSM
-    MsmWorkspace* msm_ws = nullptr;
-    G1X* host_wsum = nullptr;  // pinned
+    // MSM lanes: each in-flight MSM owns a workspace, a tail stream and a pinned result buffer
+    static constexpr int MSM_LANES = 3;
+    struct MsmLane {
+        MsmWorkspace* ws = nullptr;
+        hipStream_t tail = nullptr;
+        hipEvent_t head_done = nullptr, tail_done = nullptr;
+        hipEvent_t t_head[2] = {nullptr, nullptr}, t_acc[2] = {nullptr, nullptr};  // timing: whole head / accumulate kernel
+        size_t n = 0;
+        G1X* host_buf = nullptr;  // pinned
+        bool busy = false;
+        uint32_t nwin = 0, cw = 0;
+    } lanes[MSM_LANES];
     // scratch
     Fr* scratch = nullptr;
     size_t scratch_n = 0;
@@ -51,6 +60,8 @@ struct zk_ctx {
     bool ev_valid[ZK_T_COUNT] = {false};
     double acc_ms[ZK_T_COUNT] = {0};   // accumulated over calls since zk_timer_reset (MSM kinds only)
     uint64_t acc_n[ZK_T_COUNT] = {0};
+    uint64_t msm_launches = 0;
+    float last_plain_ms[ZK_T_COUNT] = {0};
 };
 
 #define HIPCHK(ctx, x)                 \
@@ -68,6 +79,10 @@ int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);
 // MSM of device-resident scalars against device-resident bases -> Jacobian on host (synchronises)
 int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out);
+// split form: begin enqueues the MSM on lane `lane` (head on the context stream, tail on the
+// lane's stream) and returns; end waits for the lane and finishes on the host.
+int ctx_msm_begin(zk_ctx* c, int lane, const Fr* d_scalars, const G1Affine* d_bases, size_t n);
+int ctx_msm_end(zk_ctx* c, int lane, G1Jac* out);
 // NTT between device buffers: inverse => x 1/N; coset => zeta scaling (coeff_to_extended / extended_to_coeff)
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out);
 void pk_destroy_all(zk_ctx* c);

@@ -42,7 +42,8 @@ hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affi
 // (one bucket set, *nwin_out = 1); otherwise *nwin_out windows need the host Horner.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
                    G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events = nullptr,
-                   const G1Affine* table = nullptr, uint32_t table_stride = 0);
+                   const G1Affine* table = nullptr, uint32_t table_stride = 0, hipStream_t tail_st = nullptr,
+                   hipEvent_t head_done = nullptr);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).
 G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
 

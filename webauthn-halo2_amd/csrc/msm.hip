@@ -479,9 +479,12 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
 }
 
 // `table` != nullptr selects the fixed-base mode: table[w * table_stride + i] = 2^(c w) P_i.
+// The "head" (recode .. accumulate) runs on `st`; the latency-bound "tail" (gather, bit sums,
+// D2H) runs on `tail_st` after `head_done`, so that the caller can put the next MSM's head (or
+// any other kernels) on `st` right away.  tail_st == st gives the plain sequential order.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
                    G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events,
-                   const G1Affine* table, uint32_t table_stride) {
+                   const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done) {
     if (n > ws->max_n) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const bool fixed = table != nullptr;
@@ -513,15 +516,23 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
                            fixed ? table : bases, ws->counts, parts, ws->part, ws->slot_bucket, ws->slot_pt);
         if (accum_events) hipEventRecord(accum_events[1], st);
+    }
+    hipStream_t ts = st;
+    if (tail_st && tail_st != st) {
+        if ((e = hipEventRecord(head_done, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(tail_st, head_done, 0)) != hipSuccess) return e;
+        ts = tail_st;
+    }
+    if (n > 0) {
         const uint32_t ngroups = nbt * parts;
-        hipLaunchKernelGGL(msm_gather_kernel, dim3((ngroups * GATHER_LANES + 255) / 256), dim3(256), 0, st,
+        hipLaunchKernelGGL(msm_gather_kernel, dim3((ngroups * GATHER_LANES + 255) / 256), dim3(256), 0, ts,
                            ws->bucket_start, ws->counts, ws->slot_bucket, ws->slot_pt, parts, ngroups, ws->part);
     }
-    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(256), 0, st, ws->part, parts, nb, c,
+    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(256), 0, ts, ws->part, parts, nb, c,
                        ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * BITSUM_SPLIT * sizeof(G1X),
-                          hipMemcpyDeviceToHost, st);
+                          hipMemcpyDeviceToHost, ts);
 }
 
 // bit_sums[(w * c + t) * BITSUM_SPLIT + q]: partials of G_{w,t};

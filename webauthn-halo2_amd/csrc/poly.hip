@@ -5,6 +5,7 @@
 // sites halo2-circuits/src/ecc/ecdsa_p256.rs:258,338,388 via gen_srs, and the
 // evaluation phase of create_proof at :366-373,416-423).
 #include "engine.h"
+#include "prover.h"
 
 namespace zk {
 
@@ -71,6 +72,70 @@ void launch_eval(const Fr* c, uint32_t n, const Fr& x, Fr* scratch, hipStream_t 
     }
     hipLaunchKernelGGL(poly_eval_partial_kernel, dim3(blocks), dim3(256), 0, st, c, n, x, y, scratch);
     hipLaunchKernelGGL(poly_sum_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, scratch + blocks);
+}
+
+// Batched form: blockIdx.y selects the (polynomial, point) pair; one launch evaluates every
+// opened value of a proof (18 at k=19, 43 at k=17).
+__global__ __launch_bounds__(256) void poly_eval_batch_kernel(const EvalBatchArgs* __restrict__ args, uint32_t n,
+                                                              Fr* __restrict__ block_out) {
+    __shared__ Fr sh[256];
+    const uint32_t e = blockIdx.y;
+    const Fr* __restrict__ c = args->poly[e];
+    const Fr x = args->x[e], y = args->y[e];
+    const uint32_t S = gridDim.x * 256;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    Fr acc = Fr::zero();
+    if (t < n) {
+        uint32_t m = (n - 1 - t) / S;
+        acc = fe_load(c + t + m * S);
+        while (m-- > 0) acc = fe_add(fe_mul(acc, y), fe_load(c + t + m * S));
+        Fr xp = Fr::one();
+        Fr base = x;
+        for (uint32_t k = t; k; k >>= 1) {
+            if (k & 1) xp = fe_mul(xp, base);
+            base = fe_sqr(base);
+        }
+        acc = fe_mul(acc, xp);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store(block_out + e * gridDim.x + blockIdx.x, sh[0]);
+}
+
+__global__ __launch_bounds__(256) void poly_sum_batch_kernel(const Fr* __restrict__ in, uint32_t m, Fr* __restrict__ out) {
+    __shared__ Fr sh[256];
+    const Fr* src = in + (size_t)blockIdx.x * m;
+    Fr acc = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < m; i += 256) acc = fe_add(acc, fe_load(src + i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store(out + blockIdx.x, sh[0]);
+}
+
+// host fills h_args->{poly,x}; y = x^S is derived here.  scratch: count * blocks elements; out: count.
+void launch_eval_batch(EvalBatchArgs* h_args, EvalBatchArgs* d_args, uint32_t count, uint32_t n, Fr* scratch, Fr* out,
+                       hipStream_t st) {
+    const uint32_t blocks = eval_blocks(n);
+    const uint32_t S = blocks * 256;
+    for (uint32_t e = 0; e < count; e++) {
+        Fr y = Fr::one(), base = h_args->x[e];
+        for (uint32_t k = S; k; k >>= 1) {
+            if (k & 1) y = fe_mul(y, base);
+            base = fe_sqr(base);
+        }
+        h_args->y[e] = y;
+    }
+    hipMemcpyAsync(d_args, h_args, sizeof(EvalBatchArgs), hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(poly_eval_batch_kernel, dim3(blocks, count), dim3(256), 0, st, d_args, n, scratch);
+    hipLaunchKernelGGL(poly_sum_batch_kernel, dim3(count), dim3(256), 0, st, scratch, blocks, out);
 }
 
 // ------------------------------------------------------------------ SRS ----

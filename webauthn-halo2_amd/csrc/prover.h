@@ -30,6 +30,7 @@ struct ChaChaKey {
 
 struct LookupScratch {
     uint32_t *hist, *present, *absent, *off, *dex, *aex, *err;  // T + 1 entries each (err: 1)
+    uint32_t* bsum;  // 3 x ceil(T / 1024) block sums
 };
 
 struct PermArgs {
@@ -83,6 +84,14 @@ void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c
 void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
 
 // poly.hip
+static constexpr uint32_t MAX_EVALS = 96;
+struct EvalBatchArgs {
+    const Fr* poly[MAX_EVALS];
+    Fr x[MAX_EVALS];
+    Fr y[MAX_EVALS];
+};
+void launch_eval_batch(EvalBatchArgs* h_args, EvalBatchArgs* d_args, uint32_t count, uint32_t n, Fr* scratch, Fr* out,
+                       hipStream_t st);
 uint32_t eval_blocks(uint32_t n);
 void launch_eval(const Fr* c, uint32_t n, const Fr& x, Fr* scratch, hipStream_t st);
 

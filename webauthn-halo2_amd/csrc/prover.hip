@@ -98,6 +98,8 @@ struct zk_pk_rec {
     LookupScratch lks{};
     uint32_t* lk_u32 = nullptr;
     QuotientArgs* d_qargs = nullptr;
+    EvalBatchArgs *d_evargs = nullptr, *h_evargs = nullptr;
+    Fr *ev_scratch = nullptr, *ev_out = nullptr;
 };
 
 namespace {
@@ -200,6 +202,8 @@ void pk_destroy(zk_pk_rec* pk) {
     if (pk->tail_host) hipHostFree(pk->tail_host);
     if (pk->lk_u32) hipFree(pk->lk_u32);
     if (pk->d_qargs) hipFree(pk->d_qargs);
+    if (pk->d_evargs) hipFree(pk->d_evargs);
+    if (pk->h_evargs) hipHostFree(pk->h_evargs);
     delete pk;
 }
 
@@ -397,8 +401,13 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->t_b = d.alloc(n);
     pk->t_small = d.alloc(n / 16 + 4096);
     if (d.rc) return fail(d.rc);
-    if (hipHostMalloc(&pk->tail_host, 64 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
-    if (hipMalloc(&pk->lk_u32, (size_t)(T + 2) * 6 * 4 + 16) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->tail_host, 128 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->h_evargs, sizeof(EvalBatchArgs)) != hipSuccess || hipMalloc(&pk->d_evargs, sizeof(EvalBatchArgs)) != hipSuccess)
+        return fail(ZK_ENOMEM);
+    pk->ev_scratch = d.alloc((size_t)MAX_EVALS * eval_blocks(n));
+    pk->ev_out = d.alloc(MAX_EVALS);
+    if (d.rc) return fail(d.rc);
+    if (hipMalloc(&pk->lk_u32, (size_t)(T + 2) * 6 * 4 + 16 + (size_t)3 * (T / 1024 + 2) * 4) != hipSuccess) return fail(ZK_ENOMEM);
     {
         uint32_t* b = pk->lk_u32;
         pk->lks.hist = b;
@@ -408,6 +417,7 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
         pk->lks.dex = b + 4 * (T + 2);
         pk->lks.aex = b + 5 * (T + 2);
         pk->lks.err = b + 6 * (T + 2);
+        pk->lks.bsum = b + 6 * (T + 2) + 4;
     }
     if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess) return fail(ZK_ENOMEM);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
@@ -482,11 +492,24 @@ struct Prover {
         for (auto& x : v) x = rng.next_fr();
         return v;
     }
-    void commit_write(const Fr* poly, size_t len, int basis) {
+    void commit_write(const Fr* poly, size_t len, int basis) { commit_write_lane(0, poly, len, basis); }
+    void commit_write_lane(int lane, const Fr* poly, size_t len, int basis) {
+        commit_begin(lane, poly, len, basis);
+        commit_end_write(lane);
+    }
+    // split commit: the MSM is enqueued on `lane` and its latency-bound tail overlaps whatever is
+    // launched next; the point is written to the transcript when the lane is collected.
+    void commit_begin(int lane, const Fr* poly, size_t len, int basis) {
         if (!ok()) return;
-        G1Affine p;
-        if (!commit(c, poly, len, basis, &p)) return fail(ZK_EHIP);
-        if (!tr->write_point(p)) fail(ZK_EINVAL);  // identity commitment: halo2 refuses to write it
+        int r = ctx_msm_begin(c, lane, poly, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, len);
+        if (r) fail(r);
+    }
+    void commit_end_write(int lane) {
+        if (!ok()) return;
+        G1Jac j;
+        int r = ctx_msm_end(c, lane, &j);
+        if (r) return fail(r);
+        if (!tr->write_point(g1_jac_to_affine_host(j))) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
     }
     void to_coeff(const Fr* val, Fr* poly) {
         if (!ok()) return;
@@ -525,19 +548,35 @@ struct Prover {
         const uint32_t bf = BLINDING_FACTORS, usable = lay.usable;
         tr->common_scalar(pk->transcript_repr);
 
+        // Commitments are computed as early as their inputs exist (none of a', s', the random
+        // polynomial needs a challenge) and collected in transcript order; RNG draws keep
+        // halo2's order (the random polynomial's block range is reserved up front).
         // -- 1. advice
         for (uint32_t j = 0; j < lay.n_adv; j++) {
             hipMemcpyAsync(pk->adv_val[j], advice_dev[j], (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
             set_rows(pk->adv_val[j], usable, draw(bf + 1));
         }
         draw(lay.n_adv);  // advice blinds (unused by KZG, still drawn)
-        for (uint32_t j = 0; j < lay.n_adv && ok(); j++) commit_write(pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+        // few advice columns (k=19: one): pipeline them with the lookup commitments; many: plain order
+        const bool pipe = lay.n_adv == 1 && lay.n_lookups == 1;
+        if (pipe) {
+            commit_begin(0, pk->adv_val[0], n, ZK_BASIS_LAGRANGE);
+        } else {
+            for (uint32_t j = 0; j < lay.n_adv && ok(); j++) commit_write(pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+        }
         if (!ok()) return rc;
-        const Fr theta = tr->squeeze();
-        (void)theta;  // single-expression lookups: theta-compression is the identity
 
-        // -- 2. lookups: permuted input / table
+        // -- 2. lookups: permuted input / table (single-expression lookups: theta-compression is the identity)
         const uint32_t T = 1u << lay.lookup_bits;
+        Fr theta = Fr::zero();
+        bool theta_done = false;
+        auto squeeze_theta = [&]() {
+            if (!theta_done) {
+                if (pipe) commit_end_write(0);
+                theta = tr->squeeze();
+                theta_done = true;
+            }
+        };
         for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
             const Fr* inp;
             if (lay.single) {
@@ -551,16 +590,38 @@ struct Prover {
             if (hipMemcpyAsync(&err, pk->lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
                 return ZK_EHIP;
-            if (err) return ZK_EWITNESS;  // lookup input not in table (halo2: ConstraintSystemFailure)
+            if (err) {
+                for (int q = 0; q < zk_ctx::MSM_LANES; q++)
+                    if (c->lanes[q].busy) {
+                        G1Jac dummy;
+                        ctx_msm_end(c, q, &dummy);
+                    }
+                return ZK_EWITNESS;  // lookup input not in table (halo2: ConstraintSystemFailure)
+            }
             set_rows(pk->lk_ap[l], usable, draw(bf + 1));
             set_rows(pk->lk_sp[l], usable, draw(bf + 1));
             draw(2);
-            commit_write(pk->lk_ap[l], n, ZK_BASIS_LAGRANGE);
-            commit_write(pk->lk_sp[l], n, ZK_BASIS_LAGRANGE);
+            commit_begin(1, pk->lk_ap[l], n, ZK_BASIS_LAGRANGE);
+            commit_begin(2, pk->lk_sp[l], n, ZK_BASIS_LAGRANGE);
+            squeeze_theta();
+            commit_end_write(1);
+            commit_end_write(2);
         }
+        squeeze_theta();
+        (void)theta;
         if (!ok()) return rc;
         const Fr beta = tr->squeeze();
         const Fr gamma = tr->squeeze();
+
+        // -- 5 (early). vanishing argument: the random polynomial does not depend on any challenge.
+        // Its n draws come after the grand products' draws in halo2's order: reserve that block range.
+        {
+            const uint64_t skip = (uint64_t)lay.n_chunks * (bf + 1) + (uint64_t)lay.n_lookups * (bf + 1);
+            ChaChaKey key;
+            memcpy(key.w, rng.key, 32);
+            launch_chacha_fr(key, rng.block + skip, pk->random_poly, n, st);
+            commit_begin(0, pk->random_poly, n, ZK_BASIS_MONOMIAL);
+        }
 
         // -- 3. permutation grand products
         {
@@ -590,8 +651,14 @@ struct Prover {
                 launch_prefix_product(pk->t_frac, pk->z_val[ci], n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
                 set_rows(pk->z_val[ci], n - bf, draw(bf));
                 draw(1);
-                commit_write(pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
+                // lanes 1 and 2 alternate; the previous chunk's tail overlaps this chunk's kernels
+                const int lane = 1 + (int)(ci & 1);
+                if (ci >= 2) commit_end_write(lane);
+                commit_begin(lane, pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
             }
+            // collect in order
+            if (lay.n_chunks >= 2) commit_end_write(1 + (int)(lay.n_chunks & 1));
+            commit_end_write(1 + (int)((lay.n_chunks - 1) & 1));
         }
         // -- 4. lookup grand products
         for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
@@ -601,19 +668,14 @@ struct Prover {
             launch_prefix_product(pk->t_frac, pk->lk_z[l], n, nullptr, Fr::one(), pk->t_a, pk->t_small, st);
             set_rows(pk->lk_z[l], n - bf, draw(bf));
             draw(1);
-            commit_write(pk->lk_z[l], n, ZK_BASIS_LAGRANGE);
+            commit_write_lane(1, pk->lk_z[l], n, ZK_BASIS_LAGRANGE);
         }
         if (!ok()) return rc;
 
-        // -- 5. vanishing argument: random polynomial (n draws, generated on the device from the same stream)
-        {
-            ChaChaKey key;
-            memcpy(key.w, rng.key, 32);
-            launch_chacha_fr(key, rng.block, pk->random_poly, n, st);
-            rng.block += n;
-            draw(1);
-            commit_write(pk->random_poly, n, ZK_BASIS_MONOMIAL);
-        }
+        // -- 5. collect the random polynomial's commitment (its draws happen here in stream order)
+        rng.block += n;
+        draw(1);
+        commit_end_write(0);
         if (!ok()) return rc;
         const Fr y = tr->squeeze();
 
@@ -693,28 +755,22 @@ struct Prover {
             if (r) return r;
         }
         draw(lay.n_h);  // h-piece blinds
-        for (uint32_t i = 0; i < lay.n_h && ok(); i++) commit_write(pk->h_ext + (size_t)i * n, n, ZK_BASIS_MONOMIAL);
+        for (uint32_t i = 0; i < lay.n_h && ok(); i++) {
+            const int lane = (int)(i % zk_ctx::MSM_LANES);
+            if (i >= (uint32_t)zk_ctx::MSM_LANES) commit_end_write(lane);  // oldest in flight, in order
+            commit_begin(lane, pk->h_ext + (size_t)i * n, n, ZK_BASIS_MONOMIAL);
+        }
+        for (uint32_t i = (lay.n_h > (uint32_t)zk_ctx::MSM_LANES ? lay.n_h - zk_ctx::MSM_LANES : 0); i < lay.n_h && ok(); i++)
+            commit_end_write((int)(i % zk_ctx::MSM_LANES));
         if (!ok()) return rc;
         const Fr x = tr->squeeze();
 
-        // -- 7. evaluations
+        // -- 7. evaluations: every opened value in ONE batched launch, then written in transcript order
         struct Q {
             const Fr* poly;
             int rot;
             Fr eval;
         };
-        std::vector<Q> queries;  // prover query order (== verifier's)
-        std::vector<Q> adv_q, fix_q, sig_q, z_q, lk_q;
-        for (auto& aq : lay.advice_queries) {
-            Q qq{pk->adv_poly[aq.first], aq.second, eval(pk->adv_poly[aq.first], n, xrot(x, aq.second))};
-            tr->write_scalar(qq.eval);
-            adv_q.push_back(qq);
-        }
-        for (uint32_t f = 0; f < lay.n_fix; f++) {
-            Q qq{pk->fixed_poly[f], 0, eval(pk->fixed_poly[f], n, x)};
-            tr->write_scalar(qq.eval);
-            fix_q.push_back(qq);
-        }
         // h(X) = sum x^(n i) h_i(X)
         const Fr xn = fr_pow(x, n);
         {
@@ -733,55 +789,72 @@ struct Prover {
             }
             launch_lincomb(a, st);
         }
-        const Q rand_q{pk->random_poly, 0, eval(pk->random_poly, n, x)};
-        tr->write_scalar(rand_q.eval);
-        for (uint32_t p = 0; p < lay.perm_cols.size(); p++) {
-            Q qq{pk->sigma_poly[p], 0, eval(pk->sigma_poly[p], n, x)};
-            tr->write_scalar(qq.eval);
-            sig_q.push_back(qq);
-        }
-        std::vector<Q> z_last_q(lay.n_chunks);
+        std::vector<Q> ev;  // transcript order, then h(x) (not written)
+        for (auto& aq : lay.advice_queries) ev.push_back(Q{pk->adv_poly[aq.first], aq.second, Fr::zero()});
+        const size_t i_fix = ev.size();
+        for (uint32_t f = 0; f < lay.n_fix; f++) ev.push_back(Q{pk->fixed_poly[f], 0, Fr::zero()});
+        const size_t i_rand = ev.size();
+        ev.push_back(Q{pk->random_poly, 0, Fr::zero()});
+        const size_t i_sig = ev.size();
+        for (uint32_t p = 0; p < lay.perm_cols.size(); p++) ev.push_back(Q{pk->sigma_poly[p], 0, Fr::zero()});
+        const size_t i_z = ev.size();
         for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
-            Q q0{pk->z_poly[ci], 0, eval(pk->z_poly[ci], n, x)};
-            Q q1{pk->z_poly[ci], 1, eval(pk->z_poly[ci], n, xrot(x, 1))};
-            tr->write_scalar(q0.eval);
-            tr->write_scalar(q1.eval);
-            z_q.push_back(q0);
-            z_q.push_back(q1);
-            if (ci != lay.n_chunks - 1) {
-                Q q2{pk->z_poly[ci], lay.last_rot, eval(pk->z_poly[ci], n, xrot(x, lay.last_rot))};
-                tr->write_scalar(q2.eval);
-                z_last_q[ci] = q2;
-            }
+            ev.push_back(Q{pk->z_poly[ci], 0, Fr::zero()});
+            ev.push_back(Q{pk->z_poly[ci], 1, Fr::zero()});
+            if (ci != lay.n_chunks - 1) ev.push_back(Q{pk->z_poly[ci], lay.last_rot, Fr::zero()});
         }
+        const size_t i_lk = ev.size();
         for (uint32_t l = 0; l < lay.n_lookups; l++) {
-            Q zq{pk->lk_z_poly[l], 0, eval(pk->lk_z_poly[l], n, x)};
-            Q zn_{pk->lk_z_poly[l], 1, eval(pk->lk_z_poly[l], n, xrot(x, 1))};
-            Q aq{pk->lk_ap_poly[l], 0, eval(pk->lk_ap_poly[l], n, x)};
-            Q am{pk->lk_ap_poly[l], -1, eval(pk->lk_ap_poly[l], n, xrot(x, -1))};
-            Q sq{pk->lk_sp_poly[l], 0, eval(pk->lk_sp_poly[l], n, x)};
-            tr->write_scalar(zq.eval);
-            tr->write_scalar(zn_.eval);
-            tr->write_scalar(aq.eval);
-            tr->write_scalar(am.eval);
-            tr->write_scalar(sq.eval);
-            // query order: zL@x, a'@x, s'@x, a'@w^-1 x, zL@wx
-            lk_q.push_back(zq);
-            lk_q.push_back(aq);
-            lk_q.push_back(sq);
-            lk_q.push_back(am);
-            lk_q.push_back(zn_);
+            ev.push_back(Q{pk->lk_z_poly[l], 0, Fr::zero()});
+            ev.push_back(Q{pk->lk_z_poly[l], 1, Fr::zero()});
+            ev.push_back(Q{pk->lk_ap_poly[l], 0, Fr::zero()});
+            ev.push_back(Q{pk->lk_ap_poly[l], -1, Fr::zero()});
+            ev.push_back(Q{pk->lk_sp_poly[l], 0, Fr::zero()});
         }
-        if (!ok()) return rc;
-        const Q h_q{pk->h_comb, 0, eval(pk->h_comb, n, x)};
-        queries = adv_q;
-        queries.insert(queries.end(), z_q.begin(), z_q.end());
-        for (int ci = (int)lay.n_chunks - 2; ci >= 0; ci--) queries.push_back(z_last_q[ci]);
-        queries.insert(queries.end(), lk_q.begin(), lk_q.end());
-        queries.insert(queries.end(), fix_q.begin(), fix_q.end());
-        queries.insert(queries.end(), sig_q.begin(), sig_q.end());
-        queries.push_back(h_q);
-        queries.push_back(rand_q);
+        const size_t n_written = ev.size();
+        ev.push_back(Q{pk->h_comb, 0, Fr::zero()});
+        if (ev.size() > MAX_EVALS) return ZK_EINVAL;
+        {
+            EvalBatchArgs* ha = pk->h_evargs;
+            for (size_t i = 0; i < ev.size(); i++) {
+                ha->poly[i] = ev[i].poly;
+                ha->x[i] = xrot(x, ev[i].rot);
+            }
+            hipEventRecord(c->ev[ZK_T_EVAL][0], st);
+            launch_eval_batch(ha, pk->d_evargs, (uint32_t)ev.size(), n, pk->ev_scratch, pk->ev_out, st);
+            hipEventRecord(c->ev[ZK_T_EVAL][1], st);
+            c->ev_valid[ZK_T_EVAL] = true;
+            if (hipMemcpyAsync(pk->tail_host, pk->ev_out, ev.size() * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return ZK_EHIP;
+            for (size_t i = 0; i < ev.size(); i++) ev[i].eval = pk->tail_host[i];
+        }
+        for (size_t i = 0; i < n_written; i++) tr->write_scalar(ev[i].eval);
+        // prover query order (== verifier's): advice, perm z (x, wx per chunk; then `last` in reverse), lookups
+        // (zL@x, a'@x, s'@x, a'@w^-1 x, zL@wx), fixed, sigma, h, random
+        std::vector<Q> queries(ev.begin(), ev.begin() + i_fix);
+        {
+            std::vector<Q> lastq(lay.n_chunks);
+            size_t pos = i_z;
+            for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+                queries.push_back(ev[pos++]);
+                queries.push_back(ev[pos++]);
+                if (ci != lay.n_chunks - 1) lastq[ci] = ev[pos++];
+            }
+            for (int ci = (int)lay.n_chunks - 2; ci >= 0; ci--) queries.push_back(lastq[ci]);
+            pos = i_lk;
+            for (uint32_t l = 0; l < lay.n_lookups; l++, pos += 5) {
+                queries.push_back(ev[pos]);      // zL @ x
+                queries.push_back(ev[pos + 2]);  // a' @ x
+                queries.push_back(ev[pos + 4]);  // s' @ x
+                queries.push_back(ev[pos + 3]);  // a' @ w^-1 x
+                queries.push_back(ev[pos + 1]);  // zL @ w x
+            }
+            for (size_t i = i_fix; i < i_rand; i++) queries.push_back(ev[i]);
+            for (size_t i = i_sig; i < i_z; i++) queries.push_back(ev[i]);
+            queries.push_back(ev[n_written]);  // h
+            queries.push_back(ev[i_rand]);     // random poly
+        }
         if (!ok()) return rc;
 
         // -- 8. multi-open
@@ -1006,6 +1079,11 @@ extern "C" int zk_prove(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advi
     Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
     Prover p(c, pk, rng_seed, tr);
     rc = p.run(adv.data(), scheme);
+    for (int q = 0; q < zk_ctx::MSM_LANES; q++)  // an early error may leave commitments in flight
+        if (c->lanes[q].busy) {
+            G1Jac dummy;
+            ctx_msm_end(c, q, &dummy);
+        }
     hipStreamSynchronize(c->stream);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;

@@ -133,19 +133,26 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t 
 // rows 0..T-1 and zeros up to the usable rows (halo2-lib RangeConfig; known answer
 // K2).  hist[v] = multiplicity of v in the first `usable` input rows; err set if an
 // input is not a table element (halo2: Error::ConstraintSystemFailure).
-__global__ void lk_hist_kernel(const Fr* __restrict__ inp, uint32_t usable, uint32_t T, uint32_t* __restrict__ hist,
-                               uint32_t* __restrict__ err) {
+__global__ __launch_bounds__(256) void lk_hist_kernel(const Fr* __restrict__ inp, uint32_t usable, uint32_t T,
+                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= usable) return;
-    const Fr v = fe_from_mont(fe_load(inp + i));
-    uint32_t hi = 0;
+    uint32_t val = 0xffffffffu;  // not a table element / out of range
+    if (i < usable) {
+        const Fr v = fe_from_mont(fe_load(inp + i));
+        uint32_t hi = 0;
 #pragma unroll
-    for (int k = 1; k < 8; k++) hi |= v.v[k];
-    if (hi || v.v[0] >= T) {
-        atomicOr(err, 1u);
-        return;
+        for (int k = 1; k < 8; k++) hi |= v.v[k];
+        if (hi || v.v[0] >= T) atomicOr(err, 1u);
+        else val = v.v[0];
     }
-    atomicAdd(&hist[v.v[0]], 1u);
+    // unselected rows contribute q_lookup * a = 0: most of the column hits hist[0].
+    // Count zeros per wave with a ballot and issue one atomic for them.
+    const unsigned long long zmask = __ballot(val == 0);
+    if (val == 0) {
+        if ((threadIdx.x & 63) == (uint32_t)__ffsll((long long)zmask) - 1) atomicAdd(&hist[0], (uint32_t)__popcll(zmask));
+    } else if (val != 0xffffffffu) {
+        atomicAdd(&hist[val], 1u);
+    }
 }
 
 // present[v] = hist[v] > 0 ; absent[v] = (v >= 1 && hist[v] == 0)
@@ -202,14 +209,111 @@ __global__ void lk_fill_kernel(uint32_t usable, uint32_t T, const uint32_t* __re
     fe_store(sp + p, small_to_mont(a));
 }
 
+// Three exclusive scans over T entries at once (hist, present, absent), multi-block:
+// (1) per-block sums, (2) one small block scans the block sums, (3) block-local scan + offset.
+static constexpr uint32_t S3_BLOCK = 1024;  // elements per block (256 threads x 4)
+
+__global__ __launch_bounds__(256) void scan3_sums_kernel(const uint32_t* __restrict__ a0, const uint32_t* __restrict__ a1,
+                                                         const uint32_t* __restrict__ a2, uint32_t m,
+                                                         uint32_t* __restrict__ bsum /* [3][nblocks] */, uint32_t nblocks) {
+    __shared__ uint32_t sh[3][256];
+    const uint32_t base = blockIdx.x * S3_BLOCK + threadIdx.x * 4;
+    uint32_t s0 = 0, s1 = 0, s2 = 0;
+    for (uint32_t k = 0; k < 4; k++)
+        if (base + k < m) {
+            s0 += a0[base + k];
+            s1 += a1[base + k];
+            s2 += a2[base + k];
+        }
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    sh[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d)
+            for (int q = 0; q < 3; q++) sh[q][threadIdx.x] += sh[q][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) bsum[threadIdx.x * nblocks + blockIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(1024) void scan3_top_kernel(uint32_t* __restrict__ bsum, uint32_t nblocks) {
+    // exclusive scan of each of the 3 rows in place; nblocks <= 1024 * 8
+    __shared__ uint32_t part[1024];
+    for (int q = 0; q < 3; q++) {
+        uint32_t* row = bsum + q * nblocks;
+        const uint32_t chunk = (nblocks + 1023) / 1024;
+        const uint32_t lo = min(nblocks, threadIdx.x * chunk), hi = min(nblocks, lo + chunk);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; i++) sum += row[i];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t v = (threadIdx.x >= d) ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = part[threadIdx.x] - sum;
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t h = row[i];
+            row[i] = run;
+            run += h;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void scan3_apply_kernel(const uint32_t* __restrict__ a0, const uint32_t* __restrict__ a1,
+                                                          const uint32_t* __restrict__ a2, uint32_t m,
+                                                          const uint32_t* __restrict__ bsum, uint32_t nblocks,
+                                                          uint32_t* __restrict__ o0, uint32_t* __restrict__ o1,
+                                                          uint32_t* __restrict__ o2) {
+    __shared__ uint32_t sh[3][256];
+    const uint32_t base = blockIdx.x * S3_BLOCK + threadIdx.x * 4;
+    uint32_t v[3][4];
+    uint32_t s[3] = {0, 0, 0};
+    for (uint32_t k = 0; k < 4; k++) {
+        const bool in = base + k < m;
+        v[0][k] = in ? a0[base + k] : 0;
+        v[1][k] = in ? a1[base + k] : 0;
+        v[2][k] = in ? a2[base + k] : 0;
+        for (int q = 0; q < 3; q++) s[q] += v[q][k];
+    }
+    for (int q = 0; q < 3; q++) sh[q][threadIdx.x] = s[q];
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t t[3] = {0, 0, 0};
+        if (threadIdx.x >= d)
+            for (int q = 0; q < 3; q++) t[q] = sh[q][threadIdx.x - d];
+        __syncthreads();
+        for (int q = 0; q < 3; q++) sh[q][threadIdx.x] += t[q];
+        __syncthreads();
+    }
+    const uint32_t* const ins[3] = {a0, a1, a2};
+    (void)ins;
+    uint32_t* const outs[3] = {o0, o1, o2};
+    for (int q = 0; q < 3; q++) {
+        uint32_t run = bsum[q * nblocks + blockIdx.x] + sh[q][threadIdx.x] - s[q];
+        for (uint32_t k = 0; k < 4; k++) {
+            if (base + k < m) outs[q][base + k] = run;
+            run += v[q][k];
+        }
+        // total at index m (exclusive scan convention used by lk_fill)
+        if (blockIdx.x == nblocks - 1 && threadIdx.x == 255) outs[q][m] = run;
+    }
+}
+
 void launch_lookup_permute(const Fr* inp, uint32_t usable, uint32_t T, LookupScratch& s, Fr* ap, Fr* sp, hipStream_t st) {
     hipMemsetAsync(s.hist, 0, (T + 1) * 4, st);
     hipMemsetAsync(s.err, 0, 4, st);
     hipLaunchKernelGGL(lk_hist_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, inp, usable, T, s.hist, s.err);
     hipLaunchKernelGGL(lk_flags_kernel, dim3((T + 255) / 256), dim3(256), 0, st, s.hist, T, s.present, s.absent);
-    launch_scan_u32(s.hist, s.off, T, st);
-    launch_scan_u32(s.present, s.dex, T, st);
-    launch_scan_u32(s.absent, s.aex, T, st);
+    const uint32_t nblocks = (T + S3_BLOCK - 1) / S3_BLOCK;
+    hipLaunchKernelGGL(scan3_sums_kernel, dim3(nblocks), dim3(256), 0, st, s.hist, s.present, s.absent, T, s.bsum, nblocks);
+    hipLaunchKernelGGL(scan3_top_kernel, dim3(1), dim3(1024), 0, st, s.bsum, nblocks);
+    hipLaunchKernelGGL(scan3_apply_kernel, dim3(nblocks), dim3(256), 0, st, s.hist, s.present, s.absent, T, s.bsum, nblocks,
+                       s.off, s.dex, s.aex);
     hipLaunchKernelGGL(lk_fill_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, usable, T, s.hist, s.off, s.dex, s.aex, ap, sp);
 }
 
