@@ -399,7 +399,7 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->t_frac = d.alloc(n);
     pk->t_a = d.alloc(n);
     pk->t_b = d.alloc(n);
-    pk->t_small = d.alloc(n / 16 + 4096);
+    pk->t_small = d.alloc(n / 16 + 8192);
     if (d.rc) return fail(d.rc);
     if (hipHostMalloc(&pk->tail_host, 128 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
     if (hipHostMalloc(&pk->h_evargs, sizeof(EvalBatchArgs)) != hipSuccess || hipMalloc(&pk->d_evargs, sizeof(EvalBatchArgs)) != hipSuccess)
@@ -871,6 +871,7 @@ struct Prover {
                     }
                 if (!found) sets.push_back({qq.rot, {qq}});
             }
+            size_t set_idx = 0;
             for (auto& s : sets) {
                 if (s.second.size() > MAX_LC) return ZK_EINVAL;
                 LincombArgs a;
@@ -891,9 +892,16 @@ struct Prover {
                 a.sub0_val = eb;
                 launch_lincomb(a, st);
                 launch_kate_division(pk->t_a, pk->t_b, n, xrot(x, s.first), pk->t_small, pk->t_small + (n / 32 + 8), st);
-                commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
+                // the witness commitments need no challenge in between: keep up to MSM_LANES in flight
+                // (t_b is consumed by the MSM's recode kernel before the next set overwrites it: stream order)
+                const int lane = (int)(set_idx % zk_ctx::MSM_LANES);
+                if (set_idx >= (size_t)zk_ctx::MSM_LANES) commit_end_write(lane);
+                commit_begin(lane, pk->t_b, n, ZK_BASIS_MONOMIAL);
+                set_idx++;
                 if (!ok()) return rc;
             }
+            for (size_t i = (set_idx > (size_t)zk_ctx::MSM_LANES ? set_idx - zk_ctx::MSM_LANES : 0); i < set_idx && ok(); i++)
+                commit_end_write((int)(i % zk_ctx::MSM_LANES));
         } else {
             // SHPLONK: group commitments by their set of rotations
             struct CR {

@@ -472,69 +472,119 @@ __global__ void kd_chunk_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, Fr* 
     fe_store(cval + t, acc);
 }
 
-// carry[t] = sum_{s > t} c_s * Z^(s - t - 1)   (single block, suffix scan of affine maps x -> Z^len x + c)
-__global__ __launch_bounds__(1024) void kd_carry_kernel(const Fr* __restrict__ cval, uint32_t m, Fr Z, Fr* __restrict__ carry) {
-    __shared__ Fr sm[1024];  // multiplier of the composed map of this thread's chunk-range and everything after
-    __shared__ Fr sa[1024];  // additive part
-    const uint32_t chunk = (m + 1023) / 1024;
-    // thread T owns chunk indices [lo, hi) counted from the top: process descending s
-    const uint32_t r = 1023 - threadIdx.x;  // reverse so that "earlier in scan" = higher index
-    const uint32_t lo = min(m, r * chunk), hi = min(m, lo + chunk);
-    // value entering below this thread's range given x entering from above: x -> Zpow * x + add
-    Fr zp = Fr::one(), add = Fr::zero();
-    for (uint32_t s = hi; s-- > lo;) {  // descending
-        add = fe_add(fe_mul(add, Z), fe_load(cval + s));
-        zp = fe_mul(zp, Z);
-    }
-    sm[threadIdx.x] = zp;
-    sa[threadIdx.x] = add;
+// Carries between chunks: K_t = sum_{s > t} c_s Z^(s-t-1), Z = z^KD_L.  Two-level suffix
+// scan with KNOWN multipliers (powers of Z), so a Hillis-Steele step is one product:
+//   kd_block_scan  within blocks of 256 chunks: suf[i] = sum_{s >= i, s in block} c_s Z^(s-i);
+//                  block aggregate S_B = suf[first]
+//   kd_top         G_B = S_{B+1} + Z^256 G_{B+1} (carry entering block B from above), one workgroup
+//   kd_apply       K_t = suf[t+1] (same block) + Z^(last_in_block - t) G_B
+static constexpr uint32_t KD_BLK = 256;
+
+struct KdPowers {
+    Fr step[8];   // Z^(2^j), j = 0..7
+    Fr top[12];   // (Z^256)^(2^j)
+};
+
+__global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(const Fr* __restrict__ cval, uint32_t m, KdPowers pw,
+                                                               Fr* __restrict__ suf, Fr* __restrict__ agg) {
+    __shared__ Fr sh[KD_BLK];
+    const uint32_t t = blockIdx.x * KD_BLK + threadIdx.x;
+    Fr v = t < m ? fe_load(cval + t) : Fr::zero();
+    sh[threadIdx.x] = v;
     __syncthreads();
-    // inclusive scan in thread order (thread 0 = topmost range): compose with predecessors
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        Fr pm = Fr::one(), pa = Fr::zero();
-        const bool has = threadIdx.x >= d;
-        if (has) {
-            pm = sm[threadIdx.x - d];
-            pa = sa[threadIdx.x - d];
-        }
+#pragma unroll 1
+    for (uint32_t j = 0, d = 1; d < KD_BLK; d <<= 1, j++) {
+        Fr o = Fr::zero();
+        const bool has = threadIdx.x + d < KD_BLK;
+        if (has) o = sh[threadIdx.x + d];
         __syncthreads();
         if (has) {
-            // predecessor (above) applied first: x -> m*(pm*x + pa) + a
-            const Fr m0 = sm[threadIdx.x], a0 = sa[threadIdx.x];
-            sm[threadIdx.x] = fe_mul(m0, pm);
-            sa[threadIdx.x] = fe_add(fe_mul(m0, pa), a0);
+            v = fe_add(v, fe_mul(o, pw.step[j]));
+            sh[threadIdx.x] = v;
         }
         __syncthreads();
     }
-    // value entering this thread's range from above (x = 0 at the very top)
-    Fr x = threadIdx.x ? sa[threadIdx.x - 1] : Fr::zero();
-    for (uint32_t s = hi; s-- > lo;) {
-        fe_store(carry + s, x);  // carry into chunk s = contribution of all chunks above it
-        x = fe_add(fe_mul(x, Z), fe_load(cval + s));
-    }
+    if (t < m) fe_store(suf + t, v);
+    if (threadIdx.x == 0) fe_store(agg + blockIdx.x, v);
 }
 
-__global__ void kd_apply_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, const Fr* __restrict__ carry, Fr* __restrict__ q) {
+// G[B] = sum_{B' > B} S_{B'} (Z^256)^(B'-B-1); nblk <= 1024
+__global__ __launch_bounds__(1024) void kd_top_kernel(const Fr* __restrict__ agg, uint32_t nblk, KdPowers pw, Fr* __restrict__ G) {
+    __shared__ Fr sh[1024];
+    // inclusive suffix scan of S with multiplier Z^256, then shift by one
+    Fr v = threadIdx.x < nblk ? fe_load(agg + threadIdx.x) : Fr::zero();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t j = 0, d = 1; d < 1024 && d < nblk; d <<= 1, j++) {
+        Fr o = Fr::zero();
+        const bool has = threadIdx.x + d < nblk;
+        if (has) o = sh[threadIdx.x + d];
+        __syncthreads();
+        if (has) {
+            v = fe_add(v, fe_mul(o, pw.top[j]));
+            sh[threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < nblk) fe_store(G + threadIdx.x, threadIdx.x + 1 < nblk ? sh[threadIdx.x + 1] : Fr::zero());
+}
+
+__global__ void kd_apply_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, const Fr* __restrict__ suf,
+                                const Fr* __restrict__ G, const Fr* __restrict__ zpow, uint32_t m, Fr* __restrict__ q) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = t * KD_L;
     if (base >= n) return;
     const uint32_t top = min(n, base + KD_L);
-    Fr run = fe_load(carry + t);  // = q[top - 1] contribution from above, i.e. sum_{j >= top} p[j] z^(j - top)
-    // q[i-1] = p[i] + z*q[i]; with run = q[top-1]... walk down
+    // carry into chunk t: chunks above it in the same block + everything above the block
+    const uint32_t blk = t / KD_BLK;
+    const uint32_t last = min(m, (blk + 1) * KD_BLK) - 1;
+    Fr run = (t < last) ? fe_load(suf + t + 1) : Fr::zero();
+    run = fe_add(run, fe_mul(fe_load(zpow + (last - t)), fe_load(G + blk)));
+    // run = q[top - 1]; walk down: q[i-1] = p[i] + z q[i]
     for (uint32_t i = top; i-- > base;) {
-        // run currently equals sum_{j > i} p[j] z^(j-i-1) = q[i]
         fe_store(q + i, run);
         run = fe_add(fe_mul(run, z), fe_load(p + i));
     }
 }
 
+// zpow[i] = Z^i, i < 256 (one workgroup)
+__global__ __launch_bounds__(256) void kd_zpow_kernel(Fr Z, Fr* __restrict__ zpow) {
+    Fr acc = Fr::one(), base = Z;
+    for (uint32_t e = threadIdx.x; e; e >>= 1) {
+        if (e & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    fe_store(zpow + threadIdx.x, acc);
+}
+
+// tmp: cval[m] | suf[m] | agg[nblk] | G[nblk] | zpow[256]  (m = ceil(n / 32), nblk = ceil(m / 256) <= 1024)
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st) {
     const uint32_t m = (n + KD_L - 1) / KD_L;
+    const uint32_t nblk = (m + KD_BLK - 1) / KD_BLK;
+    Fr* cval = tmp_c;
+    Fr* suf = tmp_carry;
+    Fr* agg = suf + m;
+    Fr* G = agg + nblk;
+    Fr* zpow = G + nblk;
     Fr Z = z;
     for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^32
-    hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, tmp_c);
-    hipLaunchKernelGGL(kd_carry_kernel, dim3(1), dim3(1024), 0, st, tmp_c, m, Z, tmp_carry);
-    hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, tmp_carry, q);
+    KdPowers pw;
+    Fr cur = Z;
+    for (int j = 0; j < 8; j++) {
+        pw.step[j] = cur;
+        cur = fe_sqr(cur);
+    }
+    // cur = Z^256
+    for (int j = 0; j < 12; j++) {
+        pw.top[j] = cur;
+        cur = fe_sqr(cur);
+    }
+    hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, cval);
+    hipLaunchKernelGGL(kd_zpow_kernel, dim3(1), dim3(256), 0, st, Z, zpow);
+    hipLaunchKernelGGL(kd_block_scan_kernel, dim3(nblk), dim3(KD_BLK), 0, st, cval, m, pw, suf, agg);
+    hipLaunchKernelGGL(kd_top_kernel, dim3(1), dim3(1024), 0, st, agg, nblk, pw, G);
+    hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, suf, G, zpow, m, q);
 }
 
 }  // namespace zk
