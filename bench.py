@@ -37,9 +37,9 @@ class ProofWorkload:
     shape (the real secp256r1 witness generation stays on the host and needs the
     Rust chips), uploaded before the timed region."""
 
-    name = "single-proof k=19 (bench_ecdsa.config row 1: A=1,L=1,F=1,lookup_bits=18), Blake2b+SHPLONK, synthetic same-shape witness seed 0x5eed0019+rank"
+    name = "single-proof k=19 (bench_ecdsa.config row 1: A=1,L=1,F=1,lookup_bits=18), Blake2b+SHPLONK, synthetic same-shape witnesses (job seeds 0x5eed0019+i, round-robin over ranks), one resident proving key"
 
-    def __init__(self, eng, seed):
+    def __init__(self, eng, rank, world_size):
         from webauthn_halo2_amd import circuit, engine as E
 
         self.eng = eng
@@ -47,26 +47,50 @@ class ProofWorkload:
         p = circuit.K19
         n = 1 << K
         eng.srs_setup(K)
+        from webauthn_halo2_amd import batch
+
+        # one proving key (the circuit is witness-independent), several independent witnesses:
+        # rank r of N proves jobs r, r + N, ... (BASELINE config 4), each with its own RNG stream
+        self.jobs = batch.assign(range(2 * world_size * 2), rank, world_size)[:2]
         t0 = time.time()
-        asg = circuit.synthesize(p, seed)
-        self.synth_s = time.time() - t0
-        fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+        asgs = [circuit.synthesize(p, batch.job_seed(j)) for j in self.jobs]
+        self.synth_s = (time.time() - t0) / len(asgs)
+        fixed = np.stack([asgs[0].to_limbs(c) for c in asgs[0].fixed])
         t0 = time.time()
-        self.pk = eng.keygen(p, fixed, asg.copies)
+        self.pk = eng.keygen(p, fixed, asgs[0].copies)
         self.keygen_s = time.time() - t0
         self.advice = []
-        for col in asg.advice:
-            h = eng.poly(n)
-            eng.upload_canonical(h, asg.to_limbs(col))
-            self.advice.append(h)
+        for asg in asgs:
+            cols = []
+            for col in asg.advice:
+                h = eng.poly(n)
+                eng.upload_canonical(h, asg.to_limbs(col))
+                cols.append(h)
+            self.advice.append(cols)
         self.ctr = 0
         self.proof = b""
 
     def step(self):
+        adv = self.advice[self.ctr % len(self.advice)]
         self.ctr += 1
-        seed = self.ctr.to_bytes(32, "little")
-        self.proof = self.eng.prove(self.pk, self.advice, seed, self.E.ZK_TRANSCRIPT_BLAKE2B)
+        seed = (self.jobs[0] * 1000003 + self.ctr).to_bytes(32, "little")
+        self.proof = self.eng.prove(self.pk, adv, seed, self.E.ZK_TRANSCRIPT_BLAKE2B)
         self.eng.sync()
+
+
+class FakeWorkload:
+    """CPU stand-in used only by the world_size-2 gloo test of the N>1 launch / timing logic
+    (tests/test_multiproc.py): no engine, no GPU; a step is a fixed sleep."""
+
+    name = "fake (distributed-logic test only)"
+    synth_s = keygen_s = 0.0
+    proof = b"\0" * 960
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def step(self):
+        time.sleep(0.01 * (1 + self.rank))
 
 
 def cpu_baseline(eng):
@@ -112,6 +136,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    fake = os.environ.get("ZKMI355_BENCH_FAKE") == "1"  # CPU test of the launch/timing logic only
     dist = None
     torch = None
     if world > 1:
@@ -119,24 +144,35 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if fake:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    import webauthn_halo2_amd as zk
+    if fake:
+        eng = None
+        wl = FakeWorkload(rank)
+    else:
+        import webauthn_halo2_amd as zk
 
-    eng = zk.Engine(local_rank)
-    wl = ProofWorkload(eng, 0x5EED0019 + rank)
+        eng = zk.Engine(local_rank)  # one independent proof stream per GPU: replicas, no data-path collective
+        wl = ProofWorkload(eng, rank, world)
 
     def barrier():
-        eng.sync()
+        if eng is not None:
+            eng.sync()
         if dist is not None:
-            torch.cuda.synchronize()
+            if not fake:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if not fake:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         wl.step()
-    eng.timer_reset()
+    if eng is not None:
+        eng.timer_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -144,11 +180,15 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if fake else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and fake:
+        print(json.dumps({"metric": "webauthn_es256_proofs_per_sec_k19", "value": world * args.steps / elapsed,
+                          "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "data": "fake"}))
+    elif rank == 0:
         n = 1 << K
         acc_total, acc_n = eng.timer_stats(4)  # ZK_T_MSM_ACCUM
         msm_total, msm_n = eng.timer_stats(0)
@@ -182,7 +222,7 @@ def main():
                 "traffic": None,
                 "avg_launch_ms": accum_ms,
                 "launches": int(acc_n),
-                "note": "integer-ALU-bound kernel (no MFMA, SURVEY.md 8d); whole-MSM avg %.3f ms x %d per proof; quotient kernel %.3f ms"
+                "note": "integer-ALU-bound kernel (no MFMA, SURVEY.md 8d); MSM head (recode..accumulate) avg %.3f ms x %d per proof, tails overlapped on side streams; quotient kernel %.3f ms"
                 % (msm_total / max(msm_n, 1), msm_n // max(args.steps, 1), eng.last_ms(2)),
             },
         }
@@ -192,7 +232,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
 
 
 if __name__ == "__main__":

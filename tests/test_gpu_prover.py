@@ -119,3 +119,25 @@ def test_baseline_shapes_verify(engine, cfg):
     for h in polys:
         h.free()
     engine.pk_free(pk)
+
+
+def test_one_key_many_witnesses(engine):
+    """The proving key is witness-independent (as the reference's pk is shared by every request,
+    proving-server/src/main.rs:49-63): three jobs, one zk_keygen, all proofs byte-equal to the oracle."""
+    A, L, F, k, lb = SHAPES["k19like"]
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    sh = plonk.Shape(k, A, L, F, lb)
+    engine.srs_setup(k)
+    asgs = [zk.circuit.synthesize(p, zk.batch.job_seed(i)) for i in range(3)]
+    assert all(a.fixed == asgs[0].fixed and a.copies == asgs[0].copies for a in asgs)
+    fixed = np.stack([asgs[0].to_limbs(c) for c in asgs[0].fixed])
+    pk = engine.keygen(p, fixed, asgs[0].copies)
+    opk = prover.keygen(prover.Circuit(sh, asgs[0].fixed, asgs[0].copies, asgs[0].advice))
+    for i, asg in enumerate(asgs):
+        h = engine.poly(1 << k)
+        engine.upload_canonical(h, asg.to_limbs(asg.advice[0]))
+        seed = i.to_bytes(32, "little")
+        got = engine.prove(pk, [h], seed, E.ZK_TRANSCRIPT_EVM)
+        assert got == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), "evm")
+        h.free()
+    engine.pk_free(pk)

@@ -1,5 +1,5 @@
 """Public surface of the package (re-exported by `webauthn_halo2_amd`)."""
 from .engine import Engine, ZkError, lib_path, load_library  # noqa: F401
-from . import circuit  # noqa: F401
+from . import batch, circuit  # noqa: F401
 
-__all__ = ["Engine", "ZkError", "lib_path", "load_library", "circuit"]
+__all__ = ["Engine", "ZkError", "lib_path", "load_library", "circuit", "batch"]

@@ -88,11 +88,20 @@ class Assignment:
         return np.frombuffer(b, dtype=np.uint64).reshape(-1, 4).copy()
 
 
-def synthesize(p: CircuitParams, seed: int, worst_case: bool = False) -> Assignment:
-    """Satisfying assignment of the config's shape.  seed as SURVEY.md §8d
-    (0x5eed0019 + job index).  worst_case: every value uniform in Fr."""
+STRUCT_SEED = 0xC1BC0019  # fixes the circuit (selectors, lookup flags, copy constraints); witnesses vary per job
+
+
+def synthesize(p: CircuitParams, seed: int, worst_case: bool = False, struct_seed: int = STRUCT_SEED) -> Assignment:
+    """Satisfying assignment of the config's shape.
+
+    The circuit structure — which cells are range-checked, which are copies of earlier gate
+    outputs or of constants — is drawn from `struct_seed` only, so every job shares one proving
+    key, as every request shares the reference's pk (proving-server/src/main.rs:49-63).  The
+    witness VALUES are drawn from `seed` (0x5eed0019 + job index).
+    worst_case: every free value uniform in Fr (range-checked cells stay in range)."""
     lay = Layout(p)
-    rng = random.Random(seed)
+    srng = random.Random(struct_seed)   # structure
+    rng = random.Random(seed)           # values
     n, usable, lb = lay.n, lay.usable_rows, p.lookup_bits
     T = 1 << lb
     assert T < usable, "range table must fit in the usable rows"
@@ -109,57 +118,68 @@ def synthesize(p: CircuitParams, seed: int, worst_case: bool = False) -> Assignm
     for r in range(T):
         fixed[lay.fx_table][r] = r
 
-    def pick():
-        if worst_case:
-            return rng.randrange(R), "full"
-        u = rng.random()
+    def pick_class():
+        u = srng.random()
         if u < 0.40:
-            return rng.randrange(T), "small"
+            return "small"
         if u < 0.75:
-            return rng.randrange(1 << p.limb_bits), "limb"
+            return "limb"
         if u < 0.90:
-            return rng.randrange(R), "full"
-        return 0, "zero"
+            return "full"
+        return "zero"
+
+    def value(cls):
+        if cls == "small":
+            return rng.randrange(T)
+        if worst_case:
+            return rng.randrange(R)
+        if cls == "limb":
+            return rng.randrange(1 << p.limb_bits)
+        if cls == "full":
+            return rng.randrange(R)
+        return 0
 
     gates_per_col = usable // 4
-    small_cells = []  # (gate advice col, row, value) with value < T
-    d_cells = []      # (col, row, value) outputs available for copying
-    lookup_rows = []
+    small_cells = []  # (gate advice col, row) range-checked cells
+    d_cells = []      # (col, row) gate outputs available for copying (structure) ...
+    d_vals = {}       # ... and their values (witness)
     for j in range(lay.n_gate):
         col = advice[j]
         sel = fixed[lay.fx_sel[j]]
         for g in range(gates_per_col):
             r0 = 4 * g
-            a, ca = pick()
-            b, cb = pick()
-            c, cc = pick()
-            u = rng.random()
+            ca, cb, cc = pick_class(), pick_class(), pick_class()
+            a, b, c = value(ca), value(cb), value(cc)
+            u = srng.random()
             if d_cells and u < 0.5:
                 # a := an earlier gate output (copy constraint)
-                sc, sr, sv = d_cells[rng.randrange(len(d_cells))]
-                a, ca = sv, "copy"
+                sc, sr = d_cells[srng.randrange(len(d_cells))]
+                a, ca = d_vals[(sc, sr)], "copy"
                 copies.append(((lay.perm_index("advice", j), r0), (lay.perm_index("advice", sc), sr)))
             elif u < 0.6:
                 # b := a constant from the constants column
-                f = rng.randrange(F)
-                cr = rng.randrange(n_const)
+                f = srng.randrange(F)
+                cr = srng.randrange(n_const)
                 b, cb = fixed[f][cr], "const"
                 copies.append(((lay.perm_index("fixed", f), cr), (lay.perm_index("advice", j), r0 + 1)))
             d = (a + b * c) % R
             col[r0], col[r0 + 1], col[r0 + 2], col[r0 + 3] = a, b, c, d
             sel[r0] = 1
             if ca == "small":
-                small_cells.append((j, r0, a))
+                small_cells.append((j, r0))
             if cc == "small":
-                small_cells.append((j, r0 + 2, c))
+                small_cells.append((j, r0 + 2))
             if len(d_cells) < 4096:
-                d_cells.append((j, r0 + 3, d))
+                d_cells.append((j, r0 + 3))
             else:
-                d_cells[rng.randrange(4096)] = (j, r0 + 3, d)
+                old = srng.randrange(4096)
+                d_vals.pop(d_cells[old], None)
+                d_cells[old] = (j, r0 + 3)
+            d_vals[(j, r0 + 3)] = d
     if lay.single:
         # the gate column itself is looked up under q_lookup
         ql = fixed[lay.fx_qlookup]
-        for (_, row, _) in small_cells:
+        for (_, row) in small_cells:
             ql[row] = 1
     else:
         # dedicated lookup columns: cell t holds a copy of a range-checked gate cell
@@ -167,8 +187,7 @@ def synthesize(p: CircuitParams, seed: int, worst_case: bool = False) -> Assignm
         for l in range(lay.n_lookup_cols):
             cells = small_cells[l * per:(l + 1) * per][:usable]
             lc = advice[lay.n_gate + l]
-            for t, (j, row, v) in enumerate(cells):
-                lc[t] = v
+            for t, (j, row) in enumerate(cells):
+                lc[t] = advice[j][row]
                 copies.append(((lay.perm_index("advice", lay.n_gate + l), t), (lay.perm_index("advice", j), row)))
-    del lookup_rows
     return Assignment(lay, fixed, copies, advice)
