@@ -139,10 +139,11 @@ __host__ __device__ __forceinline__ Fe<PRM> fe_neg(const Fe<PRM>& a) {
 template <class PRM>
 __host__ __device__ __forceinline__ Fe<PRM> fe_dbl(const Fe<PRM>& a) { return fe_add(a, a); }
 
-// CIOS Montgomery product, 8 x 32-bit limbs.  p < 2^254 so the running value
-// stays below 2p * 2^32 and the 10th limb of the textbook algorithm is always 0.
+// CIOS Montgomery product, 8 x 32-bit limbs (portable form: host code, and the reference
+// against which the device form below is tested).  p < 2^254 so the running value stays
+// below 2p * 2^32 and the 10th limb of the textbook algorithm is always 0.
 template <class PRM>
-__host__ __device__ __forceinline__ Fe<PRM> fe_mul(const Fe<PRM>& a, const Fe<PRM>& b) {
+__host__ __device__ __forceinline__ Fe<PRM> fe_mul_portable(const Fe<PRM>& a, const Fe<PRM>& b) {
     uint32_t t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = 0;
@@ -175,6 +176,129 @@ __host__ __device__ __forceinline__ Fe<PRM> fe_mul(const Fe<PRM>& a, const Fe<PR
     for (int i = 0; i < 8; i++) r.v[i] = t[i];
     reduce_once(r);
     return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 form: product-scanning (FIPS) Montgomery.  Column k of a*b + m*p is summed in a
+// 96-bit accumulator (lo: 64-bit VGPR pair, hi: carry count).  One product = v_mad_u64_u32
+// (32x32 + 64 -> 64, carry-out in VCC) + v_addc_co_u32 — hipcc never uses the mad's carry-out
+// by itself (it emits mad + 64-bit add + compare + select, ~4.5 instructions per product, half of
+// them register moves), hence the two-instruction asm.  The first product of a column cannot
+// overflow (the shifted-in accumulator is < 2^37) and needs no carry instruction.
+// 128 mads + 112 carries + 8 mul_lo per product instead of ~580 instructions.
+// zk_macN: N products accumulated in ONE asm statement (hipcc pads every asm boundary with an
+// s_nop, so the products of a column are chained in groups of up to four).
+#define ZK_MAC_BODY1 "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+__device__ __forceinline__ void zk_mac1(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t y0) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x0), "v"(y0) : "vcc");
+}
+__device__ __forceinline__ void zk_mac2(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+}
+__device__ __forceinline__ void zk_mac4(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                                        uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3) : "vcc");
+}
+// same with the second factor a uniform constant (modulus limb) in an SGPR
+__device__ __forceinline__ void zk_mac1k(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t k0) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x0), "s"(k0) : "vcc");
+}
+__device__ __forceinline__ void zk_mac2k(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t k0, uint32_t x1, uint32_t k1) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x0), "s"(k0), "v"(x1), "s"(k1) : "vcc");
+}
+__device__ __forceinline__ void zk_mac4k(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t k0, uint32_t x1, uint32_t k1,
+                                         uint32_t x2, uint32_t k2, uint32_t x3, uint32_t k3) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi) : "v"(x0), "s"(k0), "v"(x1), "s"(k1), "v"(x2), "s"(k2), "v"(x3), "s"(k3) : "vcc");
+}
+// first product of a column: the shifted-in accumulator is < 2^37, no carry possible
+__device__ __forceinline__ void zk_mac_nc(uint64_t& lo, uint32_t x, uint32_t y) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(lo) : "v"(x), "v"(y) : "vcc");
+}
+
+// sum_{i = I0}^{I1-1} a[i] * b[K - i]
+template <int I0, int I1, int K, class PRM>
+__device__ __forceinline__ void zk_col_ab(uint64_t& lo, uint32_t& hi, const Fe<PRM>& a, const Fe<PRM>& b) {
+    if constexpr (I1 - I0 >= 4) {
+        zk_mac4(lo, hi, a.v[I0], b.v[K - I0], a.v[I0 + 1], b.v[K - I0 - 1], a.v[I0 + 2], b.v[K - I0 - 2], a.v[I0 + 3], b.v[K - I0 - 3]);
+        zk_col_ab<I0 + 4, I1, K>(lo, hi, a, b);
+    } else if constexpr (I1 - I0 >= 2) {
+        zk_mac2(lo, hi, a.v[I0], b.v[K - I0], a.v[I0 + 1], b.v[K - I0 - 1]);
+        zk_col_ab<I0 + 2, I1, K>(lo, hi, a, b);
+    } else if constexpr (I1 - I0 == 1) {
+        zk_mac1(lo, hi, a.v[I0], b.v[K - I0]);
+    }
+}
+// sum_{i = I0}^{I1-1} m[i] * P[K - i]
+template <int I0, int I1, int K, class PRM>
+__device__ __forceinline__ void zk_col_mp(uint64_t& lo, uint32_t& hi, const uint32_t (&m)[8]) {
+    if constexpr (I1 - I0 >= 4) {
+        zk_mac4k(lo, hi, m[I0], PRM::P[K - I0], m[I0 + 1], PRM::P[K - I0 - 1], m[I0 + 2], PRM::P[K - I0 - 2], m[I0 + 3], PRM::P[K - I0 - 3]);
+        zk_col_mp<I0 + 4, I1, K, PRM>(lo, hi, m);
+    } else if constexpr (I1 - I0 >= 2) {
+        zk_mac2k(lo, hi, m[I0], PRM::P[K - I0], m[I0 + 1], PRM::P[K - I0 - 1]);
+        zk_col_mp<I0 + 2, I1, K, PRM>(lo, hi, m);
+    } else if constexpr (I1 - I0 == 1) {
+        zk_mac1k(lo, hi, m[I0], PRM::P[K - I0]);
+    }
+}
+
+template <int K, class PRM>
+__device__ __forceinline__ void zk_fips_low(uint64_t& lo, uint32_t& hi, uint32_t (&m)[8], const Fe<PRM>& a, const Fe<PRM>& b) {
+    zk_mac_nc(lo, a.v[0], b.v[K]);
+    zk_col_ab<1, K + 1, K>(lo, hi, a, b);
+    zk_col_mp<0, K, K, PRM>(lo, hi, m);
+    m[K] = (uint32_t)lo * PRM::INV;
+    zk_mac1k(lo, hi, m[K], PRM::P[0]);
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+}
+template <int K, class PRM>
+__device__ __forceinline__ void zk_fips_high(uint64_t& lo, uint32_t& hi, const uint32_t (&m)[8], Fe<PRM>& r, const Fe<PRM>& a,
+                                             const Fe<PRM>& b) {
+    zk_mac_nc(lo, a.v[K - 7], b.v[7]);
+    zk_col_ab<K - 6, 8, K>(lo, hi, a, b);
+    zk_col_mp<K - 7, 8, K, PRM>(lo, hi, m);
+    r.v[K - 8] = (uint32_t)lo;
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+}
+
+template <class PRM>
+__device__ __forceinline__ Fe<PRM> fe_mul_gfx950(const Fe<PRM>& a, const Fe<PRM>& b) {
+    uint32_t m[8];
+    Fe<PRM> r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    zk_fips_low<0>(lo, hi, m, a, b);
+    zk_fips_low<1>(lo, hi, m, a, b);
+    zk_fips_low<2>(lo, hi, m, a, b);
+    zk_fips_low<3>(lo, hi, m, a, b);
+    zk_fips_low<4>(lo, hi, m, a, b);
+    zk_fips_low<5>(lo, hi, m, a, b);
+    zk_fips_low<6>(lo, hi, m, a, b);
+    zk_fips_low<7>(lo, hi, m, a, b);
+    zk_fips_high<8>(lo, hi, m, r, a, b);
+    zk_fips_high<9>(lo, hi, m, r, a, b);
+    zk_fips_high<10>(lo, hi, m, r, a, b);
+    zk_fips_high<11>(lo, hi, m, r, a, b);
+    zk_fips_high<12>(lo, hi, m, r, a, b);
+    zk_fips_high<13>(lo, hi, m, r, a, b);
+    zk_fips_high<14>(lo, hi, m, r, a, b);
+    r.v[7] = (uint32_t)lo;  // column 15 is empty; the total is < 2p < 2^255
+    reduce_once(r);
+    return r;
+}
+#endif
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_mul(const Fe<PRM>& a, const Fe<PRM>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_gfx950(a, b);
+#else
+    return fe_mul_portable(a, b);
+#endif
 }
 
 template <class PRM>
