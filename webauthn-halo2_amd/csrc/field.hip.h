@@ -86,8 +86,9 @@ __host__ __device__ __forceinline__ void reduce_once(Fe<PRM>& a) {
     }
 }
 
+// Portable add / sub (host, and reference for the device forms).
 template <class PRM>
-__host__ __device__ __forceinline__ Fe<PRM> fe_add(const Fe<PRM>& a, const Fe<PRM>& b) {
+__host__ __device__ __forceinline__ Fe<PRM> fe_add_portable(const Fe<PRM>& a, const Fe<PRM>& b) {
     Fe<PRM> r;
     uint64_t c = 0;
 #pragma unroll
@@ -101,7 +102,7 @@ __host__ __device__ __forceinline__ Fe<PRM> fe_add(const Fe<PRM>& a, const Fe<PR
 }
 
 template <class PRM>
-__host__ __device__ __forceinline__ Fe<PRM> fe_sub(const Fe<PRM>& a, const Fe<PRM>& b) {
+__host__ __device__ __forceinline__ Fe<PRM> fe_sub_portable(const Fe<PRM>& a, const Fe<PRM>& b) {
     Fe<PRM> r;
     int64_t c = 0;
 #pragma unroll
@@ -120,6 +121,54 @@ __host__ __device__ __forceinline__ Fe<PRM> fe_sub(const Fe<PRM>& a, const Fe<PR
         }
     }
     return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 forms: straight carry chains (hipcc turns the portable 64-bit-accumulator code into
+// ~90 instructions per addition, half of them moves).  add: r = a + b - p, then + (p & mask) if
+// that borrowed; sub: r = a - b, then + (p & mask) if that borrowed.  r holds a on entry and the
+// result on exit.  The modulus limbs are VGPR operands: a literal or SGPR together with the
+// VCC carry-in would need two constant-bus reads, which a gfx9-family VOP2 does not have.
+template <class PRM>
+__device__ __forceinline__ void zk_add_asm(uint32_t (&r)[8], const uint32_t (&b)[8]) {
+    uint32_t m, t;
+    asm("v_add_co_u32 %0, vcc, %0, %10\n\tv_addc_co_u32 %1, vcc, %1, %11, vcc\n\tv_addc_co_u32 %2, vcc, %2, %12, vcc\n\tv_addc_co_u32 %3, vcc, %3, %13, vcc\n\tv_addc_co_u32 %4, vcc, %4, %14, vcc\n\tv_addc_co_u32 %5, vcc, %5, %15, vcc\n\tv_addc_co_u32 %6, vcc, %6, %16, vcc\n\tv_addc_co_u32 %7, vcc, %7, %17, vcc\n\tv_sub_co_u32 %0, vcc, %0, %18\n\tv_subb_co_u32 %1, vcc, %1, %19, vcc\n\tv_subb_co_u32 %2, vcc, %2, %20, vcc\n\tv_subb_co_u32 %3, vcc, %3, %21, vcc\n\tv_subb_co_u32 %4, vcc, %4, %22, vcc\n\tv_subb_co_u32 %5, vcc, %5, %23, vcc\n\tv_subb_co_u32 %6, vcc, %6, %24, vcc\n\tv_subb_co_u32 %7, vcc, %7, %25, vcc\n\tv_cndmask_b32_e64 %8, 0, -1, vcc\n\tv_and_b32 %9, %18, %8\n\tv_add_co_u32 %0, vcc, %0, %9\n\tv_and_b32 %9, %19, %8\n\tv_addc_co_u32 %1, vcc, %1, %9, vcc\n\tv_and_b32 %9, %20, %8\n\tv_addc_co_u32 %2, vcc, %2, %9, vcc\n\tv_and_b32 %9, %21, %8\n\tv_addc_co_u32 %3, vcc, %3, %9, vcc\n\tv_and_b32 %9, %22, %8\n\tv_addc_co_u32 %4, vcc, %4, %9, vcc\n\tv_and_b32 %9, %23, %8\n\tv_addc_co_u32 %5, vcc, %5, %9, vcc\n\tv_and_b32 %9, %24, %8\n\tv_addc_co_u32 %6, vcc, %6, %9, vcc\n\tv_and_b32 %9, %25, %8\n\tv_addc_co_u32 %7, vcc, %7, %9, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "=&v"(m), "=&v"(t)
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(PRM::P[0]), "v"(PRM::P[1]),
+          "v"(PRM::P[2]), "v"(PRM::P[3]), "v"(PRM::P[4]), "v"(PRM::P[5]), "v"(PRM::P[6]), "v"(PRM::P[7])
+        : "vcc");
+}
+template <class PRM>
+__device__ __forceinline__ void zk_sub_asm(uint32_t (&r)[8], const uint32_t (&b)[8]) {
+    uint32_t m, t;
+    asm("v_sub_co_u32 %0, vcc, %0, %10\n\tv_subb_co_u32 %1, vcc, %1, %11, vcc\n\tv_subb_co_u32 %2, vcc, %2, %12, vcc\n\tv_subb_co_u32 %3, vcc, %3, %13, vcc\n\tv_subb_co_u32 %4, vcc, %4, %14, vcc\n\tv_subb_co_u32 %5, vcc, %5, %15, vcc\n\tv_subb_co_u32 %6, vcc, %6, %16, vcc\n\tv_subb_co_u32 %7, vcc, %7, %17, vcc\n\tv_cndmask_b32_e64 %8, 0, -1, vcc\n\tv_and_b32 %9, %18, %8\n\tv_add_co_u32 %0, vcc, %0, %9\n\tv_and_b32 %9, %19, %8\n\tv_addc_co_u32 %1, vcc, %1, %9, vcc\n\tv_and_b32 %9, %20, %8\n\tv_addc_co_u32 %2, vcc, %2, %9, vcc\n\tv_and_b32 %9, %21, %8\n\tv_addc_co_u32 %3, vcc, %3, %9, vcc\n\tv_and_b32 %9, %22, %8\n\tv_addc_co_u32 %4, vcc, %4, %9, vcc\n\tv_and_b32 %9, %23, %8\n\tv_addc_co_u32 %5, vcc, %5, %9, vcc\n\tv_and_b32 %9, %24, %8\n\tv_addc_co_u32 %6, vcc, %6, %9, vcc\n\tv_and_b32 %9, %25, %8\n\tv_addc_co_u32 %7, vcc, %7, %9, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "=&v"(m), "=&v"(t)
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(PRM::P[0]), "v"(PRM::P[1]),
+          "v"(PRM::P[2]), "v"(PRM::P[3]), "v"(PRM::P[4]), "v"(PRM::P[5]), "v"(PRM::P[6]), "v"(PRM::P[7])
+        : "vcc");
+}
+#endif
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_add(const Fe<PRM>& a, const Fe<PRM>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fe<PRM> r = a;
+    zk_add_asm<PRM>(r.v, b.v);
+    return r;
+#else
+    return fe_add_portable(a, b);
+#endif
+}
+
+template <class PRM>
+__host__ __device__ __forceinline__ Fe<PRM> fe_sub(const Fe<PRM>& a, const Fe<PRM>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fe<PRM> r = a;
+    zk_sub_asm<PRM>(r.v, b.v);
+    return r;
+#else
+    return fe_sub_portable(a, b);
+#endif
 }
 
 template <class PRM>
