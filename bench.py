@@ -93,6 +93,24 @@ class FakeWorkload:
         time.sleep(0.01 * (1 + self.rank))
 
 
+def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (separate FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/*_pmc_hbm.csv; KiB as
+    rocprofv3 reports them — on gfx950 FETCH_SIZE under-counts wide coalesced reads 2x, so this is a
+    lower bound for streaming reads; the accumulate kernel's reads are 64-byte gathers)."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    if not files:
+        return None
+    tot = 0.0
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"] == kernel and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            tot += float(row["avg_value_per_launch"]) * 1024.0
+    return tot or None
+
+
 def cpu_baseline(eng):
     """Oracle C restatement (halo2 best_multiexp / best_fft) on the host cores:
     one MSM(2^19) + one NTT(2^19) + one NTT(2^21), scaled to the per-proof operator counts."""
@@ -219,7 +237,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(),
                 "avg_launch_ms": accum_ms,
                 "launches": int(acc_n),
                 "note": "integer-ALU-bound kernel (no MFMA, SURVEY.md 8d); MSM head (recode..accumulate) avg %.3f ms x %d per proof, tails overlapped on side streams; quotient kernel %.3f ms"
