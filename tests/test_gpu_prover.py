@@ -3,6 +3,8 @@ produces, from the same witness and the same ChaCha20 stream, byte-identical pro
 the oracle's restated create_proof, for every BASELINE column shape (scaled to small
 k), both transcripts; at k=17 / k=19 the proofs are checked by the oracle verifier that
 the reference's golden proof pins."""
+import os
+
 import numpy as np
 import pytest
 
@@ -141,3 +143,32 @@ def test_one_key_many_witnesses(engine):
         assert got == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), "evm")
         h.free()
     engine.pk_free(pk)
+
+
+def test_reference_api_mirror(engine, tmp_path):
+    """download_keys / generate_proof / generate_proof_evm (reference ecdsa_p256.rs:256-427) at the
+    server's default degree 17 (proving-server/src/main.rs:17): sizes as published, accepted by the
+    pinned verifier, same request -> same witness, error behaviour on bad input."""
+    from webauthn_halo2_amd import ecdsa_p256 as api
+
+    api._STATE.clear()
+    pkp, vkp = str(tmp_path / "proving_key.pk"), str(tmp_path / "verifying_key.vk")
+    api.download_keys(17, pkp, vkp)
+    eng = api._STATE[0]["eng"]
+    req = [bytes([i]) * 32 for i in range(5)]
+    with pytest.raises(FileNotFoundError):
+        api.generate_proof(*req, str(tmp_path / "missing.pk"), 17)
+    with pytest.raises(ValueError):
+        api.generate_proof(b"short", *req[1:], pkp, 17)
+    pf = api.generate_proof(*req, pkp, 17, rng_seed=bytes(32))
+    pe = api.generate_proof_evm(*req, pkp, 17, rng_seed=bytes(32))
+    assert (len(pf), len(pe)) == (1920, 2720)
+    assert pe == api.generate_proof_evm(*req, pkp, 17, rng_seed=bytes(32))
+    assert pe != api.generate_proof_evm(*req, pkp, 17)  # OsRng-style fresh randomness
+    sh = plonk.Shape(17, 4, 1, 1, 16)
+    p, pk = api._STATE[0]["keys"][pkp]
+    vk = product_vk(eng, pk, sh)
+    assert plonk.verify(vk, pf, "blake2b") and plonk.verify(vk, pe, "evm")
+    assert os.path.getsize(vkp) == 12 + (6 + 6) * 64 + 32
+    eng.close()
+    api._STATE.clear()
