@@ -21,10 +21,10 @@
 //   3. msm_scan          exclusive scan of bucket totals -> bucket starts
 //   4. msm_sort<SCATTER> same workgroups: LDS cursors = bucket start + reserved base,
 //                        counting-sort scatter of (bucket, +-base index) entries
-//   5. msm_accumulate    fixed-length segments (32 entries) of the sorted list, one lane
-//                        each, XYZZ mixed adds (8M + 2S); a bucket lying strictly inside
-//                        a segment is final, the first/last run of a segment is a "slot"
-//   6. msm_gather        one workgroup per (bucket, part): sums that bucket's slots
+//   5. msm_accumulate    bucket ranges are padded to multiples of 32 entries; every lane sums one
+//                        aligned 32-entry segment with XYZZ mixed adds (8M + 2S) -> one partial
+//                        sum ("slot") per lane, all lanes of a launch do the same amount of work
+//   6. msm_gather        16-lane groups sum each bucket's slots (shuffle tree), on the tail stream
 //   7. msm_bitsum        sum_j j B_j = sum_t 2^t G_t, G_t = sum of buckets with bit t of j set:
 //                        c tree reductions per bucket set; the short Horner is done on the host
 // Load balance does not depend on the scalar distribution: witness columns are
@@ -38,6 +38,7 @@
 namespace zk {
 
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
+static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
 static constexpr uint32_t SEG0 = 32;      // entries per accumulate lane
 
@@ -51,8 +52,7 @@ struct MsmWorkspace {
     uint32_t* blockbase;        // [nblk][nb]
     uint32_t* counts;           // [4]
     uint2* entries;             // [max_n * nwin]
-    uint32_t* slot_bucket;      // [2 * threads]
-    G1X* slot_pt;
+    G1X* slot_pt;               // [entries / SEG0]
     G1X* part;                  // [nbt * parts]
     G1X* bit_sum;               // [nwin * c]
 };
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void msm_sort_kernel(const int32_t* __restrict
     }
 }
 
-// exclusive scan of in[0..m) into out[0..m], out[m] = total = counts[0]
+// exclusive scan of the bucket sizes, each rounded up to a multiple of SEG0 (so that an
+// accumulate lane never straddles two buckets): out[0..m], out[m] = padded total = counts[0]
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                         uint32_t m, uint32_t* __restrict__ counts) {
     __shared__ uint32_t part[1024];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     const uint32_t lo = min(m, threadIdx.x * chunk);
     const uint32_t hi = min(m, lo + chunk);
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += in[i];
+    for (uint32_t i = lo; i < hi; i++) sum += (in[i] + SEG0 - 1) & ~(SEG0 - 1);
     part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t run = part[threadIdx.x] - sum;
     for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t h = in[i];
+        const uint32_t h = (in[i] + SEG0 - 1) & ~(SEG0 - 1);
         out[i] = run;
         run += h;
     }
@@ -175,50 +176,37 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
 }
 
+// fill the padding at the end of every bucket with skip markers
+__global__ void msm_pad_kernel(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ bucket_start, uint32_t m,
+                               uint2* __restrict__ entries) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= m) return;
+    const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
+    for (uint32_t p = beg; p < end; p++) entries[p] = make_uint2(b, SKIP_ENTRY);
+}
+
 // ------------------------------------------------------------ accumulate ---
 
-// Emits exactly two slots per active lane: (first bucket, first-run sum) and (last
-// bucket, last-run sum, or identity when the segment is a single run).  Runs strictly
-// inside the segment are complete buckets: they go to part[bucket * parts].
+// Every lane sums one aligned segment of SEG0 entries; bucket ranges are padded to multiples
+// of SEG0, so a segment lies inside ONE bucket and yields one partial sum ("slot").
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint2* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
-                                                            const uint32_t* __restrict__ counts, uint32_t parts,
-                                                            G1X* __restrict__ part, uint32_t* __restrict__ slot_bucket,
+                                                            const uint32_t* __restrict__ counts,
                                                             G1X* __restrict__ slot_pt) {
-    const uint32_t total = counts[0];
+    const uint32_t total = counts[0];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nthreads = (total + SEG0 - 1) / SEG0;
-    if (t >= nthreads) return;
-    const uint32_t beg = t * SEG0;
-    const uint32_t end = min(total, beg + SEG0);
-    uint32_t cur = entries[beg].x;
+    if (t * SEG0 >= total) return;
+    const uint2* e = entries + (size_t)t * SEG0;
     G1X acc = G1X::identity();
-    bool first_open = true;
-    for (uint32_t pos = beg; pos < end; pos++) {
-        const uint2 e = entries[pos];
-        if (e.x != cur) {
-            if (first_open) {
-                slot_bucket[2 * t] = cur;
-                g1x_store(slot_pt + 2 * t, acc);
-                first_open = false;
-            } else {
-                g1x_store(part + (size_t)cur * parts, acc);
-            }
-            acc = G1X::identity();
-            cur = e.x;
-        }
-        G1Affine p = affine_load(bases + (e.y & ~SIGN_BIT));
+    for (uint32_t k = 0; k < SEG0; k++) {
+        const uint32_t y = e[k].y;
+        if (y == SKIP_ENTRY) continue;  // padding at the end of a bucket
+        G1Affine p = affine_load(bases + (y & ~SIGN_BIT));
         if (affine_is_identity(p)) continue;
-        if (e.y & SIGN_BIT) p.y = fe_neg(p.y);
+        if (y & SIGN_BIT) p.y = fe_neg(p.y);
         g1x_add_affine(acc, p.x, p.y);
     }
-    if (first_open) {  // one run covers the whole segment
-        slot_bucket[2 * t] = cur;
-        g1x_store(slot_pt + 2 * t, acc);
-        acc = G1X::identity();
-    }
-    slot_bucket[2 * t + 1] = cur;
-    g1x_store(slot_pt + 2 * t + 1, acc);
+    g1x_store(slot_pt + t, acc);
 }
 
 __global__ void msm_clear_kernel(G1X* __restrict__ p, uint32_t m) {
@@ -296,52 +284,37 @@ __device__ __forceinline__ void group_sum(G1X& acc, int width) {
     }
 }
 
-// One 16-lane group per (bucket b, part p): sums the slots of bucket b that fall in the
-// p-th share of the bucket's slot range (lanes stride over the share, then a 4-step
-// shuffle tree).  A bucket uses ceil(slots / 128) parts (at most `parts`); the others stay
-// identity.  Buckets that were a strictly-inner run of a single accumulate lane are
-// already final in part[b * parts] and are skipped.
-static constexpr uint32_t GATHER_LANES = 16;
+// One LANES-lane group per (bucket b, part p): sums the p-th share of the bucket's slots
+// (slots [start_b / SEG0, start_{b+1} / SEG0) — contiguous, all of bucket b), lanes stride over
+// the share, then a shuffle tree.  A bucket uses ceil(slots / (4 * LANES)) parts (at most
+// `parts`); the others stay identity.
+template <uint32_t LANES>
 __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restrict__ bucket_start,
-                                                         const uint32_t* __restrict__ counts,
-                                                         const uint32_t* __restrict__ slot_bucket,
                                                          const G1X* __restrict__ slot_pt, uint32_t parts, uint32_t ngroups,
                                                          G1X* __restrict__ part) {
-    const uint32_t gid = (blockIdx.x * 256 + threadIdx.x) / GATHER_LANES;
-    const uint32_t lane = threadIdx.x & (GATHER_LANES - 1);
+    const uint32_t gid = (blockIdx.x * 256 + threadIdx.x) / LANES;
+    const uint32_t lane = threadIdx.x & (LANES - 1);
     G1X acc = G1X::identity();
     bool active = false;
     uint32_t b = 0, p = 0;
     if (gid < ngroups) {
         b = gid / parts;
         p = gid - b * parts;
-        const uint32_t total = counts[0];
-        const uint32_t lo = bucket_start[b], hi = bucket_start[b + 1];
-        if (lo != hi) {
-            const uint32_t t_first = lo / SEG0, t_last = (hi - 1) / SEG0;
-            bool inner = false;
-            if (t_first == t_last) {
-                const uint32_t seg_beg = t_first * SEG0, seg_end = min(total, seg_beg + SEG0);
-                inner = lo != seg_beg && hi != seg_end;  // strictly inner run: already written
-            }
-            const uint32_t s0 = 2 * t_first, s1 = 2 * t_last + 2;
-            const uint32_t len = s1 - s0;
-            const uint32_t used = min(parts, (len + 127) / 128);
-            if (!inner && p < used) {
-                active = true;
-                const uint32_t share = (len + used - 1) / used;
-                const uint32_t a0 = s0 + p * share, a1 = min(s1, a0 + share);
+        const uint32_t s0 = bucket_start[b] / SEG0, s1 = bucket_start[b + 1] / SEG0;
+        const uint32_t len = s1 - s0;
+        const uint32_t used = min(parts, (len + 4 * LANES - 1) / (4 * LANES));
+        if (p < used) {
+            active = true;
+            const uint32_t share = (len + used - 1) / used;
+            const uint32_t a0 = s0 + p * share, a1 = min(s1, a0 + share);
 #pragma unroll 1
-                for (uint32_t s = a0 + lane; s < a1; s += GATHER_LANES) {
-                    if (slot_bucket[s] == b) {
-                        const G1X v = g1x_load(slot_pt + s);
-                        g1x_add_cold(acc, v);
-                    }
-                }
+            for (uint32_t s = a0 + lane; s < a1; s += LANES) {
+                const G1X v = g1x_load(slot_pt + s);
+                g1x_add_cold(acc, v);
             }
         }
     }
-    group_sum(acc, GATHER_LANES);  // every lane of the wave takes part in the shuffles
+    group_sum(acc, LANES);  // every lane of the wave takes part in the shuffles
     if (active && lane == 0) g1x_store(part + (size_t)b * parts + p, acc);
 }
 
@@ -445,19 +418,18 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     ws->parts_fixed = 8;
     ws->parts_generic = 1;
     const size_t nbt = (size_t)ws->nwin * ws->nb;
-    const size_t ent = max_n * ws->nwin;
+    const size_t ent = max_n * ws->nwin + nbt * (SEG0 - 1);  // + per-bucket padding
     const size_t nchunks = (max_n + CHUNK - 1) / CHUNK;
     const size_t threads = (ent + SEG0 - 1) / SEG0 + 1;
     size_t part_n = nbt * ws->parts_generic;
     if ((size_t)ws->nb * ws->parts_fixed > part_n) part_n = (size_t)ws->nb * ws->parts_fixed;
-    MSM_TRY(hipMalloc(&ws->digits, ent * sizeof(int32_t)));
+    MSM_TRY(hipMalloc(&ws->digits, max_n * ws->nwin * sizeof(int32_t)));
     MSM_TRY(hipMalloc(&ws->totals, (nbt + 1) * 4));
     MSM_TRY(hipMalloc(&ws->bucket_start, (nbt + 1) * 4));
     MSM_TRY(hipMalloc(&ws->blockbase, nchunks * ws->nwin * ws->nb * 4));
     MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
     MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint2)));
-    MSM_TRY(hipMalloc(&ws->slot_bucket, 2 * threads * 4));
-    MSM_TRY(hipMalloc(&ws->slot_pt, 2 * threads * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->bit_sum, (size_t)ws->nwin * c * BITSUM_SPLIT * sizeof(G1X)));
     return ws;
@@ -471,7 +443,6 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->blockbase);
     hipFree(ws->counts);
     hipFree(ws->entries);
-    hipFree(ws->slot_bucket);
     hipFree(ws->slot_pt);
     hipFree(ws->part);
     hipFree(ws->bit_sum);
@@ -510,11 +481,13 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
         hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
                            nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
                            ws->entries);
-        const size_t worst = (size_t)n * nwin;
+        hipLaunchKernelGGL(msm_pad_kernel, dim3((nbt + 255) / 256), dim3(256), 0, st, ws->totals, ws->bucket_start, nbt,
+                           ws->entries);
+        const size_t worst = (size_t)n * nwin + (size_t)nbt * (SEG0 - 1);  // worst-case padded entry count
         const size_t threads = (worst + SEG0 - 1) / SEG0;
         if (accum_events) hipEventRecord(accum_events[0], st);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                           fixed ? table : bases, ws->counts, parts, ws->part, ws->slot_bucket, ws->slot_pt);
+                           fixed ? table : bases, ws->counts, ws->slot_pt);
         if (accum_events) hipEventRecord(accum_events[1], st);
     }
     hipStream_t ts = st;
@@ -525,8 +498,12 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
     }
     if (n > 0) {
         const uint32_t ngroups = nbt * parts;
-        hipLaunchKernelGGL(msm_gather_kernel, dim3((ngroups * GATHER_LANES + 255) / 256), dim3(256), 0, ts,
-                           ws->bucket_start, ws->counts, ws->slot_bucket, ws->slot_pt, parts, ngroups, ws->part);
+        if (fixed)
+            hipLaunchKernelGGL(msm_gather_kernel<16>, dim3((ngroups * 16 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
+                               ws->slot_pt, parts, ngroups, ws->part);
+        else
+            hipLaunchKernelGGL(msm_gather_kernel<4>, dim3((ngroups * 4 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
+                               ws->slot_pt, parts, ngroups, ws->part);
     }
     hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(256), 0, ts, ws->part, parts, nb, c,
                        ws->bit_sum);
