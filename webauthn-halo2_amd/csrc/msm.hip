@@ -21,8 +21,8 @@
 //   3. msm_scan          exclusive scan of bucket totals -> bucket starts
 //   4. msm_sort<SCATTER> same workgroups: LDS cursors = bucket start + reserved base,
 //                        counting-sort scatter of (bucket, +-base index) entries
-//   5. msm_accumulate    bucket ranges are padded to multiples of 32 entries; every lane sums one
-//                        aligned 32-entry segment with XYZZ mixed adds (8M + 2S) -> one partial
+//   5. msm_accumulate    bucket ranges are padded to multiples of 16 entries; every lane sums one
+//                        aligned 16-entry segment with XYZZ mixed adds (8M + 2S) -> one partial
 //                        sum ("slot") per lane, all lanes of a launch do the same amount of work
 //   6. msm_gather        16-lane groups sum each bucket's slots (shuffle tree), on the tail stream
 //   7. msm_bitsum        sum_j j B_j = sum_t 2^t G_t, G_t = sum of buckets with bit t of j set:
@@ -40,7 +40,7 @@ namespace zk {
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
-static constexpr uint32_t SEG0 = 32;      // entries per accumulate lane
+static constexpr uint32_t SEG0 = 16;      // entries per accumulate lane
 
 struct MsmWorkspace {
     size_t max_n;
