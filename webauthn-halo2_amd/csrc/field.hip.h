@@ -314,6 +314,16 @@ __device__ __forceinline__ void zk_fips_high(uint64_t& lo, uint32_t& hi, const u
     hi = 0;
 }
 
+// r in [0, 2p) -> [0, p): subtract p, add it back under the borrow mask (25 instructions)
+template <class PRM>
+__device__ __forceinline__ void zk_reduce_once_asm(uint32_t (&r)[8]) {
+    uint32_t m, t;
+    asm("v_sub_co_u32 %0, vcc, %0, %10\n\tv_subb_co_u32 %1, vcc, %1, %11, vcc\n\tv_subb_co_u32 %2, vcc, %2, %12, vcc\n\tv_subb_co_u32 %3, vcc, %3, %13, vcc\n\tv_subb_co_u32 %4, vcc, %4, %14, vcc\n\tv_subb_co_u32 %5, vcc, %5, %15, vcc\n\tv_subb_co_u32 %6, vcc, %6, %16, vcc\n\tv_subb_co_u32 %7, vcc, %7, %17, vcc\n\tv_cndmask_b32_e64 %8, 0, -1, vcc\n\tv_and_b32 %9, %10, %8\n\tv_add_co_u32 %0, vcc, %0, %9\n\tv_and_b32 %9, %11, %8\n\tv_addc_co_u32 %1, vcc, %1, %9, vcc\n\tv_and_b32 %9, %12, %8\n\tv_addc_co_u32 %2, vcc, %2, %9, vcc\n\tv_and_b32 %9, %13, %8\n\tv_addc_co_u32 %3, vcc, %3, %9, vcc\n\tv_and_b32 %9, %14, %8\n\tv_addc_co_u32 %4, vcc, %4, %9, vcc\n\tv_and_b32 %9, %15, %8\n\tv_addc_co_u32 %5, vcc, %5, %9, vcc\n\tv_and_b32 %9, %16, %8\n\tv_addc_co_u32 %6, vcc, %6, %9, vcc\n\tv_and_b32 %9, %17, %8\n\tv_addc_co_u32 %7, vcc, %7, %9, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "=&v"(m), "=&v"(t)
+        : "v"(PRM::P[0]), "v"(PRM::P[1]), "v"(PRM::P[2]), "v"(PRM::P[3]), "v"(PRM::P[4]), "v"(PRM::P[5]), "v"(PRM::P[6]), "v"(PRM::P[7])
+        : "vcc");
+}
+
 template <class PRM>
 __device__ __forceinline__ Fe<PRM> fe_mul_gfx950(const Fe<PRM>& a, const Fe<PRM>& b) {
     uint32_t m[8];
@@ -336,7 +346,7 @@ __device__ __forceinline__ Fe<PRM> fe_mul_gfx950(const Fe<PRM>& a, const Fe<PRM>
     zk_fips_high<13>(lo, hi, m, r, a, b);
     zk_fips_high<14>(lo, hi, m, r, a, b);
     r.v[7] = (uint32_t)lo;  // column 15 is empty; the total is < 2p < 2^255
-    reduce_once(r);
+    zk_reduce_once_asm<PRM>(r.v);
     return r;
 }
 #endif
