@@ -46,12 +46,12 @@ struct MsmWorkspace {
     size_t max_n;
     uint32_t c, nwin, nb;       // window bits, windows, buckets per window
     uint32_t parts_fixed, parts_generic;
-    int32_t* digits;            // [nwin][max_n]
+    int16_t* digits;            // [nwin][max_n]  (|digit| <= 2^(c-1) <= 8192)
     uint32_t* totals;           // [nwin*nb + 1]
     uint32_t* bucket_start;     // [nwin*nb + 1]
     uint32_t* blockbase;        // [nblk][nb]
     uint32_t* counts;           // [4]
-    uint2* entries;             // [max_n * nwin]
+    uint32_t* entries;          // [max_n * nwin + padding]: +-base index, bucket implied by position
     G1X* slot_pt;               // [entries / SEG0]
     G1X* part;                  // [nbt * parts]
     G1X* bit_sum;               // [nwin * c]
@@ -74,7 +74,7 @@ uint32_t msm_ws_window(const MsmWorkspace* ws) { return ws->c; }
 // ---------------------------------------------------------------- recode ---
 
 __global__ __launch_bounds__(256) void msm_recode_kernel(const Fr* __restrict__ scalars, uint32_t n, uint32_t stride,
-                                                         uint32_t c, uint32_t nwin, int32_t* __restrict__ digits) {
+                                                         uint32_t c, uint32_t nwin, int16_t* __restrict__ digits) {
     __shared__ uint32_t limbs[256][9];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -102,24 +102,24 @@ __global__ __launch_bounds__(256) void msm_recode_kernel(const Fr* __restrict__ 
             d = (int32_t)raw;
             carry = 0;
         }
-        digits[(size_t)w * stride + i] = d;
+        digits[(size_t)w * stride + i] = (int16_t)d;
     }
 }
 
 // ------------------------------------------------------- histogram / scatter ---
 // grid.x = nchunks * nwin; blk = w * nchunks + chunk.  slice = fixed ? 0 : w.
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void msm_sort_kernel(const int32_t* __restrict__ digits, uint32_t n, uint32_t stride,
+__global__ __launch_bounds__(256) void msm_sort_kernel(const int16_t* __restrict__ digits, uint32_t n, uint32_t stride,
                                                        uint32_t nchunks, uint32_t nb, uint32_t fixed,
                                                        uint32_t table_stride, uint32_t* __restrict__ totals,
                                                        const uint32_t* __restrict__ bucket_start,
-                                                       uint32_t* __restrict__ blockbase, uint2* __restrict__ entries) {
+                                                       uint32_t* __restrict__ blockbase, uint32_t* __restrict__ entries) {
     extern __shared__ uint32_t lds[];  // nb counters / cursors
     const uint32_t blk = blockIdx.x;
     const uint32_t w = blk / nchunks, chunk = blk - w * nchunks;
     const uint32_t slice = fixed ? 0 : w;
     const uint32_t lo = chunk * CHUNK, hi = min(n, lo + CHUNK);
-    const int32_t* dg = digits + (size_t)w * stride;
+    const int16_t* dg = digits + (size_t)w * stride;
     if (!SCATTER) {
         for (uint32_t b = threadIdx.x; b < nb; b += 256) lds[b] = 0;
     } else {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void msm_sort_kernel(const int32_t* __restrict
         const uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
         if (SCATTER) {
             const uint32_t idx = (fixed ? w * table_stride : 0) + i;
-            entries[pos] = make_uint2(slice * nb + mag - 1, idx | (d < 0 ? SIGN_BIT : 0));
+            entries[pos] = idx | (d < 0 ? SIGN_BIT : 0);
         }
     }
     if (!SCATTER) {
@@ -178,28 +178,28 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
 
 // fill the padding at the end of every bucket with skip markers
 __global__ void msm_pad_kernel(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ bucket_start, uint32_t m,
-                               uint2* __restrict__ entries) {
+                               uint32_t* __restrict__ entries) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= m) return;
     const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
-    for (uint32_t p = beg; p < end; p++) entries[p] = make_uint2(b, SKIP_ENTRY);
+    for (uint32_t p = beg; p < end; p++) entries[p] = SKIP_ENTRY;
 }
 
 // ------------------------------------------------------------ accumulate ---
 
 // Every lane sums one aligned segment of SEG0 entries; bucket ranges are padded to multiples
 // of SEG0, so a segment lies inside ONE bucket and yields one partial sum ("slot").
-__global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint2* __restrict__ entries,
+__global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
                                                             const uint32_t* __restrict__ counts,
                                                             G1X* __restrict__ slot_pt) {
     const uint32_t total = counts[0];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
-    const uint2* e = entries + (size_t)t * SEG0;
+    const uint32_t* e = entries + (size_t)t * SEG0;
     G1X acc = G1X::identity();
     for (uint32_t k = 0; k < SEG0; k++) {
-        const uint32_t y = e[k].y;
+        const uint32_t y = e[k];
         if (y == SKIP_ENTRY) continue;  // padding at the end of a bucket
         G1Affine p = affine_load(bases + (y & ~SIGN_BIT));
         if (affine_is_identity(p)) continue;
@@ -423,12 +423,12 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     const size_t threads = (ent + SEG0 - 1) / SEG0 + 1;
     size_t part_n = nbt * ws->parts_generic;
     if ((size_t)ws->nb * ws->parts_fixed > part_n) part_n = (size_t)ws->nb * ws->parts_fixed;
-    MSM_TRY(hipMalloc(&ws->digits, max_n * ws->nwin * sizeof(int32_t)));
+    MSM_TRY(hipMalloc(&ws->digits, max_n * ws->nwin * sizeof(int16_t)));
     MSM_TRY(hipMalloc(&ws->totals, (nbt + 1) * 4));
     MSM_TRY(hipMalloc(&ws->bucket_start, (nbt + 1) * 4));
     MSM_TRY(hipMalloc(&ws->blockbase, nchunks * ws->nwin * ws->nb * 4));
     MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
-    MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint2)));
+    MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint32_t)));
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->bit_sum, (size_t)ws->nwin * c * BITSUM_SPLIT * sizeof(G1X)));
@@ -476,7 +476,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
                            ws->digits);
         hipLaunchKernelGGL(msm_sort_kernel<false>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
                            nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
-                           (uint2*)nullptr);
+                           (uint32_t*)nullptr);
         hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
         hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
                            nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
