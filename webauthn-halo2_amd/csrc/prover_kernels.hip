@@ -351,9 +351,9 @@ void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, 
     hipLaunchKernelGGL(lk_numden_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ap, sp, inp, tab, beta, gamma, num, den, n);
 }
 
-// frac[i] = num[i] / den[i]  (Montgomery's trick over 8 elements per thread; 0 -> 0 like batch_invert)
+// frac[i] = num[i] / den[i]  (Montgomery's trick over 16 elements per thread; 0 -> 0 like batch_invert)
 __global__ void frac_kernel(const Fr* __restrict__ num, const Fr* __restrict__ den, Fr* __restrict__ frac, uint32_t n) {
-    constexpr int E = 8;
+    constexpr int E = 16;
     const uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) * E;
     if (base >= n) return;
     Fr d[E], pre[E];
@@ -378,8 +378,8 @@ __global__ void frac_kernel(const Fr* __restrict__ num, const Fr* __restrict__ d
     }
 }
 void launch_frac(const Fr* num, const Fr* den, Fr* frac, uint32_t n, hipStream_t st) {
-    const uint32_t threads = (n + 7) / 8;
-    hipLaunchKernelGGL(frac_kernel, dim3((threads + 127) / 128), dim3(128), 0, st, num, den, frac, n);
+    const uint32_t threads = (n + 15) / 16;
+    hipLaunchKernelGGL(frac_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, num, den, frac, n);
 }
 
 // Prefix product: z[0] = init, z[i+1] = z[i] * f[i] for i < n-1.
