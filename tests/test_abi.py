@@ -46,3 +46,14 @@ def test_product_does_not_reference_oracle():
                     # prover_smoke() is the smoke-test checker hook: the only place allowed to reach the oracle
                     src = src[:src.index("def prover_smoke")]
                 assert "zkoracle" not in src and "liboracle" not in src, f
+
+
+def test_header_is_plain_c():
+    """The ABI header must be consumable by a C compiler (cgo / bindgen / ctypes-style binding)."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "zkmi355.h"\nint main(void) { zk_ctx* c = 0; zk_circuit_params p = {19, 1, 1, 1, 18}; (void)c; (void)p; return ZK_OK; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", src])

