@@ -562,7 +562,13 @@ struct Prover {
         if (pipe) {
             commit_begin(0, pk->adv_val[0], n, ZK_BASIS_LAGRANGE);
         } else {
-            for (uint32_t j = 0; j < lay.n_adv && ok(); j++) commit_write(pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+            // several advice columns: keep MSM_LANES commitments in flight, collect in column order
+            const uint32_t LN = (uint32_t)zk_ctx::MSM_LANES;
+            for (uint32_t j = 0; j < lay.n_adv && ok(); j++) {
+                if (j >= LN) commit_end_write((int)(j % LN));
+                commit_begin((int)(j % LN), pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+            }
+            for (uint32_t j = (lay.n_adv > LN ? lay.n_adv - LN : 0); j < lay.n_adv && ok(); j++) commit_end_write((int)(j % LN));
         }
         if (!ok()) return rc;
 
