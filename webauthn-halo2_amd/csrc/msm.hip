@@ -24,7 +24,8 @@
 //   5. msm_accumulate    bucket ranges are padded to multiples of 16 entries; every lane sums one
 //                        aligned 16-entry segment with XYZZ mixed adds (8M + 2S) -> one partial
 //                        sum ("slot") per lane, all lanes of a launch do the same amount of work
-//   6. msm_gather        16-lane groups sum each bucket's slots (shuffle tree), on the tail stream
+//   6. msm_gather1/2     two-level sum of each bucket's slots: dense lanes add 8 slots serially, then
+//                        16-lane groups finish each bucket with a shuffle tree (tail stream)
 //   7. msm_bitsum        sum_j j B_j = sum_t 2^t G_t, G_t = sum of buckets with bit t of j set:
 //                        c tree reductions per bucket set; the short Horner is done on the host
 // Load balance does not depend on the scalar distribution: witness columns are
@@ -41,6 +42,8 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
 static constexpr uint32_t SEG0 = 16;      // entries per accumulate lane
+static constexpr uint32_t GA = 8;         // slots per first-level gather lane
+static constexpr uint32_t PAD = SEG0 * GA;  // bucket ranges are padded to multiples of PAD entries
 
 struct MsmWorkspace {
     size_t max_n;
@@ -53,6 +56,7 @@ struct MsmWorkspace {
     uint32_t* counts;           // [4]
     uint32_t* entries;          // [max_n * nwin + padding]: +-base index, bucket implied by position
     G1X* slot_pt;               // [entries / SEG0]
+    G1X* partial;               // [entries / PAD]
     G1X* part;                  // [nbt * parts]
     G1X* bit_sum;               // [nwin * c]
 };
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(256) void msm_sort_kernel(const int16_t* __restrict
     }
 }
 
-// exclusive scan of the bucket sizes, each rounded up to a multiple of SEG0 (so that an
-// accumulate lane never straddles two buckets): out[0..m], out[m] = padded total = counts[0]
+// exclusive scan of the bucket sizes, each rounded up to a multiple of PAD (so that neither an
+// accumulate lane nor a first-level gather lane straddles two buckets): out[0..m], out[m] = padded total = counts[0]
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                         uint32_t m, uint32_t* __restrict__ counts) {
     __shared__ uint32_t part[1024];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     const uint32_t lo = min(m, threadIdx.x * chunk);
     const uint32_t hi = min(m, lo + chunk);
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += (in[i] + SEG0 - 1) & ~(SEG0 - 1);
+    for (uint32_t i = lo; i < hi; i++) sum += (in[i] + PAD - 1) & ~(PAD - 1);
     part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t run = part[threadIdx.x] - sum;
     for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t h = (in[i] + SEG0 - 1) & ~(SEG0 - 1);
+        const uint32_t h = (in[i] + PAD - 1) & ~(PAD - 1);
         out[i] = run;
         run += h;
     }
@@ -284,13 +288,29 @@ __device__ __forceinline__ void group_sum(G1X& acc, int width) {
     }
 }
 
-// One LANES-lane group per (bucket b, part p): sums the p-th share of the bucket's slots
-// (slots [start_b / SEG0, start_{b+1} / SEG0) — contiguous, all of bucket b), lanes stride over
-// the share, then a shuffle tree.  A bucket uses ceil(slots / (4 * LANES)) parts (at most
-// `parts`); the others stay identity.
+// First-level gather: every lane sums GA consecutive slots serially (same bucket by alignment):
+// dense lanes, no idle tree steps — this is where most of the slot additions happen.
+__global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X* __restrict__ slot_pt, const uint32_t* __restrict__ counts,
+                                                         G1X* __restrict__ partial) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if ((size_t)t * PAD >= counts[0]) return;
+    const G1X* src = slot_pt + (size_t)t * GA;
+    G1X acc = g1x_load(src);
+#pragma unroll 1
+    for (uint32_t k = 1; k < GA; k++) {
+        const G1X v = g1x_load(src + k);
+        g1x_add_cold(acc, v);
+    }
+    g1x_store(partial + t, acc);
+}
+
+// Second level: one LANES-lane group per (bucket b, part p) sums the p-th share of the bucket's
+// first-level partials ([start_b / PAD, start_{b+1} / PAD) — contiguous, all of bucket b): lanes
+// stride over the share, then a shuffle tree.  A bucket uses ceil(partials / (4 * LANES)) parts
+// (at most `parts`); the others stay identity.
 template <uint32_t LANES>
 __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restrict__ bucket_start,
-                                                         const G1X* __restrict__ slot_pt, uint32_t parts, uint32_t ngroups,
+                                                         const G1X* __restrict__ partial, uint32_t parts, uint32_t ngroups,
                                                          G1X* __restrict__ part) {
     const uint32_t gid = (blockIdx.x * 256 + threadIdx.x) / LANES;
     const uint32_t lane = threadIdx.x & (LANES - 1);
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
     if (gid < ngroups) {
         b = gid / parts;
         p = gid - b * parts;
-        const uint32_t s0 = bucket_start[b] / SEG0, s1 = bucket_start[b + 1] / SEG0;
+        const uint32_t s0 = bucket_start[b] / PAD, s1 = bucket_start[b + 1] / PAD;
         const uint32_t len = s1 - s0;
         const uint32_t used = min(parts, (len + 4 * LANES - 1) / (4 * LANES));
         if (p < used) {
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
             const uint32_t a0 = s0 + p * share, a1 = min(s1, a0 + share);
 #pragma unroll 1
             for (uint32_t s = a0 + lane; s < a1; s += LANES) {
-                const G1X v = g1x_load(slot_pt + s);
+                const G1X v = g1x_load(partial + s);
                 g1x_add_cold(acc, v);
             }
         }
@@ -418,7 +438,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     ws->parts_fixed = 8;
     ws->parts_generic = 1;
     const size_t nbt = (size_t)ws->nwin * ws->nb;
-    const size_t ent = max_n * ws->nwin + nbt * (SEG0 - 1);  // + per-bucket padding
+    const size_t ent = max_n * ws->nwin + nbt * (PAD - 1);  // + per-bucket padding
     const size_t nchunks = (max_n + CHUNK - 1) / CHUNK;
     const size_t threads = (ent + SEG0 - 1) / SEG0 + 1;
     size_t part_n = nbt * ws->parts_generic;
@@ -430,6 +450,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
     MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint32_t)));
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->bit_sum, (size_t)ws->nwin * c * BITSUM_SPLIT * sizeof(G1X)));
     return ws;
@@ -444,6 +465,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->counts);
     hipFree(ws->entries);
     hipFree(ws->slot_pt);
+    hipFree(ws->partial);
     hipFree(ws->part);
     hipFree(ws->bit_sum);
     delete ws;
@@ -483,7 +505,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
                            ws->entries);
         hipLaunchKernelGGL(msm_pad_kernel, dim3((nbt + 255) / 256), dim3(256), 0, st, ws->totals, ws->bucket_start, nbt,
                            ws->entries);
-        const size_t worst = (size_t)n * nwin + (size_t)nbt * (SEG0 - 1);  // worst-case padded entry count
+        const size_t worst = (size_t)n * nwin + (size_t)nbt * (PAD - 1);  // worst-case padded entry count
         const size_t threads = (worst + SEG0 - 1) / SEG0;
         if (accum_events) hipEventRecord(accum_events[0], st);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
@@ -497,13 +519,17 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
         ts = tail_st;
     }
     if (n > 0) {
+        const size_t worst = (size_t)n * nwin + (size_t)nbt * (PAD - 1);
+        const size_t lanes1 = (worst + PAD - 1) / PAD;
+        hipLaunchKernelGGL(msm_gather1_kernel, dim3((uint32_t)((lanes1 + 63) / 64)), dim3(64), 0, ts, ws->slot_pt, ws->counts,
+                           ws->partial);
         const uint32_t ngroups = nbt * parts;
         if (fixed)
             hipLaunchKernelGGL(msm_gather_kernel<16>, dim3((ngroups * 16 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
-                               ws->slot_pt, parts, ngroups, ws->part);
+                               ws->partial, parts, ngroups, ws->part);
         else
             hipLaunchKernelGGL(msm_gather_kernel<4>, dim3((ngroups * 4 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
-                               ws->slot_pt, parts, ngroups, ws->part);
+                               ws->partial, parts, ngroups, ws->part);
     }
     hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(256), 0, ts, ws->part, parts, nb, c,
                        ws->bit_sum);
