@@ -334,7 +334,8 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
             }
         }
     }
-    group_sum(acc, LANES);  // every lane of the wave takes part in the shuffles
+    if (!__any(active)) return;  // wave-uniform: no group of this wave has work
+    group_sum(acc, LANES);       // every lane of the wave takes part in the shuffles
     if (active && lane == 0) g1x_store(part + (size_t)b * parts + p, acc);
 }
 
