@@ -121,25 +121,32 @@ def cpu_baseline(eng):
     bases = eng.srs_export(0, 0, n)
     s = np.frombuffer(np.random.default_rng(5).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
     s[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    t0 = time.time()
-    cops.msm(s, bases, cores)
-    t_msm = time.time() - t0
-    t0 = time.time()
-    cops.ntt(s, F.omega(K), K, cores)
-    t_ntt19 = time.time() - t0
+    def best(fn, thread_options):
+        """fastest of a few thread counts (the port spawns a thread team per call/stage: on a many-core
+        host the full core count is not always the fastest choice) — the baseline gets its best case"""
+        bt, bn = None, None
+        for nt in thread_options:
+            t0 = time.time()
+            fn(nt)
+            dt = time.time() - t0
+            if bt is None or dt < bt:
+                bt, bn = dt, nt
+        return bt, bn
+
+    opts = sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True)
+    t_msm, n_msm = best(lambda nt: cops.msm(s, bases, nt), opts)
+    t_ntt19, n_ntt = best(lambda nt: cops.ntt(s, F.omega(K), K, nt), opts)
     big = np.concatenate([s, s, s, s])
-    t0 = time.time()
-    cops.ntt(big, F.omega(K + 2), K + 2, cores)
-    t_ntt21 = time.time() - t0
+    t_ntt21, _ = best(lambda nt: cops.ntt(big, F.omega(K + 2), K + 2, nt), opts)
     per_proof = 12 * t_msm + 5 * t_ntt19 + 6 * t_ntt21
     return {
         "value": 1.0 / per_proof,
         "unit": "proofs/s",
-        "cores": cores,
+        "cores": n_msm,  # threads of the fastest configuration actually used (host has %d cores)
         "kind": "port",
-        "sample": "oracle C port of halo2 best_multiexp/best_fft: 1xMSM(2^19)=%.2fs, 1xNTT(2^19)=%.3fs, 1xNTT(2^21)=%.3fs; "
+        "sample": "host has %d cores; oracle C port of halo2 best_multiexp/best_fft, best of thread counts %s: 1xMSM(2^19)=%.2fs (%d thr), 1xNTT(2^19)=%.3fs (%d thr), 1xNTT(2^21)=%.3fs; "
         "scaled to 12 MSM + 5 NTT(2^19) + 6 NTT(2^21) per proof (quotient/eval not included); "
-        "the reference Rust prover cannot be built on this node (no cargo/rustc)" % (t_msm, t_ntt19, t_ntt21),
+        "the reference Rust prover cannot be built on this node (no cargo/rustc)" % (cores, opts, t_msm, n_msm, t_ntt19, n_ntt, t_ntt21),
     }
 
 
