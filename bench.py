@@ -142,7 +142,7 @@ def cpu_baseline(eng):
     return {
         "value": 1.0 / per_proof,
         "unit": "proofs/s",
-        "cores": n_msm,  # threads of the fastest configuration actually used (host has %d cores)
+        "cores": n_msm,  # threads of the fastest configuration actually used
         "kind": "port",
         "sample": "host has %d cores; oracle C port of halo2 best_multiexp/best_fft, best of thread counts %s: 1xMSM(2^19)=%.2fs (%d thr), 1xNTT(2^19)=%.3fs (%d thr), 1xNTT(2^21)=%.3fs; "
         "scaled to 12 MSM + 5 NTT(2^19) + 6 NTT(2^21) per proof (quotient/eval not included); "
