@@ -53,6 +53,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
     const uint32_t tw_shift = a.log_n - a.log_ns - a.log_r;  // N / (Ns * R)
     const uint32_t nmask = N - 1;
 
+    // ---- the R/2 twiddles of the in-tile stages (w_R^j = w_N^(j N/R)) go to LDS once per workgroup
+    Fr* wr = s + tile;
+    for (uint32_t j = threadIdx.x; j < (R >> 1); j += NTT_THREADS) {
+        const uint32_t ex = j << (a.log_n - a.log_r);
+        wr[j] = fe_load(a.tw + (a.inverse ? ((N - ex) & nmask) : ex));
+    }
+
     // ---- load: s[r*T + t] = in[j + r*N/R] * pre * w_{Ns*R}^{r*(j mod Ns)}
     for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
         const uint32_t t = e & (T - 1), r = e >> a.log_t;
@@ -90,12 +97,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
             const Fr u = *pu, v = *pv;
             *pu = fe_add(u, v);
             Fr d = fe_sub(u, v);
-            if (lo) {
-                // w_R^(lo * R/(2*half)) = w_N^(lo * N/(2*half))
-                const uint32_t ex = lo << (a.log_n - st - 1);
-                const uint32_t ti = a.inverse ? ((N - ex) & nmask) : ex;
-                d = fe_mul(d, fe_load(a.tw + ti));
-            }
+            if (lo) d = fe_mul(d, wr[lo << (a.log_r - st - 1)]);  // w_R^(lo * R/(2*half))
             *pv = d;
         }
         __syncthreads();
@@ -205,7 +207,7 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
             a.post[i] = job.post[i];
         }
         const uint32_t blocks = N >> (a.log_r + a.log_t);
-        const size_t lds = (size_t)sizeof(Fr) << (a.log_r + a.log_t);
+        const size_t lds = ((size_t)sizeof(Fr) << (a.log_r + a.log_t)) + (sizeof(Fr) << a.log_r) / 2;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(NTT_THREADS), lds, st, a);
         cur_in = bufs[which];
         which ^= 1;
