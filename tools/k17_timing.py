@@ -1,0 +1,15 @@
+import sys,os,time
+sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),"oracle")]
+import numpy as np, webauthn_halo2_amd as zk
+from webauthn_halo2_amd import engine as E
+p=zk.circuit.K17; eng=zk.Engine(0); eng.srs_setup(17)
+asg=zk.circuit.synthesize(p,1); pk=eng.keygen(p,np.stack([asg.to_limbs(c) for c in asg.fixed]),asg.copies)
+polys=[]
+for col in asg.advice:
+    h=eng.poly(1<<17); eng.upload_canonical(h,asg.to_limbs(col)); polys.append(h)
+for tk in (E.ZK_TRANSCRIPT_BLAKE2B, E.ZK_TRANSCRIPT_EVM):
+    for i in range(3): eng.prove(pk,polys,bytes(32),tk)
+    ts=[]
+    for i in range(8):
+        t0=time.perf_counter(); eng.prove(pk,polys,bytes(32),tk); ts.append((time.perf_counter()-t0)*1e3)
+    print(os.environ.get("ZKMI355_MSM_WINDOW"), tk, round(min(ts),2))

@@ -31,6 +31,7 @@
 // Load balance does not depend on the scalar distribution: witness columns are
 // dominated by zeros / small values (hot low buckets), and a segment is a fixed number
 // of entries whatever bucket they fall in.
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -64,7 +65,9 @@ struct MsmWorkspace {
 uint32_t msm_auto_window(size_t n) {
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 6;
+    // measured on MI355X with whole proofs (tools/k17_timing.py, bench.py): 13 at 2^19, 12 at 2^16..2^18
+    int c = lg >= 19 ? (int)lg - 6 : (lg >= 16 ? 12 : (int)lg - 5);
+    if (const char* e = getenv("ZKMI355_MSM_WINDOW")) c = atoi(e);  // tuning override
     if (c < 9) c = 9;
     if (c > 14) c = 14;  // 2^(c-1) u32 counters must fit the LDS histogram
     return (uint32_t)c;
