@@ -109,6 +109,8 @@ typedef struct {
     uint32_t num_lookup_advice;
     uint32_t num_fixed;
     uint32_t lookup_bits;
+    uint32_t num_idle_gate_columns; /* trailing gate columns whose selector is never enabled: halo2's selector
+                                       compression gives them no fixed column (their gate keeps its y-slot) */
 } zk_circuit_params;
 typedef uint64_t zk_pk; /* opaque: proving key + verifying key + prover workspace, device resident */
 
@@ -128,6 +130,9 @@ int zk_pk_free(zk_ctx* ctx, zk_pk pk);
 /* the VerifyingKey half: commitments (affine Montgomery) and transcript_repr; counts = {n_fixed, n_perm} */
 int zk_vk_export(zk_ctx* ctx, zk_pk pk, uint64_t* fixed_commitments, uint64_t* perm_commitments,
                  uint64_t transcript_repr[4], uint32_t counts[2]);
+/* bytes zk_prove will write for this key / transcript / scheme (what `transcript.finalize().len()` is in
+ * the reference, e.g. 960 at k=19 Blake2b, halo2-circuits/src/results/ecdsa_bench.csv:2) */
+int zk_proof_size(zk_ctx* ctx, zk_pk pk, int transcript, int scheme, size_t* out);
 /* replaces plonk::create_proof (ecdsa_p256.rs:366-373, 416-423, 555-562) for one circuit with no
  * instances.  `advice` are resident columns (Lagrange values, Montgomery, n rows each; the last 7 rows
  * are overwritten by blinding in a private copy).  Randomness: ChaCha20Rng::from_seed(rng_seed), one

@@ -37,9 +37,16 @@ class Shape:
     num_lookup_advice: int     # L
     num_fixed: int             # F: constant columns
     lookup_bits: int = 0
+    # gate columns (the last ones) whose selector is never enabled: halo2's selector compression replaces a
+    # never-enabled selector by the constant 0, so it has no fixed column; the gate keeps its slot in the
+    # y-combination.  [RECALLED plonk/circuit/compress_selectors; explains the published sizes of the
+    # k <= 13 rows, halo2-circuits/src/results/ecdsa_bench.csv:8-10, SURVEY.md App. A.1]
+    idle_gate_columns: int = 0
 
     def __post_init__(self):
         A, L, F = self.num_advice, self.num_lookup_advice, self.num_fixed
+        U = self.idle_gate_columns
+        assert 0 <= U < A and not (A == 1 and U)
         self.n = 1 << self.k
         self.single = A == 1
         self.n_gate = A
@@ -53,9 +60,9 @@ class Shape:
             self.fx_qlookup = F + 2
             self.n_fix = F + 3
         else:
-            self.fx_sel = [F + 1 + j for j in range(A)]
+            self.fx_sel = [F + 1 + j for j in range(A - U)] + [None] * U
             self.fx_qlookup = None
-            self.n_fix = F + 1 + A
+            self.n_fix = F + 1 + A - U
         self.advice_queries = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(self.n_lookup_cols)]
         self.fixed_queries = [(f, 0) for f in range(self.n_fix)]
         self.perm_cols = [("fixed", f) for f in self.fx_const] + [("advice", j) for j in range(self.n_adv)]
@@ -361,7 +368,7 @@ def expected_h_eval(vk, pf):
     # gates: q_j * (a + b*c - d)
     for j in range(sh.n_gate):
         a, b, c, d = (adv[(j, r)] for r in range(4))
-        exprs.append(fix[sh.fx_sel[j]] * ((a + b * c - d) % R) % R)
+        exprs.append(0 if sh.fx_sel[j] is None else fix[sh.fx_sel[j]] * ((a + b * c - d) % R) % R)
     # permutation argument
     col_eval = lambda col: fix[col[1]] if col[0] == "fixed" else adv[(col[1], 0)]
     pe = pf.perm_evals

@@ -145,7 +145,9 @@ def transcript_repr(shape: Shape, fixed_commitments, permutation_commitments):
     shape and the vk commitments, reduced mod r.  Only used for circuits built
     here; the reference's own k=17 value is a fixture."""
     h = hashlib.blake2b(digest_size=64, person=b"zkmi355-vk-repr")
-    h.update(bytes([shape.k, shape.num_advice, shape.num_lookup_advice, shape.num_fixed, shape.lookup_bits]))
+    for v in (shape.k, shape.num_advice, shape.num_lookup_advice, shape.num_fixed, shape.lookup_bits,
+              shape.idle_gate_columns):
+        h.update(int(v).to_bytes(2, "little"))
     for p in list(fixed_commitments) + list(permutation_commitments):
         p = (0, 0) if p is None else p
         h.update(p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little"))
@@ -323,7 +325,7 @@ def create_proof(pk: ProvingKey, advice, rng, kind="evm", scheme=None, trace=Non
         active = (1 - ll - lb) % R
         for j in range(sh.n_gate):
             a, b, c, d4 = (rot(adv_e[j], i, r) for r in range(4))
-            push(fix_e[sh.fx_sel[j]][i] * ((a + b * c - d4) % R) % R)
+            push(0 if sh.fx_sel[j] is None else fix_e[sh.fx_sel[j]][i] * ((a + b * c - d4) % R) % R)
         push(l0 * (1 - z_e[0][i]) % R)
         zl = z_e[-1][i]
         push(ll * ((zl * zl - zl) % R) % R)

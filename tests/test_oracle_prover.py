@@ -12,14 +12,16 @@ SHAPES = {  # (A, L, F, k, lookup_bits): k=19-, k=17-, k=18-like, and one with F
     "k17like": (4, 1, 1, 7, 5),
     "k18like": (2, 1, 1, 6, 4),
     "wide": (3, 2, 2, 7, 5),
+    "idle": (4, 1, 1, 6, 4, 1),   # last gate column never enabled: no selector column (bench rows k <= 13)
 }
 
 
 def build(name, seed=0x5EED0019, worst=False):
-    A, L, F, k, lb = SHAPES[name]
-    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    A, L, F, k, lb, idle = (SHAPES[name] + (0,))[:6]
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb,
+                                 idle_gate_columns=idle)
     asg = zk.circuit.synthesize(p, seed, worst_case=worst)
-    sh = plonk.Shape(k, A, L, F, lb)
+    sh = plonk.Shape(k, A, L, F, lb, idle)
     assert sh.perm_cols == asg.layout.perm_cols and sh.n_fix == asg.layout.n_fix
     return prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice)), asg
 
@@ -68,3 +70,14 @@ def test_cross_transcript_schemes():
         proof = prover.create_proof(pk, asg.advice, ChaCha20Rng(bytes(32)), kind, scheme)
         assert plonk.verify(pk.vk, proof, kind, scheme)
         assert not plonk.verify(pk.vk, proof, kind, "gwc" if scheme == "shplonk" else "shplonk")
+
+
+def test_published_proof_sizes_of_every_bench_row():
+    """K6 widened: the shape model gives the published Blake2b/SHPLONK proof size of all nine rows of
+    halo2-circuits/src/results/ecdsa_bench.csv; rows k <= 13 need 1/2/3 idle gate columns."""
+    rows = [(19, 1, 1, 1, 18, 0, 960), (18, 2, 1, 1, 17, 0, 1344), (17, 4, 1, 1, 16, 0, 1920),
+            (16, 8, 2, 1, 15, 0, 3552), (15, 17, 3, 1, 14, 0, 6560), (14, 34, 6, 1, 13, 0, 12704),
+            (13, 68, 12, 1, 12, 1, 24960), (12, 139, 24, 2, 11, 2, 50496), (11, 291, 53, 4, 10, 3, 106496)]
+    for k, A, L, F, lb, idle, size in rows:
+        sh = plonk.Shape(k, A, L, F, lb, idle)
+        assert 32 * (sh.n_points_before_multiopen() + 2 + sh.n_evals()) == size, k

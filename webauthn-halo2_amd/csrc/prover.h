@@ -7,11 +7,14 @@ namespace zk {
 
 static constexpr uint32_t MAX_LC = 40;       // inputs of one linear combination
 static constexpr uint32_t MAX_CHUNK = 3;     // permutation columns per grand product (degree - 2)
-static constexpr uint32_t MAX_ADV = 40;
-static constexpr uint32_t MAX_FIX = 48;
-static constexpr uint32_t MAX_PERM = 48;
-static constexpr uint32_t MAX_CHUNKS = 24;
-static constexpr uint32_t MAX_LOOKUPS = 8;
+// sized for every row of the reference's bench_ecdsa.config, down to k=11 (291 gate + 53 lookup columns,
+// 4 constants columns); the argument blocks below live in device memory, not in the kernarg segment
+static constexpr uint32_t MAX_ADV = 352;
+static constexpr uint32_t MAX_FIX = 304;
+static constexpr uint32_t MAX_PERM = 352;
+static constexpr uint32_t MAX_CHUNKS = 176;
+static constexpr uint32_t MAX_LOOKUPS = 56;
+static constexpr uint32_t NO_SELECTOR = 0xffffffffu;  // gate column whose selector was compressed to the constant 0
 static constexpr uint32_t BLINDING_FACTORS = 6;  // max(3, 4 queries per gate column) + 2
 
 struct LincombArgs {
@@ -84,13 +87,13 @@ void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c
 void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
 
 // poly.hip
-static constexpr uint32_t MAX_EVALS = 96;
-struct EvalBatchArgs {
-    const Fr* poly[MAX_EVALS];
-    Fr x[MAX_EVALS];
-    Fr y[MAX_EVALS];
+struct EvalItem {
+    const Fr* poly;
+    uint64_t pad_;
+    Fr x;
+    Fr y;  // x^(threads of the launch), filled by launch_eval_batch
 };
-void launch_eval_batch(EvalBatchArgs* h_args, EvalBatchArgs* d_args, uint32_t count, uint32_t n, Fr* scratch, Fr* out,
+void launch_eval_batch(EvalItem* h_items, EvalItem* d_items, uint32_t count, uint32_t n, Fr* scratch, Fr* out,
                        hipStream_t st);
 uint32_t eval_blocks(uint32_t n);
 void launch_eval(const Fr* c, uint32_t n, const Fr& x, Fr* scratch, hipStream_t st);

@@ -29,7 +29,7 @@ struct Col {
 };
 
 struct Layout {
-    uint32_t k, n, A, L, F, lookup_bits;
+    uint32_t k, n, A, L, F, lookup_bits, idle;
     bool single;
     uint32_t n_gate, n_lookup_cols, n_adv, fx_table, fx_qlookup, n_fix;
     std::vector<uint32_t> fx_sel;
@@ -40,7 +40,8 @@ struct Layout {
 
     bool init(const zk_circuit_params& p) {
         k = p.k; A = p.num_advice; L = p.num_lookup_advice; F = p.num_fixed; lookup_bits = p.lookup_bits;
-        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1) return false;
+        idle = p.num_idle_gate_columns;
+        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1 || idle >= A) return false;
         n = 1u << k;
         single = A == 1;
         n_gate = A;
@@ -53,9 +54,9 @@ struct Layout {
             fx_qlookup = F + 2;
             n_fix = F + 3;
         } else {
-            for (uint32_t j = 0; j < A; j++) fx_sel.push_back(F + 1 + j);
+            for (uint32_t j = 0; j < A; j++) fx_sel.push_back(j < A - idle ? F + 1 + j : NO_SELECTOR);
             fx_qlookup = 0;
-            n_fix = F + 1 + A;
+            n_fix = F + 1 + A - idle;
         }
         perm_cols.clear();
         for (uint32_t f = 0; f < F; f++) perm_cols.push_back(Col{1, f});
@@ -98,7 +99,8 @@ struct zk_pk_rec {
     LookupScratch lks{};
     uint32_t* lk_u32 = nullptr;
     QuotientArgs* d_qargs = nullptr;
-    EvalBatchArgs *d_evargs = nullptr, *h_evargs = nullptr;
+    EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
+    uint32_t max_evals = 0;
     Fr *ev_scratch = nullptr, *ev_out = nullptr;
 };
 
@@ -240,6 +242,8 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     zk_pk_rec* pk = new (std::nothrow) zk_pk_rec();
     if (!pk) return ZK_ENOMEM;
     pk->lay = lay;
+    pk->max_evals = (uint32_t)(lay.advice_queries.size() + lay.n_fix + lay.perm_cols.size() + 3 * lay.n_chunks +
+                               5 * lay.n_lookups + 16);
     Dev d{c, pk};
     hipStream_t st = c->stream;
     const Fr* tw = nullptr;
@@ -355,8 +359,9 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     // ---- transcript_repr: stand-in for halo2's pinned-vk hash (same rule as the oracle's keygen)
     {
         Blake2b h("zkmi355-vk-repr");
-        const uint8_t hdr[5] = {(uint8_t)lay.k, (uint8_t)lay.A, (uint8_t)lay.L, (uint8_t)lay.F, (uint8_t)lay.lookup_bits};
-        h.update(hdr, 5);
+        const uint16_t hdr[6] = {(uint16_t)lay.k, (uint16_t)lay.A,           (uint16_t)lay.L,
+                                 (uint16_t)lay.F, (uint16_t)lay.lookup_bits, (uint16_t)lay.idle};
+        h.update((const uint8_t*)hdr, 12);
         auto absorb = [&](const G1Affine& p) {
             const Fq x = fe_from_mont(p.x), y = fe_from_mont(p.y);
             h.update((const uint8_t*)x.v, 32);
@@ -401,11 +406,12 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->t_b = d.alloc(n);
     pk->t_small = d.alloc(n / 16 + 8192);
     if (d.rc) return fail(d.rc);
-    if (hipHostMalloc(&pk->tail_host, 128 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
-    if (hipHostMalloc(&pk->h_evargs, sizeof(EvalBatchArgs)) != hipSuccess || hipMalloc(&pk->d_evargs, sizeof(EvalBatchArgs)) != hipSuccess)
+    if (hipHostMalloc(&pk->tail_host, (pk->max_evals + 16) * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->h_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess ||
+        hipMalloc(&pk->d_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess)
         return fail(ZK_ENOMEM);
-    pk->ev_scratch = d.alloc((size_t)MAX_EVALS * eval_blocks(n));
-    pk->ev_out = d.alloc(MAX_EVALS);
+    pk->ev_scratch = d.alloc((size_t)pk->max_evals * eval_blocks(n));
+    pk->ev_out = d.alloc(pk->max_evals);
     if (d.rc) return fail(d.rc);
     if (hipMalloc(&pk->lk_u32, (size_t)(T + 2) * 6 * 4 + 16 + (size_t)3 * (T / 1024 + 2) * 4) != hipSuccess) return fail(ZK_ENOMEM);
     {
@@ -532,6 +538,37 @@ struct Prover {
             return Fr::zero();
         }
         return *c->host_small;
+    }
+    // out = sum_j c_j * in_j (- sub0 on coefficient 0), any number of inputs: MAX_LC per launch
+    struct Term {
+        const Fr* poly;
+        Fr c;
+    };
+    void lincomb_many(Fr* out, const std::vector<Term>& terms, bool sub0, const Fr& sub0_val, bool accumulate_first = false) {
+        size_t done = 0;
+        bool first = !accumulate_first;
+        do {
+            LincombArgs a;
+            memset(&a, 0, sizeof(a));
+            a.out = out;
+            a.n = n;
+            const size_t take = std::min<size_t>(MAX_LC, terms.size() - done);
+            a.count = (uint32_t)take;
+            a.accumulate = first ? 0 : 1;
+            for (size_t j = 0; j < take; j++) {
+                a.in[j] = terms[done + j].poly;
+                a.len[j] = n;
+                a.c[j] = terms[done + j].c;
+                a.unit[j] = terms[done + j].c == Fr::one();
+            }
+            done += take;
+            if (done == terms.size() && sub0) {
+                a.sub0 = 1;
+                a.sub0_val = sub0_val;
+            }
+            launch_lincomb(a, st);
+            first = false;
+        } while (done < terms.size());
     }
     Fr xrot(const Fr& x, int r) const {
         Fr w = r >= 0 ? omega : omega_inv;
@@ -819,12 +856,12 @@ struct Prover {
         }
         const size_t n_written = ev.size();
         ev.push_back(Q{pk->h_comb, 0, Fr::zero()});
-        if (ev.size() > MAX_EVALS) return ZK_EINVAL;
+        if (ev.size() > pk->max_evals) return ZK_ESTATE;
         {
-            EvalBatchArgs* ha = pk->h_evargs;
+            EvalItem* ha = pk->h_evargs;
             for (size_t i = 0; i < ev.size(); i++) {
-                ha->poly[i] = ev[i].poly;
-                ha->x[i] = xrot(x, ev[i].rot);
+                ha[i].poly = ev[i].poly;
+                ha[i].x = xrot(x, ev[i].rot);
             }
             hipEventRecord(c->ev[ZK_T_EVAL][0], st);
             launch_eval_batch(ha, pk->d_evargs, (uint32_t)ev.size(), n, pk->ev_scratch, pk->ev_out, st);
@@ -879,24 +916,14 @@ struct Prover {
             }
             size_t set_idx = 0;
             for (auto& s : sets) {
-                if (s.second.size() > MAX_LC) return ZK_EINVAL;
-                LincombArgs a;
-                memset(&a, 0, sizeof(a));
-                a.out = pk->t_a;
-                a.n = n;
-                a.count = (uint32_t)s.second.size();
+                std::vector<Term> terms;
                 Fr pv = Fr::one(), eb = Fr::zero();
-                for (uint32_t j = 0; j < a.count; j++) {
-                    a.in[j] = s.second[j].poly;
-                    a.len[j] = n;
-                    a.c[j] = pv;
-                    a.unit[j] = j == 0;
-                    eb = fe_add(eb, fe_mul(pv, s.second[j].eval));
+                for (auto& qq : s.second) {
+                    terms.push_back(Term{qq.poly, pv});
+                    eb = fe_add(eb, fe_mul(pv, qq.eval));
                     pv = fe_mul(pv, v);
                 }
-                a.sub0 = 1;
-                a.sub0_val = eb;
-                launch_lincomb(a, st);
+                lincomb_many(pk->t_a, terms, true, eb);
                 launch_kate_division(pk->t_a, pk->t_b, n, xrot(x, s.first), pk->t_small, pk->t_small + (n / 32 + 8), st);
                 // the witness commitments need no challenge in between: keep up to MSM_LANES in flight
                 // (t_b is consumed by the MSM's recode kernel before the next set overwrites it: stream order)
@@ -970,25 +997,16 @@ struct Prover {
             for (auto& rs : rsets) {
                 std::vector<Fr> pts;
                 for (int r : rs.rots) pts.push_back(xrot(x, r));
-                if (rs.coms.size() > MAX_LC) return ZK_EINVAL;
-                LincombArgs a;
-                memset(&a, 0, sizeof(a));
-                a.out = pk->t_a;
-                a.n = n;
-                a.count = (uint32_t)rs.coms.size();
+                std::vector<Term> terms;
                 std::vector<Fr> rsum(pts.size(), Fr::zero());
                 Fr py = Fr::one();
-                for (uint32_t j = 0; j < a.count; j++) {
-                    CR* cr = rs.coms[j];
+                for (CR* cr : rs.coms) {
                     low[com_index(cr)] = lagrange_interpolate(pts, cr->evals);
-                    a.in[j] = cr->poly;
-                    a.len[j] = n;
-                    a.c[j] = py;
-                    a.unit[j] = j == 0;
+                    terms.push_back(Term{cr->poly, py});
                     for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
                     py = fe_mul(py, yc);
                 }
-                launch_lincomb(a, st);
+                lincomb_many(pk->t_a, terms, false, Fr::zero());
                 // subtract sum_j y^j R_j(X) (degree < |set|) from the low coefficients
                 std::vector<Fr> lowc(pts.size());
                 if (hipMemcpyAsync(pk->tail_host, pk->t_a, pts.size() * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1020,14 +1038,10 @@ struct Prover {
             if (!ok()) return rc;
             const Fr u = tr->squeeze();
             // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
-            LincombArgs a;
-            memset(&a, 0, sizeof(a));
-            a.out = pk->t_a;
-            a.n = n;
+            std::vector<Term> terms;
             Fr sub = Fr::zero();
             pv = Fr::one();
             std::vector<Fr> z_diffs;
-            uint32_t cnt = 0;
             for (auto& rs : rsets) {
                 std::vector<Fr> diffs;
                 for (int r : all_rots)
@@ -1036,12 +1050,8 @@ struct Prover {
                 z_diffs.push_back(zi);
                 Fr py = Fr::one();
                 for (CR* cr : rs.coms) {
-                    if (cnt + 1 >= MAX_LC) return ZK_EINVAL;
                     const Fr coef = fe_mul(fe_mul(pv, zi), py);
-                    a.in[cnt] = cr->poly;
-                    a.len[cnt] = n;
-                    a.c[cnt] = coef;
-                    cnt++;
+                    terms.push_back(Term{cr->poly, coef});
                     sub = fe_add(sub, fe_mul(coef, eval_small(low[com_index(cr)], u)));
                     py = fe_mul(py, yc);
                 }
@@ -1050,14 +1060,8 @@ struct Prover {
             std::vector<Fr> all_pts;
             for (int r : all_rots) all_pts.push_back(xrot(x, r));
             const Fr zt = vanishing_eval(all_pts, u);
-            a.in[cnt] = hx;
-            a.len[cnt] = n;
-            a.c[cnt] = fe_neg(zt);
-            cnt++;
-            a.count = cnt;
-            a.sub0 = 1;
-            a.sub0_val = sub;
-            launch_lincomb(a, st);
+            terms.push_back(Term{hx, fe_neg(zt)});
+            lincomb_many(pk->t_a, terms, true, sub);
             launch_kate_division(pk->t_a, pk->t_b, n, u, pk->t_small, pk->t_small + (n / 32 + 8), st);
             launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
             commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
@@ -1067,6 +1071,25 @@ struct Prover {
 };
 
 }  // namespace
+
+extern "C" int zk_proof_size(zk_ctx* c, zk_pk pkh, int transcript, int scheme, size_t* out) {
+    if (!c || !out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    auto it = c->pks.find(pkh);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    if (transcript != ZK_TRANSCRIPT_BLAKE2B && transcript != ZK_TRANSCRIPT_EVM) return ZK_EINVAL;
+    if (scheme == ZK_SCHEME_DEFAULT) scheme = transcript == ZK_TRANSCRIPT_EVM ? ZK_SCHEME_GWC : ZK_SCHEME_SHPLONK;
+    if (scheme != ZK_SCHEME_GWC && scheme != ZK_SCHEME_SHPLONK) return ZK_EINVAL;
+    const Layout& lay = it->second->lay;
+    // commitments: advice, (a', s', zL) per lookup, z per chunk, random, h pieces; then the opening proof:
+    // SHPLONK two points, GWC one per distinct rotation {0,1,2,3,-1} (+ `last` once there is a chunk link)
+    size_t points = lay.n_adv + 3 * lay.n_lookups + lay.n_chunks + 1 + lay.n_h;
+    points += scheme == ZK_SCHEME_SHPLONK ? 2 : 5 + (lay.n_chunks > 1 ? 1 : 0);
+    const size_t evals = lay.advice_queries.size() + lay.n_fix + 1 + lay.perm_cols.size() + 3 * lay.n_chunks - 1 +
+                         5 * lay.n_lookups;
+    *out = points * (transcript == ZK_TRANSCRIPT_EVM ? 64 : 32) + evals * 32;
+    return ZK_OK;
+}
 
 extern "C" int zk_prove(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, const uint8_t rng_seed[32],
                         int transcript, int scheme, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {

@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __res
 
     // ---- gates
     for (uint32_t j = 0; j < a.n_gate; j++) {
+        if (a.fx_sel[j] == NO_SELECTOR) {  // never-enabled gate: contributes 0 but keeps its power of y
+            push(Fr::zero());
+            continue;
+        }
         const Fr* c = a.adv[j];
         const Fr a0 = fe_load(c + i), a1 = fe_load(c + rot(1)), a2 = fe_load(c + rot(2)), a3 = fe_load(c + rot(3));
         const Fr q = fe_load(a.fix[a.fx_sel[j]] + i);

@@ -24,7 +24,8 @@ ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
 class CircuitParamsC(ctypes.Structure):
     _fields_ = [("k", ctypes.c_uint32), ("num_advice", ctypes.c_uint32), ("num_lookup_advice", ctypes.c_uint32),
-                ("num_fixed", ctypes.c_uint32), ("lookup_bits", ctypes.c_uint32)]
+                ("num_fixed", ctypes.c_uint32), ("lookup_bits", ctypes.c_uint32),
+                ("num_idle_gate_columns", ctypes.c_uint32)]
 
 
 class ZkError(RuntimeError):
@@ -83,6 +84,7 @@ def load_library():
                        ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_pk_free": ([vp, ctypes.c_uint64], ctypes.c_int),
         "zk_vk_export": ([vp, ctypes.c_uint64, u64p, u64p, u64p, ctypes.POINTER(ctypes.c_uint32)], ctypes.c_int),
+        "zk_proof_size": ([vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_prove": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.c_char_p, ctypes.c_int,
                       ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_poly_upload_canonical": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
@@ -230,7 +232,8 @@ class Engine:
     def keygen(self, params, fixed_canonical, copies):
         """params: circuit.CircuitParams; fixed_canonical: (n_fix, n, 4) uint64 canonical limbs;
         copies: iterable of ((perm_col, row), (perm_col, row))."""
-        cp = CircuitParamsC(params.degree, params.num_advice, params.num_lookup_advice, params.num_fixed, params.lookup_bits)
+        cp = CircuitParamsC(params.degree, params.num_advice, params.num_lookup_advice, params.num_fixed, params.lookup_bits,
+                            getattr(params, "idle_gate_columns", 0))
         fx = np.ascontiguousarray(fixed_canonical, dtype=np.uint64)
         cps = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], dtype=np.uint32).reshape(-1, 4))
         h = ctypes.c_uint64()
@@ -253,10 +256,16 @@ class Engine:
     def prove(self, pk, advice_polys, seed=bytes(32), transcript=ZK_TRANSCRIPT_BLAKE2B, scheme=ZK_SCHEME_DEFAULT):
         hs = (ctypes.c_uint64 * len(advice_polys))(*[p.h for p in advice_polys])
         ln = ctypes.c_size_t()
-        buf = ctypes.create_string_buffer(1 << 16)
+        self._chk(self.L.zk_proof_size(self.ctx, pk, transcript, scheme, ctypes.byref(ln)), "zk_proof_size")
+        buf = ctypes.create_string_buffer(ln.value)
         self._chk(self.L.zk_prove(self.ctx, pk, hs, len(advice_polys), seed, transcript, scheme, buf, len(buf),
                                   ctypes.byref(ln)), "zk_prove")
         return buf.raw[:ln.value]
+
+    def proof_size(self, pk, transcript=ZK_TRANSCRIPT_BLAKE2B, scheme=ZK_SCHEME_DEFAULT):
+        ln = ctypes.c_size_t()
+        self._chk(self.L.zk_proof_size(self.ctx, pk, transcript, scheme, ctypes.byref(ln)), "zk_proof_size")
+        return ln.value
 
     def sync(self):
         self._chk(self.L.zk_sync(self.ctx), "zk_sync")
