@@ -111,6 +111,34 @@ def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
     return tot or None
 
 
+ALU_PEAK_GADDS = 11.7  # XYZZ mixed additions/s the integer VALU sustains (tools/ubench_alu.hip on MI355X)
+
+
+def alu_roofline(eng, k):
+    """The dominant kernel against the roofline that actually bounds it: one commitment of a uniformly
+    random column (what 11 of the 12 MSMs of a proof are), bucket additions per second."""
+    import numpy as np
+    n = 1 << k
+    rng = np.random.default_rng(0x19)
+    col = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    col[:, 3] &= np.uint64((1 << 60) - 1)  # any value < 2^252 < r is a Montgomery image
+    p = eng.poly(n, col)
+    c, windows = eng.srs_msm_plan()
+    eng.commit(p, 1)
+    eng.timer_reset()
+    reps = 5
+    for _ in range(reps):
+        eng.commit(p, 1)  # ZK_BASIS_LAGRANGE
+    ms, cnt = eng.timer_stats(4)
+    p.free()
+    ms /= max(cnt, 1)
+    adds = n * windows * (1.0 - 2.0 ** -c)  # a signed digit is zero with probability 2^-c
+    achieved = adds / (ms * 1e-3) / 1e9
+    return {"kernel": "msm_accumulate_kernel", "bound": "int-valu", "achieved": achieved, "peak": ALU_PEAK_GADDS,
+            "unit": "G mixed adds/s", "frac": achieved / ALU_PEAK_GADDS, "avg_launch_ms": ms, "window_bits": c,
+            "adds_per_launch": adds}
+
+
 def cpu_baseline(eng):
     """Oracle C restatement (halo2 best_multiexp / best_fft) on the host cores:
     one MSM(2^19) + one NTT(2^19) + one NTT(2^21), scaled to the per-proof operator counts."""
@@ -288,6 +316,7 @@ def main():
                 % (msm_total / max(msm_n, 1), msm_n // max(args.steps, 1), eng.last_ms(2)),
             },
         }
+        out["roofline"]["alu"] = alu_roofline(eng, K)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng)
         print(json.dumps(out))

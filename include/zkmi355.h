@@ -78,6 +78,10 @@ int zk_srs_setup(zk_ctx* ctx, uint32_t k, const uint8_t seed[32]);
 int zk_srs_load(zk_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange);
 int zk_srs_export(zk_ctx* ctx, int basis, uint64_t* out_affine_mont /* n x 8 */, size_t first, size_t count);
 int zk_srs_k(const zk_ctx* ctx); /* -1 if none */
+/* how zk_commit runs over the resident SRS: signed window width and the number of windows (= bucket
+ * additions per scalar; best_multiexp's `c` and `segments`, halo2_proofs arithmetic.rs [RECALLED]).
+ * window_bits == 0: no window-multiple tables (k < 10).  For measurement (bench.py's ALU roofline). */
+int zk_srs_msm_plan(const zk_ctx* ctx, uint32_t* window_bits, uint32_t* windows);
 
 /* ---- resident polynomials -------------------------------------------------- */
 int zk_poly_alloc(zk_ctx* ctx, size_t n, zk_poly* out);

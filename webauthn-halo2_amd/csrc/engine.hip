@@ -527,6 +527,14 @@ int zk_srs_export(zk_ctx* c, int basis, uint64_t* out, size_t first, size_t coun
 
 int zk_srs_k(const zk_ctx* c) { return c ? c->srs_k : -1; }
 
+int zk_srs_msm_plan(const zk_ctx* c, uint32_t* window_bits, uint32_t* windows) {
+    if (!c || !window_bits || !windows) return ZK_EINVAL;
+    if (c->srs_k < 0) return ZK_ESTATE;
+    *window_bits = c->table_c;  // 0: no window-multiple tables (k < 10), zk_commit takes the generic path
+    *windows = c->table_c ? msm_num_windows(c->table_c) : 0;
+    return ZK_OK;
+}
+
 // ---- resident polynomials ----------------------------------------------------
 
 static PolyRec* find_poly(zk_ctx* c, zk_poly h) {

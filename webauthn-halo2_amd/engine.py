@@ -65,6 +65,7 @@ def load_library():
         "zk_srs_load": ([vp, u32, u64p, u64p], ctypes.c_int),
         "zk_srs_export": ([vp, ctypes.c_int, u64p, sz, sz], ctypes.c_int),
         "zk_srs_k": ([vp], ctypes.c_int),
+        "zk_srs_msm_plan": ([vp, ctypes.POINTER(u32), ctypes.POINTER(u32)], ctypes.c_int),
         "zk_poly_alloc": ([vp, sz, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_poly_free": ([vp, ctypes.c_uint64], ctypes.c_int),
         "zk_poly_len": ([vp, ctypes.c_uint64, ctypes.POINTER(sz)], ctypes.c_int),
@@ -173,6 +174,11 @@ class Engine:
         if g.shape[0] != (1 << k) or gl.shape[0] != (1 << k):
             raise ValueError("SRS arrays must hold 2^k points")
         self._chk(self.L.zk_srs_load(self.ctx, k, _p(g), _p(gl)), "zk_srs_load")
+
+    def srs_msm_plan(self):
+        c, w = ctypes.c_uint32(), ctypes.c_uint32()
+        self._chk(self.L.zk_srs_msm_plan(self.ctx, ctypes.byref(c), ctypes.byref(w)), "zk_srs_msm_plan")
+        return c.value, w.value
 
     def srs_export(self, basis, first, count):
         out = np.zeros((count, 8), dtype=np.uint64)
