@@ -227,6 +227,50 @@ __host__ __device__ __forceinline__ Fe<PRM> fe_mul_portable(const Fe<PRM>& a, co
     return r;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host (x86-64) form: the same CIOS on 4 x 64-bit limbs with 128-bit products — the transcript-side
+// arithmetic (window Horner, to_affine, Lagrange interpolation) sits between GPU phases of a proof.
+template <class PRM>
+inline Fe<PRM> fe_mul_host64(const Fe<PRM>& a, const Fe<PRM>& b) {
+    typedef unsigned __int128 u128;
+    uint64_t A[4], B[4], P[4], t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+        P[i] = (uint64_t)PRM::P[2 * i] | ((uint64_t)PRM::P[2 * i + 1] << 32);
+    }
+    // -p^-1 mod 2^64 from the 32-bit constant: one Newton step
+    const uint64_t inv32 = PRM::INV;
+    const uint64_t inv64 = inv32 * (2 + P[0] * inv32);
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)A[j] * B[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        const uint64_t t4 = t[4] + (uint64_t)c;
+        const uint64_t m = t[0] * inv64;
+        c = ((u128)m * P[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t4;
+        t[3] = (uint64_t)c;
+        t[4] = (uint64_t)(c >> 64);
+    }
+    Fe<PRM> r;
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)t[i];
+        r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    reduce_once(r);
+    return r;
+}
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // gfx950 form: product-scanning (FIPS) Montgomery.  Column k of a*b + m*p is summed in a
 // 96-bit accumulator (lo: 64-bit VGPR pair, hi: carry count).  One product = v_mad_u64_u32
@@ -356,7 +400,7 @@ __host__ __device__ __forceinline__ Fe<PRM> fe_mul(const Fe<PRM>& a, const Fe<PR
 #if defined(__HIP_DEVICE_COMPILE__)
     return fe_mul_gfx950(a, b);
 #else
-    return fe_mul_portable(a, b);
+    return fe_mul_host64(a, b);
 #endif
 }
 

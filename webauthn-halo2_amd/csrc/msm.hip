@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
     bool active = false;
     uint32_t b = 0, p = 0;
     if (gid < ngroups) {
-        b = gid / parts;
-        p = gid - b * parts;
+        // part-major: the groups of part 0 (the only one most buckets use) are adjacent, so their waves are
+        // full and the waves of the unused parts exit at once
+        const uint32_t nbk = ngroups / parts;
+        p = gid / nbk;
+        b = gid - p * nbk;
         const uint32_t s0 = bucket_start[b] / PAD, s1 = bucket_start[b + 1] / PAD;
         const uint32_t len = s1 - s0;
         const uint32_t used = min(parts, (len + 4 * LANES - 1) / (4 * LANES));
@@ -348,16 +351,20 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
 // grid = slices * c * BITSUM_SPLIT workgroups, each covering a quarter of the buckets;
 // the host adds the BITSUM_SPLIT partials and runs the c-term Horner.
 static constexpr uint32_t BITSUM_SPLIT = 4;
-__global__ __launch_bounds__(256) void msm_bitsum_kernel(const G1X* __restrict__ part, uint32_t parts, uint32_t nb,
-                                                         uint32_t c, G1X* __restrict__ out) {
-    __shared__ G1X sh[4];
+static constexpr uint32_t BITSUM_THREADS = 512;
+__global__ __launch_bounds__(BITSUM_THREADS) void msm_bitsum_kernel(const G1X* __restrict__ part, uint32_t parts, uint32_t nb,
+                                                                    uint32_t c, G1X* __restrict__ out) {
+    __shared__ G1X sh[BITSUM_THREADS / 64];
     const uint32_t q = blockIdx.x % BITSUM_SPLIT;
     const uint32_t st = blockIdx.x / BITSUM_SPLIT;
     const uint32_t slice = st / c, t = st - slice * c;
     G1X acc = G1X::identity();
+    // the multipliers j in [1, nb] with bit t set, enumerated densely (no lane idles on a clear bit):
+    // t < c-1: j = i with a 1 inserted at bit t, i < nb/2;  t = c-1: j = nb only
+    const uint32_t items = t + 1 < c ? nb >> 1 : 1;
 #pragma unroll 1
-    for (uint32_t j = q * 256 + threadIdx.x + 1; j <= nb; j += 256 * BITSUM_SPLIT) {
-        if (!((j >> t) & 1)) continue;
+    for (uint32_t i = q * BITSUM_THREADS + threadIdx.x; i < items; i += BITSUM_THREADS * BITSUM_SPLIT) {
+        const uint32_t j = t + 1 < c ? (((i >> t) << (t + 1)) | (1u << t) | (i & ((1u << t) - 1))) : nb;
         const G1X* src = part + ((size_t)slice * nb + (j - 1)) * parts;
 #pragma unroll 1
         for (uint32_t k = 0; k < parts; k++) {
@@ -370,8 +377,8 @@ __global__ __launch_bounds__(256) void msm_bitsum_kernel(const G1X* __restrict__
     if ((threadIdx.x & 63) == 0) g1x_store(sh + wave, acc);
     __syncthreads();
     if (wave == 0) {
-        acc = (threadIdx.x < 4) ? g1x_load(sh + threadIdx.x) : G1X::identity();
-        group_sum(acc, 4);
+        acc = (threadIdx.x < BITSUM_THREADS / 64) ? g1x_load(sh + threadIdx.x) : G1X::identity();
+        group_sum(acc, BITSUM_THREADS / 64);
         if (threadIdx.x == 0) g1x_store(out + blockIdx.x, acc);
     }
 }
@@ -535,7 +542,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
             hipLaunchKernelGGL(msm_gather_kernel<4>, dim3((ngroups * 4 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
                                ws->partial, parts, ngroups, ws->part);
     }
-    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(256), 0, ts, ws->part, parts, nb, c,
+    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(BITSUM_THREADS), 0, ts, ws->part, parts, nb, c,
                        ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * BITSUM_SPLIT * sizeof(G1X),

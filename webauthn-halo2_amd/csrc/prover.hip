@@ -14,6 +14,8 @@
 // the handful of blinding rows and on the device for the n-coefficient random
 // polynomial — the engine's kernels themselves consume no randomness.
 #include <algorithm>
+#include <deque>
+#include <vector>
 
 #include "ctx.h"
 #include "prover.h"
@@ -95,7 +97,8 @@ struct zk_pk_rec {
         lk_in_coset;
     Fr *random_poly = nullptr, *h_ext = nullptr, *h_comb = nullptr;
     Fr *t_num = nullptr, *t_den = nullptr, *t_frac = nullptr, *t_a = nullptr, *t_b = nullptr, *t_small = nullptr;
-    Fr* tail_host = nullptr;  // pinned staging for blinding rows / scalars
+    Fr* tail_host = nullptr;  // pinned staging for evaluations / scalars
+    Fr* rows_host = nullptr;  // pinned ring for blinding rows (Prover::set_rows)
     LookupScratch lks{};
     uint32_t* lk_u32 = nullptr;
     QuotientArgs* d_qargs = nullptr;
@@ -202,6 +205,7 @@ void pk_destroy(zk_pk_rec* pk) {
     if (!pk) return;
     for (Fr* p : pk->dev) hipFree(p);
     if (pk->tail_host) hipHostFree(pk->tail_host);
+    if (pk->rows_host) hipHostFree(pk->rows_host);
     if (pk->lk_u32) hipFree(pk->lk_u32);
     if (pk->d_qargs) hipFree(pk->d_qargs);
     if (pk->d_evargs) hipFree(pk->d_evargs);
@@ -407,6 +411,7 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->t_small = d.alloc(n / 16 + 8192);
     if (d.rc) return fail(d.rc);
     if (hipHostMalloc(&pk->tail_host, (pk->max_evals + 16) * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->rows_host, 64 * 8 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
     if (hipHostMalloc(&pk->h_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess ||
         hipMalloc(&pk->d_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess)
         return fail(ZK_ENOMEM);
@@ -477,6 +482,8 @@ struct Prover {
     const Fr *tw, *tw_ext;
     Fr omega, omega_inv;
     int rc = ZK_OK;
+    static constexpr uint32_t ROWS_RING = 64, ROWS_SLOT = 8;  // slots of BLINDING_FACTORS + 1 elements
+    uint32_t rows_slot = 0;
 
     Prover(zk_ctx* c_, zk_pk_rec* pk_, const uint8_t seed[32], Transcript* t)
         : c(c_), pk(pk_), lay(pk_->lay), st(c_->stream), rng(seed), tr(t), n(pk_->lay.n), N(4 * pk_->lay.n) {}
@@ -487,11 +494,42 @@ struct Prover {
     }
 
     // ---- device helpers
+    // blinding rows: staged through a ring of pinned slots so the host does not wait for the stream
+    // (it only does when the ring wraps)
     void set_rows(Fr* col, uint32_t first, const std::vector<Fr>& vals) {
-        memcpy(pk->tail_host, vals.data(), vals.size() * sizeof(Fr));
-        if (hipMemcpyAsync(col + first, pk->tail_host, vals.size() * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess)
-            fail(ZK_EHIP);
+        if (!ok()) return;
+        if (vals.size() > ROWS_SLOT) return fail(ZK_ESTATE);
+        if (rows_slot == ROWS_RING) {
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(ZK_EHIP);
+            rows_slot = 0;
+        }
+        Fr* slot = pk->rows_host + (size_t)rows_slot++ * ROWS_SLOT;
+        memcpy(slot, vals.data(), vals.size() * sizeof(Fr));
+        if (hipMemcpyAsync(col + first, slot, vals.size() * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) fail(ZK_EHIP);
+    }
+    // commitments in flight over a set of MSM lanes, collected (written to the transcript) in the
+    // order they were begun
+    struct LaneFifo {
+        std::vector<int> lanes;
+        std::deque<int> busy;
+    };
+    void fifo_begin(LaneFifo& f, const Fr* poly, size_t len, int basis) {
+        if (!ok()) return;
+        if (f.busy.size() == f.lanes.size()) {
+            commit_end_write(f.busy.front());
+            f.busy.pop_front();
+        }
+        int lane = -1;
+        for (int l : f.lanes)
+            if (std::find(f.busy.begin(), f.busy.end(), l) == f.busy.end()) lane = l;
+        commit_begin(lane, poly, len, basis);
+        f.busy.push_back(lane);
+    }
+    void fifo_drain(LaneFifo& f) {
+        while (!f.busy.empty()) {
+            commit_end_write(f.busy.front());
+            f.busy.pop_front();
+        }
     }
     std::vector<Fr> draw(uint32_t count) {
         std::vector<Fr> v(count);
@@ -596,16 +634,22 @@ struct Prover {
         draw(lay.n_adv);  // advice blinds (unused by KZG, still drawn)
         // few advice columns (k=19: one): pipeline them with the lookup commitments; many: plain order
         const bool pipe = lay.n_adv == 1 && lay.n_lookups == 1;
+        // The coefficient and extended-coset forms the quotient needs are produced right behind each
+        // commitment's head: they need no challenge, and they keep the main stream busy while the MSM tails
+        // (and the host's transcript work) would otherwise leave it idle.
         if (pipe) {
             commit_begin(0, pk->adv_val[0], n, ZK_BASIS_LAGRANGE);
+            to_coeff(pk->adv_val[0], pk->adv_poly[0]);
+            to_coset(pk->adv_poly[0], pk->adv_coset[0]);
         } else {
             // several advice columns: keep MSM_LANES commitments in flight, collect in column order
-            const uint32_t LN = (uint32_t)zk_ctx::MSM_LANES;
+            LaneFifo f{{0, 1, 2}, {}};
             for (uint32_t j = 0; j < lay.n_adv && ok(); j++) {
-                if (j >= LN) commit_end_write((int)(j % LN));
-                commit_begin((int)(j % LN), pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+                fifo_begin(f, pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
+                to_coeff(pk->adv_val[j], pk->adv_poly[j]);
+                to_coset(pk->adv_poly[j], pk->adv_coset[j]);
             }
-            for (uint32_t j = (lay.n_adv > LN ? lay.n_adv - LN : 0); j < lay.n_adv && ok(); j++) commit_end_write((int)(j % LN));
+            fifo_drain(f);
         }
         if (!ok()) return rc;
 
@@ -646,6 +690,10 @@ struct Prover {
             draw(2);
             commit_begin(1, pk->lk_ap[l], n, ZK_BASIS_LAGRANGE);
             commit_begin(2, pk->lk_sp[l], n, ZK_BASIS_LAGRANGE);
+            to_coeff(pk->lk_ap[l], pk->lk_ap_poly[l]);
+            to_coset(pk->lk_ap_poly[l], pk->lk_ap_coset[l]);
+            to_coeff(pk->lk_sp[l], pk->lk_sp_poly[l]);
+            to_coset(pk->lk_sp_poly[l], pk->lk_sp_coset[l]);
             squeeze_theta();
             commit_end_write(1);
             commit_end_write(2);
@@ -666,7 +714,8 @@ struct Prover {
             commit_begin(0, pk->random_poly, n, ZK_BASIS_MONOMIAL);
         }
 
-        // -- 3. permutation grand products
+        // -- 3. permutation grand products (lanes 1 and 2: a chunk's tail overlaps the next chunk's kernels)
+        LaneFifo zf{{1, 2}, {}};
         {
             const Fr delta = fr_delta();
             Fr dcur = Fr::one();
@@ -694,14 +743,10 @@ struct Prover {
                 launch_prefix_product(pk->t_frac, pk->z_val[ci], n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
                 set_rows(pk->z_val[ci], n - bf, draw(bf));
                 draw(1);
-                // lanes 1 and 2 alternate; the previous chunk's tail overlaps this chunk's kernels
-                const int lane = 1 + (int)(ci & 1);
-                if (ci >= 2) commit_end_write(lane);
-                commit_begin(lane, pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
+                fifo_begin(zf, pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
+                to_coeff(pk->z_val[ci], pk->z_poly[ci]);
+                to_coset(pk->z_poly[ci], pk->z_coset[ci]);
             }
-            // collect in order
-            if (lay.n_chunks >= 2) commit_end_write(1 + (int)(lay.n_chunks & 1));
-            commit_end_write(1 + (int)((lay.n_chunks - 1) & 1));
         }
         // -- 4. lookup grand products
         for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
@@ -711,8 +756,11 @@ struct Prover {
             launch_prefix_product(pk->t_frac, pk->lk_z[l], n, nullptr, Fr::one(), pk->t_a, pk->t_small, st);
             set_rows(pk->lk_z[l], n - bf, draw(bf));
             draw(1);
-            commit_write_lane(1, pk->lk_z[l], n, ZK_BASIS_LAGRANGE);
+            fifo_begin(zf, pk->lk_z[l], n, ZK_BASIS_LAGRANGE);
+            to_coeff(pk->lk_z[l], pk->lk_z_poly[l]);
+            to_coset(pk->lk_z_poly[l], pk->lk_z_coset[l]);
         }
+        fifo_drain(zf);
         if (!ok()) return rc;
 
         // -- 5. collect the random polynomial's commitment (its draws happen here in stream order)
@@ -722,23 +770,7 @@ struct Prover {
         if (!ok()) return rc;
         const Fr y = tr->squeeze();
 
-        // -- 6. quotient
-        for (uint32_t j = 0; j < lay.n_adv && ok(); j++) {
-            to_coeff(pk->adv_val[j], pk->adv_poly[j]);
-            to_coset(pk->adv_poly[j], pk->adv_coset[j]);
-        }
-        for (uint32_t ci = 0; ci < lay.n_chunks && ok(); ci++) {
-            to_coeff(pk->z_val[ci], pk->z_poly[ci]);
-            to_coset(pk->z_poly[ci], pk->z_coset[ci]);
-        }
-        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
-            to_coeff(pk->lk_ap[l], pk->lk_ap_poly[l]);
-            to_coset(pk->lk_ap_poly[l], pk->lk_ap_coset[l]);
-            to_coeff(pk->lk_sp[l], pk->lk_sp_poly[l]);
-            to_coset(pk->lk_sp_poly[l], pk->lk_sp_coset[l]);
-            to_coeff(pk->lk_z[l], pk->lk_z_poly[l]);
-            to_coset(pk->lk_z_poly[l], pk->lk_z_coset[l]);
-        }
+        // -- 6. quotient (every coefficient / coset form was produced behind its commitment above)
         if (!ok()) return rc;
         {
             QuotientArgs q;
