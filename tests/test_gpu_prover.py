@@ -74,6 +74,22 @@ def test_proofs_byte_identical_to_oracle(engine, name):
     engine.pk_free(pk)
 
 
+def test_batch_inversion_fallback_same_bytes(engine, monkeypatch):
+    """The grand products normally use one inversion per product (prefix x suffix scans); a zero
+    denominator sends them down the batch-inversion path.  Both must give the same proof."""
+    A, L, F, k, lb = SHAPES["k17like"]
+    _, asg, pk, polys = setup(engine, A, L, F, k, lb)
+    seed = b"\x21" * 32
+    a = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
+    monkeypatch.setenv("ZKMI355_BATCH_INVERT", "1")
+    b = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
+    monkeypatch.delenv("ZKMI355_BATCH_INVERT")
+    assert a == b
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
+
+
 def test_worst_case_witness_and_second_seed(engine):
     A, L, F, k, lb = SHAPES["k17like"]
     p, asg, pk, polys = setup(engine, A, L, F, k, lb, seed=0x5EED0019 + 3, worst=True)

@@ -42,8 +42,14 @@ namespace zk {
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
-static constexpr uint32_t SEG0 = 16;      // entries per accumulate lane
-static constexpr uint32_t GA = 8;         // slots per first-level gather lane
+#ifndef ZK_SEG0  // build-time tuning knobs (tools/ab_variants.sh)
+#define ZK_SEG0 16
+#endif
+#ifndef ZK_GA
+#define ZK_GA 8
+#endif
+static constexpr uint32_t SEG0 = ZK_SEG0;  // entries per accumulate lane
+static constexpr uint32_t GA = ZK_GA;      // slots per first-level gather lane
 static constexpr uint32_t PAD = SEG0 * GA;  // bucket ranges are padded to multiples of PAD entries
 
 struct MsmWorkspace {

@@ -83,6 +83,8 @@ void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, 
 void launch_frac(const Fr* num, const Fr* den, Fr* frac, uint32_t n, hipStream_t st);
 void launch_prefix_product(const Fr* f, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_local,
                            Fr* tmp_tot, hipStream_t st);
+int launch_grand_product(const Fr* num, const Fr* den, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_p,
+                         Fr* tmp_r, Fr* tmp_tot, Fr* host_q, hipStream_t st);
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st);
 void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
 

@@ -13,6 +13,8 @@
 // ChaCha20Rng layout): one 64-byte block per Fr::random, drawn on the host for
 // the handful of blinding rows and on the device for the n-coefficient random
 // polynomial — the engine's kernels themselves consume no randomness.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <deque>
 #include <vector>
@@ -555,6 +557,21 @@ struct Prover {
         if (r) return fail(r);
         if (!tr->write_point(g1_jac_to_affine_host(j))) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
     }
+    // z[0] = init, z[i+1] = z[i] * t_num[i] / t_den[i]
+    void grand_product(Fr* z, const Fr* init_dev) {
+        if (!ok()) return;
+        // ZKMI355_BATCH_INVERT=1 forces the fallback path (tests keep it covered)
+        const char* force = getenv("ZKMI355_BATCH_INVERT");
+        const int r = force && force[0] == '1'
+                          ? 1
+                          : launch_grand_product(pk->t_num, pk->t_den, z, n, init_dev, Fr::one(), pk->t_frac, pk->t_a,
+                                                 pk->t_small, c->host_small, st);
+        if (r < 0) return fail(ZK_EHIP);
+        if (r == 1) {  // a zero denominator: halo2's batch_invert semantics (0 -> 0)
+            launch_frac(pk->t_num, pk->t_den, pk->t_frac, n, st);
+            launch_prefix_product(pk->t_frac, z, n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
+        }
+    }
     void to_coeff(const Fr* val, Fr* poly) {
         if (!ok()) return;
         hipMemcpyAsync(poly, val, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
@@ -737,10 +754,9 @@ struct Prover {
                 a.num = pk->t_num;
                 a.den = pk->t_den;
                 launch_perm_numden(a, st);
-                launch_frac(pk->t_num, pk->t_den, pk->t_frac, n, st);
                 // z[0] = previous chunk's z at row `usable` (or 1)
                 const Fr* init_dev = ci ? pk->z_val[ci - 1] + usable : nullptr;
-                launch_prefix_product(pk->t_frac, pk->z_val[ci], n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
+                grand_product(pk->z_val[ci], init_dev);
                 set_rows(pk->z_val[ci], n - bf, draw(bf));
                 draw(1);
                 fifo_begin(zf, pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
@@ -752,8 +768,7 @@ struct Prover {
         for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
             const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
             launch_lk_numden(pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], beta, gamma, pk->t_num, pk->t_den, n, st);
-            launch_frac(pk->t_num, pk->t_den, pk->t_frac, n, st);
-            launch_prefix_product(pk->t_frac, pk->lk_z[l], n, nullptr, Fr::one(), pk->t_a, pk->t_small, st);
+            grand_product(pk->lk_z[l], nullptr);
             set_rows(pk->lk_z[l], n - bf, draw(bf));
             draw(1);
             fifo_begin(zf, pk->lk_z[l], n, ZK_BASIS_LAGRANGE);

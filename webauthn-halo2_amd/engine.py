@@ -36,7 +36,8 @@ class ZkError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libzkmi355.so")
+    # ZKMI355_LIB: an alternative build of the same library (A/B tuning variants, tools/ab_variants.sh)
+    return os.environ.get("ZKMI355_LIB") or os.path.join(_HERE, "libzkmi355.so")
 
 
 def load_library():
