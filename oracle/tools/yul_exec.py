@@ -288,9 +288,33 @@ def runtime_block(yul_text):
     return Parser(toks).block()
 
 
-def run_verifier(yul_path, proof: bytes):
+def with_vk(yul_text, transcript_repr, commitments):
+    """The same generated program with another circuit's verifying key: replaces, in memory, the
+    transcript_repr literal and the 12 vk commitment literals (the 24 `mstore(addr, 0x<64 hex>)` after
+    the generator (1, 2) and before the 8 G2 words) by the given ones.  Shape-dependent code is untouched,
+    so the key must be of the shape the program was generated for (k=17, 4/1/1 columns)."""
+    import re
+    lit = list(re.finditer(r"mstore\(0x[0-9a-f]+, 0x([0-9a-f]{64})\)", yul_text))
+    assert len(lit) == 2 + 24 + 8 and len(commitments) == 12
+    flat = [c for pt in commitments for c in pt]
+    out, last = [], 0
+    for m, v in zip(lit[2:26], flat):
+        out.append(yul_text[last:m.start(1)])
+        out.append("%064x" % v)
+        last = m.end(1)
+    out.append(yul_text[last:])
+    text = "".join(out)
+    text, cnt = re.subn(r"mstore\(0x0, \d+\)", "mstore(0x0, %d)" % transcript_repr, text, count=1)
+    assert cnt == 1
+    return text
+
+
+def run_verifier(yul_path, proof: bytes, vk=None):
     vm = VM(proof)
-    blk = runtime_block(open(yul_path).read())
+    text = open(yul_path).read()
+    if vk is not None:
+        text = with_vk(text, vk[0], vk[1])
+    blk = runtime_block(text)
     try:
         vm.run(blk)
     except Halt as h:

@@ -69,3 +69,42 @@ def test_reference_yul_verifier_agrees():
     bad = bytearray(proof)
     bad[777] ^= 0x10
     assert yul_exec.run_verifier("/root/reference/proving-server/P256Verifier.yul", bytes(bad))[0] == plonk.verify(vk, bytes(bad), "evm") == False  # noqa: E712
+
+
+def load_engine_fixture():
+    d = json.load(open(os.path.join(GOLD, "engine_proof_k17_evm.json")))
+    shape = plonk.Shape(d["k"], d["num_advice"], d["num_lookup_advice"], d["num_fixed"], d["lookup_bits"])
+    pt = lambda p: (int(p[0], 16), int(p[1], 16))
+    vk = plonk.VerifyingKey(shape, [pt(p) for p in d["fixed_commitments"]],
+                            [pt(p) for p in d["permutation_commitments"]], int(d["transcript_repr"], 16))
+    return vk, bytes.fromhex(d["proof"])
+
+
+def test_engine_proof_fixture_verifies():
+    """A proof the device prover made on an MI355X for the k=17 bench shape
+    (tests/golden/make_engine_fixture.py) is accepted by the golden-proof-pinned verifier."""
+    vk, proof = load_engine_fixture()
+    assert len(proof) == 2720
+    assert plonk.verify(vk, proof, "evm")
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/proving-server/P256Verifier.yul"),
+                    reason="reference tree not present (GPU box)")
+def test_reference_yul_verifier_accepts_engine_proof():
+    """BASELINE config 3: the reference's GENERATED verifier program (proving-server/P256Verifier.yul,
+    executed where it lies) accepts the device prover's EVM proof bytes unchanged.  The program is
+    vk-specific, so the synthetic circuit's 12 vk commitments and transcript_repr replace the ECDSA
+    circuit's literals in memory; every instruction of the verification logic is the reference's."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "tools"))
+    import yul_exec
+    vk, proof = load_engine_fixture()
+    key = (vk.transcript_repr, list(vk.fixed_commitments) + list(vk.permutation_commitments))
+    yul = "/root/reference/proving-server/P256Verifier.yul"
+    ok, vm = yul_exec.run_verifier(yul, proof, vk=key)
+    assert ok and vm.precompile_calls == {5: 1, 6: 38, 7: 39, 8: 1}
+    # the unmodified program (ECDSA circuit's key) must reject it, and a flipped bit must be rejected with our key
+    assert not yul_exec.run_verifier(yul, proof)[0]
+    bad = bytearray(proof)
+    bad[1500] ^= 1
+    assert not yul_exec.run_verifier(yul, bytes(bad), vk=key)[0]
