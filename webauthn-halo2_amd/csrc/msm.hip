@@ -24,7 +24,7 @@
 //   5. msm_accumulate    bucket ranges are padded to multiples of 16 entries; every lane sums one
 //                        aligned 16-entry segment with XYZZ mixed adds (8M + 2S) -> one partial
 //                        sum ("slot") per lane, all lanes of a launch do the same amount of work
-//   6. msm_gather1/2     two-level sum of each bucket's slots: dense lanes add 8 slots serially, then
+//   6. msm_gather1/2     two-level sum of each bucket's slots: dense lanes add 4 slots serially, then
 //                        16-lane groups finish each bucket with a shuffle tree (tail stream)
 //   7. msm_bitsum        sum_j j B_j = sum_t 2^t G_t, G_t = sum of buckets with bit t of j set:
 //                        c tree reductions per bucket set; the short Horner is done on the host
@@ -42,11 +42,12 @@ namespace zk {
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
+static constexpr uint32_t SORT_LDS_BUCKETS = 8192;  // 32 KiB of LDS counters per sort workgroup
 #ifndef ZK_SEG0  // build-time tuning knobs (tools/ab_variants.sh)
 #define ZK_SEG0 16
 #endif
 #ifndef ZK_GA
-#define ZK_GA 8
+#define ZK_GA 4
 #endif
 static constexpr uint32_t SEG0 = ZK_SEG0;  // entries per accumulate lane
 static constexpr uint32_t GA = ZK_GA;      // slots per first-level gather lane
@@ -75,7 +76,7 @@ uint32_t msm_auto_window(size_t n) {
     int c = lg >= 19 ? (int)lg - 6 : (lg >= 16 ? 12 : (int)lg - 5);
     if (const char* e = getenv("ZKMI355_MSM_WINDOW")) c = atoi(e);  // tuning override
     if (c < 9) c = 9;
-    if (c > 14) c = 14;  // 2^(c-1) u32 counters must fit the LDS histogram
+    if (c > 15) c = 15;  // digits are int16
     return (uint32_t)c;
 }
 
@@ -127,34 +128,41 @@ __global__ __launch_bounds__(256) void msm_sort_kernel(const int16_t* __restrict
                                                        uint32_t table_stride, uint32_t* __restrict__ totals,
                                                        const uint32_t* __restrict__ bucket_start,
                                                        uint32_t* __restrict__ blockbase, uint32_t* __restrict__ entries) {
-    extern __shared__ uint32_t lds[];  // nb counters / cursors
+    extern __shared__ uint32_t lds[];  // min(nb, SORT_LDS_BUCKETS) counters / cursors
     const uint32_t blk = blockIdx.x;
     const uint32_t w = blk / nchunks, chunk = blk - w * nchunks;
     const uint32_t slice = fixed ? 0 : w;
     const uint32_t lo = chunk * CHUNK, hi = min(n, lo + CHUNK);
     const int16_t* dg = digits + (size_t)w * stride;
-    if (!SCATTER) {
-        for (uint32_t b = threadIdx.x; b < nb; b += 256) lds[b] = 0;
-    } else {
-        for (uint32_t b = threadIdx.x; b < nb; b += 256)
-            lds[b] = bucket_start[slice * nb + b] + blockbase[(size_t)blk * nb + b];
-    }
-    __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const int32_t d = dg[i];
-        if (d == 0) continue;
-        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        const uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
-        if (SCATTER) {
-            const uint32_t idx = (fixed ? w * table_stride : 0) + i;
-            entries[pos] = idx | (d < 0 ? SIGN_BIT : 0);
+    // bucket sets beyond the LDS budget (c = 15) are handled in several sweeps over the chunk's digits
+    const uint32_t span = min(nb, SORT_LDS_BUCKETS);
+    for (uint32_t b0 = 0; b0 < nb; b0 += span) {
+        if (!SCATTER) {
+            for (uint32_t b = threadIdx.x; b < span; b += 256) lds[b] = 0;
+        } else {
+            for (uint32_t b = threadIdx.x; b < span; b += 256)
+                lds[b] = bucket_start[slice * nb + b0 + b] + blockbase[(size_t)blk * nb + b0 + b];
         }
-    }
-    if (!SCATTER) {
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nb; b += 256) {
-            const uint32_t cnt = lds[b];
-            blockbase[(size_t)blk * nb + b] = cnt ? atomicAdd(&totals[slice * nb + b], cnt) : 0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const int32_t d = dg[i];
+            if (d == 0) continue;
+            const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            const uint32_t rel = mag - 1 - b0;
+            if (rel >= span) continue;
+            const uint32_t pos = atomicAdd(&lds[rel], 1u);
+            if (SCATTER) {
+                const uint32_t idx = (fixed ? w * table_stride : 0) + i;
+                entries[pos] = idx | (d < 0 ? SIGN_BIT : 0);
+            }
+        }
+        __syncthreads();
+        if (!SCATTER) {
+            for (uint32_t b = threadIdx.x; b < span; b += 256) {
+                const uint32_t cnt = lds[b];
+                blockbase[(size_t)blk * nb + b0 + b] = cnt ? atomicAdd(&totals[slice * nb + b0 + b], cnt) : 0;
+            }
+            __syncthreads();
         }
     }
 }
@@ -442,7 +450,7 @@ hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affi
 MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     if (err) *err = hipSuccess;
     if (c == 0) c = msm_auto_window(max_n);
-    if (c < 9 || c > 14 || max_n == 0 || max_n > ((size_t)1 << 26)) {
+    if (c < 9 || c > 15 || max_n == 0 || max_n > ((size_t)1 << 26)) {
         if (err) *err = hipErrorInvalidValue;
         return nullptr;
     }
@@ -513,11 +521,11 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
         const uint32_t nchunks = (n32 + CHUNK - 1) / CHUNK;
         hipLaunchKernelGGL(msm_recode_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, scalars, n32, stride, c, nwin,
                            ws->digits);
-        hipLaunchKernelGGL(msm_sort_kernel<false>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
+        hipLaunchKernelGGL(msm_sort_kernel<false>, dim3(nchunks * nwin), dim3(256), (nb < SORT_LDS_BUCKETS ? nb : SORT_LDS_BUCKETS) * 4, st, ws->digits, n32, stride,
                            nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
                            (uint32_t*)nullptr);
         hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
-        hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), nb * 4, st, ws->digits, n32, stride,
+        hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), (nb < SORT_LDS_BUCKETS ? nb : SORT_LDS_BUCKETS) * 4, st, ws->digits, n32, stride,
                            nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
                            ws->entries);
         hipLaunchKernelGGL(msm_pad_kernel, dim3((nbt + 255) / 256), dim3(256), 0, st, ws->totals, ws->bucket_start, nbt,
