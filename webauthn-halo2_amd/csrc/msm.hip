@@ -167,6 +167,88 @@ __global__ __launch_bounds__(256) void msm_sort_kernel(const int16_t* __restrict
     }
 }
 
+// ---- fixed-base mode: every window feeds ONE bucket set, so a workgroup owns a chunk of scalars with
+// ALL their windows: digit extraction and the LDS histogram are one kernel, and the scatter re-reads the
+// digits it wrote (5 launches per MSM head instead of 10).
+static constexpr uint32_t FCHUNK = 1024;  // scalars per workgroup (x nwin entries)
+
+__device__ __forceinline__ uint32_t msm_digits_of(const uint32_t* L, uint32_t c, uint32_t nwin, uint32_t i, uint32_t stride,
+                                                  int16_t* __restrict__ digits, uint32_t* hist) {
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < nwin; w++) {
+        const uint32_t bit = w * c, word = bit >> 5, off = bit & 31;
+        uint32_t raw = 0;
+        if (word < 8) {
+            const uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
+            raw = (uint32_t)(two >> off) & mask;
+        }
+        raw += carry;
+        int32_t d;
+        if (raw > half) {
+            d = (int32_t)raw - (int32_t)(1u << c);
+            carry = 1;
+        } else {
+            d = (int32_t)raw;
+            carry = 0;
+        }
+        digits[(size_t)w * stride + i] = (int16_t)d;
+        if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+    }
+    return carry;
+}
+
+__global__ __launch_bounds__(256) void msm_recode_hist_kernel(const Fr* __restrict__ scalars, uint32_t n, uint32_t stride,
+                                                              uint32_t c, uint32_t nwin, uint32_t nb,
+                                                              int16_t* __restrict__ digits, uint32_t* __restrict__ totals,
+                                                              uint32_t* __restrict__ blockbase) {
+    extern __shared__ uint32_t lds[];  // nb counters, then 256 x 9 limbs
+    uint32_t* hist = lds;
+    uint32_t* L = lds + nb + threadIdx.x * 9;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const Fr s = fe_from_mont(fe_load(scalars + i));
+#pragma unroll
+        for (int k = 0; k < 8; k++) L[k] = s.v[k];
+        L[8] = 0;
+        msm_digits_of(L, c, nwin, i, stride, digits, hist);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const uint32_t cnt = hist[b];
+        blockbase[(size_t)blockIdx.x * nb + b] = cnt ? atomicAdd(&totals[b], cnt) : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void msm_scatter_fixed_kernel(const int16_t* __restrict__ digits, uint32_t n, uint32_t stride,
+                                                                uint32_t nwin, uint32_t nb, uint32_t table_stride,
+                                                                const uint32_t* __restrict__ totals,
+                                                                const uint32_t* __restrict__ bucket_start,
+                                                                const uint32_t* __restrict__ blockbase,
+                                                                uint32_t* __restrict__ entries) {
+    extern __shared__ uint32_t lds[];  // nb cursors
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) lds[b] = bucket_start[b] + blockbase[(size_t)blockIdx.x * nb + b];
+    // this workgroup's share of the bucket padding (skip markers up to the next multiple of PAD)
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
+        const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
+        for (uint32_t q = beg; q < end; q++) entries[q] = SKIP_ENTRY;
+    }
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    for (uint32_t w = 0; w < nwin; w++) {
+        const int16_t* dg = digits + (size_t)w * stride;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const int32_t d = dg[i];
+            if (d == 0) continue;
+            const uint32_t pos = atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
+            entries[pos] = (w * table_stride + i) | (d < 0 ? SIGN_BIT : 0);
+        }
+    }
+}
+
 // exclusive scan of the bucket sizes, each rounded up to a multiple of PAD (so that neither an
 // accumulate lane nor a first-level gather lane straddles two buckets): out[0..m], out[m] = padded total = counts[0]
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
@@ -230,9 +312,13 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __re
     g1x_store(slot_pt + t, acc);
 }
 
-__global__ void msm_clear_kernel(G1X* __restrict__ p, uint32_t m) {
+// start-of-MSM reset in one launch: bucket parts = identity, bucket totals = 0, counts = 0
+__global__ void msm_clear_kernel(G1X* __restrict__ p, uint32_t m, uint32_t* __restrict__ totals, uint32_t nt,
+                                 uint32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) g1x_store(p + i, G1X::identity());
+    if (i < nt) totals[i] = 0;
+    if (i < 4) counts[i] = 0;
 }
 
 // ---- "cold" group arithmetic for the low-parallelism reduction kernels: the field
@@ -471,7 +557,10 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err) {
     MSM_TRY(hipMalloc(&ws->digits, max_n * ws->nwin * sizeof(int16_t)));
     MSM_TRY(hipMalloc(&ws->totals, (nbt + 1) * 4));
     MSM_TRY(hipMalloc(&ws->bucket_start, (nbt + 1) * 4));
-    MSM_TRY(hipMalloc(&ws->blockbase, nchunks * ws->nwin * ws->nb * 4));
+    {
+        const size_t generic_blocks = nchunks * ws->nwin, fixed_blocks = (max_n + FCHUNK - 1) / FCHUNK;
+        MSM_TRY(hipMalloc(&ws->blockbase, (generic_blocks > fixed_blocks ? generic_blocks : fixed_blocks) * ws->nb * 4));
+    }
     MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
     MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint32_t)));
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
@@ -512,24 +601,35 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, s
     *nwin_out = slices;
     *c_out = c;
     hipError_t e;
-    if ((e = hipMemsetAsync(ws->totals, 0, (nbt + 1) * 4, st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(ws->counts, 0, 16, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(msm_clear_kernel, dim3((nbt * parts + 255) / 256), dim3(256), 0, st, ws->part, nbt * parts);
+    {
+        const uint32_t m = nbt * parts > nbt + 1 ? nbt * parts : nbt + 1;
+        hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, nbt * parts, ws->totals, nbt + 1,
+                           ws->counts);
+    }
     if (n > 0) {
         const uint32_t n32 = (uint32_t)n;
         const uint32_t stride = (uint32_t)ws->max_n;
         const uint32_t nchunks = (n32 + CHUNK - 1) / CHUNK;
-        hipLaunchKernelGGL(msm_recode_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, scalars, n32, stride, c, nwin,
-                           ws->digits);
-        hipLaunchKernelGGL(msm_sort_kernel<false>, dim3(nchunks * nwin), dim3(256), (nb < SORT_LDS_BUCKETS ? nb : SORT_LDS_BUCKETS) * 4, st, ws->digits, n32, stride,
-                           nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
-                           (uint32_t*)nullptr);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
-        hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), (nb < SORT_LDS_BUCKETS ? nb : SORT_LDS_BUCKETS) * 4, st, ws->digits, n32, stride,
-                           nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
-                           ws->entries);
-        hipLaunchKernelGGL(msm_pad_kernel, dim3((nbt + 255) / 256), dim3(256), 0, st, ws->totals, ws->bucket_start, nbt,
-                           ws->entries);
+        if (fixed && nb <= SORT_LDS_BUCKETS) {
+            const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
+            hipLaunchKernelGGL(msm_recode_hist_kernel, dim3(nblk), dim3(256), (nb + 256 * 9) * 4, st, scalars, n32, stride, c, nwin,
+                               nb, ws->digits, ws->totals, ws->blockbase);
+            hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
+            hipLaunchKernelGGL(msm_scatter_fixed_kernel, dim3(nblk), dim3(256), nb * 4, st, ws->digits, n32, stride, nwin, nb,
+                               table_stride, ws->totals, ws->bucket_start, ws->blockbase, ws->entries);
+        } else {
+            hipLaunchKernelGGL(msm_recode_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, scalars, n32, stride, c, nwin,
+                               ws->digits);
+            hipLaunchKernelGGL(msm_sort_kernel<false>, dim3(nchunks * nwin), dim3(256), (nb < SORT_LDS_BUCKETS ? nb : SORT_LDS_BUCKETS) * 4, st, ws->digits, n32, stride,
+                               nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
+                               (uint32_t*)nullptr);
+            hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
+            hipLaunchKernelGGL(msm_sort_kernel<true>, dim3(nchunks * nwin), dim3(256), (nb < SORT_LDS_BUCKETS ? nb : SORT_LDS_BUCKETS) * 4, st, ws->digits, n32, stride,
+                               nchunks, nb, fixed ? 1u : 0u, table_stride, ws->totals, ws->bucket_start, ws->blockbase,
+                               ws->entries);
+            hipLaunchKernelGGL(msm_pad_kernel, dim3((nbt + 255) / 256), dim3(256), 0, st, ws->totals, ws->bucket_start, nbt,
+                               ws->entries);
+        }
         const size_t worst = (size_t)n * nwin + (size_t)nbt * (PAD - 1);  // worst-case padded entry count
         const size_t threads = (worst + SEG0 - 1) / SEG0;
         if (accum_events) hipEventRecord(accum_events[0], st);

@@ -15,6 +15,8 @@
 // (zeta^i pre-multiply, zero-extension) is fused into the first pass's load and
 // 1/N, coset un-scaling and truncation into the last pass's store.
 #include "field.hip.h"
+#include <stdlib.h>
+
 #include "engine.h"
 
 namespace zk {
@@ -167,7 +169,8 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
     const uint32_t log_n = job.log_n;
     const uint32_t N = 1u << log_n;
     uint32_t bits[8];
-    const int np = ntt_plan(log_n, job.max_log_r ? job.max_log_r : 7, bits);
+    static const uint32_t env_r = getenv("ZKMI355_NTT_MAXR") ? (uint32_t)atoi(getenv("ZKMI355_NTT_MAXR")) : 0;  // tuning override
+    const int np = ntt_plan(log_n, job.max_log_r ? job.max_log_r : (env_r ? env_r : 7), bits);
     if (np == 0) {  // N == 1
         if (job.dst != job.src) return hipMemcpyAsync(job.dst, job.src, sizeof(Fr), hipMemcpyDeviceToDevice, st);
         return hipSuccess;
