@@ -574,8 +574,7 @@ struct Prover {
     }
     void to_coeff(const Fr* val, Fr* poly) {
         if (!ok()) return;
-        hipMemcpyAsync(poly, val, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
-        int r = ctx_ntt(c, poly, n, poly, lay.k, true, false, n);
+        int r = ctx_ntt(c, val, n, poly, lay.k, true, false, n);  // out of place: no staging copies
         if (r) fail(r);
     }
     void to_coset(const Fr* poly, Fr* coset) {
