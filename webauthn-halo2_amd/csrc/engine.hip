@@ -159,6 +159,7 @@ const char* zk_strerror(int code) {
         case ZK_EHIP: return "HIP runtime error";
         case ZK_ENODEV: return "no usable gfx950 device";
         case ZK_ESTATE: return "missing prerequisite (SRS / key not loaded)";
+        case ZK_EWITNESS: return "witness does not satisfy the circuit (lookup input outside the table)";
         default: return "unknown error";
     }
 }

@@ -1,0 +1,255 @@
+// field29.hip.h — carry-free field arithmetic for the hottest loops: 9 limbs of 29 bits.
+//
+// CDNA4's only wide multiplier is v_mad_u64_u32 (32 x 32 + 64 -> 64) and it has no carry-IN, so
+// with saturated 32-bit limbs every product needs a second, equally slow, carry instruction
+// (field.hip.h).  With 29-bit limbs a whole column of the product-scanning Montgomery product —
+// nine a_i*b_j and nine m_i*p_j terms, each < 2^61 — fits one 64-bit accumulator: no carries, plain
+// C++ (hipcc emits one v_mad_u64_u32 per term), 258 instead of 318 instructions per product and no
+// dependent carry chain: 157 G products/s against 121 G/s chip-wide, and 1.5x faster for a lone wave
+// (tools/ubench_f29.hip).
+//
+// Representation ("internal form"): x is held as X = x * 2^261 mod p, as an integer in [0, k*p) for a
+// small k that the caller tracks ("lazy"), in limbs that are at most a little above 29 bits:
+//   mul29   limbs a_i * b_j < 2^60.6 (e.g. 2^30.6 x 2^30), value bounds k_a * k_b <= 168 (2^261 / p =
+//           169.4): result limbs < 2^29, value < 2p
+//   add29   limb-wise;  sub29<K, E>  a + C - b with C = K*p spread so that every limb of C is >= 2^E:
+//           needs limbs b_i < 2^E, value b < K*p (and b's top limb <= (K-1)p's); result value < a + K*p
+//   norm29  carry propagation back to 29-bit limbs (value unchanged)
+// The memory image of the rest of the engine (standard Montgomery form x * 2^256, 8 x 32-bit words, the
+// Rust layout) converts for free on the way in: to29_x32 reads the limbs of (v << 5), i.e. 32 * v, a
+// valid internal form with k = 32.  On the way out one product with the standard "one" (2^256) divides
+// by 32 again.
+#pragma once
+#include "field.hip.h"
+
+namespace zk {
+
+static constexpr uint32_t M29 = (1u << 29) - 1;
+
+template <class PRM>
+struct Lim29 {
+    // limb i of K * p (K small): 29-bit digits of the 256-bit product
+    static constexpr uint32_t kp_limb(uint32_t K, int i) {
+        uint64_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t carry = 0;
+        for (int j = 0; j < 8; j++) {
+            const uint64_t t = (uint64_t)PRM::P[j] * K + carry;
+            w[j] = t & 0xffffffffu;
+            carry = t >> 32;
+        }
+        w[8] = carry;
+        const int bit = 29 * i, q = bit >> 5, o = bit & 31;
+        uint64_t two = w[q];
+        if (q + 1 < 9) two |= w[q + 1] << 32;
+        return (uint32_t)(two >> o) & M29;
+    }
+    static constexpr uint32_t INV = PRM::INV & M29;  // -p^-1 mod 2^29
+    // limb i of the spread form of K * p: every limb but the top carries an extra 2^E, borrowed from the next
+    static constexpr uint32_t spread(uint32_t K, int E, int i) {
+        const uint32_t d = kp_limb(K, i);
+        const uint32_t borrow = 1u << (E - 29);
+        if (i == 0) return d + (1u << E);
+        if (i < 8) return d + (1u << E) - borrow;
+        return d - borrow;
+    }
+    static constexpr uint32_t P[9] = {kp_limb(1, 0), kp_limb(1, 1), kp_limb(1, 2), kp_limb(1, 3), kp_limb(1, 4),
+                                      kp_limb(1, 5), kp_limb(1, 6), kp_limb(1, 7), kp_limb(1, 8)};
+};
+template <class PRM, uint32_t K, int E>
+struct Spread29 {
+    typedef Lim29<PRM> L;
+    static constexpr uint32_t C[9] = {L::spread(K, E, 0), L::spread(K, E, 1), L::spread(K, E, 2), L::spread(K, E, 3), L::spread(K, E, 4),
+                                      L::spread(K, E, 5), L::spread(K, E, 6), L::spread(K, E, 7), L::spread(K, E, 8)};
+};
+
+template <class PRM>
+struct Fe29 {
+    uint32_t l[9];
+};
+
+// plain limb split of a 256-bit integer (value unchanged)
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> to29(const Fe<PRM>& a) {
+    Fe29<PRM> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 5, o = bit & 31;
+        uint64_t two = a.v[w];
+        if (w + 1 < 8) two |= (uint64_t)a.v[w + 1] << 32;
+        r.l[i] = (uint32_t)(two >> o) & M29;
+    }
+    return r;
+}
+
+// limbs of 32 * a (a < 2^254): standard Montgomery form -> internal form with k = 32, limbs < 2^29
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> to29_x32(const Fe<PRM>& a) {
+    Fe29<PRM> r;
+    r.l[0] = (a.v[0] << 5) & M29;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        const int bit = 29 * i - 5, w = bit >> 5, o = bit & 31;
+        uint64_t two = a.v[w];
+        if (w + 1 < 8) two |= (uint64_t)a.v[w + 1] << 32;
+        r.l[i] = (uint32_t)(two >> o) & M29;
+    }
+    return r;
+}
+
+// normalised limbs (< 2^29), value < 2^256 -> 8 x 32-bit words
+template <class PRM>
+__device__ __forceinline__ Fe<PRM> from29(const Fe29<PRM>& a) {
+    Fe<PRM> r;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const int i = (32 * w) / 29, o = 32 * w - 29 * i;
+        uint64_t v = (uint64_t)a.l[i] >> o;
+        v |= (uint64_t)a.l[i + 1] << (29 - o);
+        if (i + 2 < 9) v |= (uint64_t)a.l[i + 2] << (58 - o);
+        r.v[w] = (uint32_t)v;
+    }
+    return r;
+}
+
+// a * b * 2^-261 mod p, lazily: result limbs < 2^29, value < p * (1 + k_a k_b / 169.4)
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& b) {
+    uint32_t m[9];
+    Fe29<PRM> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+        m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
+        acc += (uint64_t)m[k] * Lim29<PRM>::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+        r.l[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> add29(const Fe29<PRM>& a, const Fe29<PRM>& b) {
+    Fe29<PRM> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+// a - b + K*p, limb-wise (see the header for the conditions on b)
+template <uint32_t K, int E, class PRM>
+__device__ __forceinline__ Fe29<PRM> sub29(const Fe29<PRM>& a, const Fe29<PRM>& b) {
+    Fe29<PRM> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (Spread29<PRM, K, E>::C[i] - b.l[i]);
+    return r;
+}
+
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> norm29(const Fe29<PRM>& a) {
+    Fe29<PRM> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t t = a.l[i] + c;
+        r.l[i] = t & M29;
+        c = t >> 29;
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+
+// value < 2p, normalised limbs: is it 0 mod p?
+template <class PRM>
+__device__ __forceinline__ bool is_zero29(const Fe29<PRM>& a) {
+    uint32_t any = 0, dif = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        any |= a.l[i];
+        dif |= a.l[i] ^ Lim29<PRM>::P[i];
+    }
+    return any == 0 || dif == 0;
+}
+
+// standard Montgomery form (canonical) -> internal form with k < 2: one product by 2^266 mod p
+template <class PRM>
+struct Conv29 {
+    // 2^e mod p as 8 words, by repeated doubling at compile time
+    static constexpr void pow2_words(int e, uint32_t (&out)[8]) {
+        uint32_t v[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < e; s++) {
+            uint32_t carry = 0;
+            for (int j = 0; j < 8; j++) {
+                const uint32_t n = (v[j] << 1) | carry;
+                carry = v[j] >> 31;
+                v[j] = n;
+            }
+            // p < 2^254 and v < p before doubling, so 2v < 2^255: no carry out; subtract p if >= p
+            bool ge = true;
+            for (int j = 7; j >= 0; j--) {
+                if (v[j] != PRM::P[j]) {
+                    ge = v[j] > PRM::P[j];
+                    break;
+                }
+            }
+            if (ge) {
+                uint64_t borrow = 0;
+                for (int j = 0; j < 8; j++) {
+                    const uint64_t t = (uint64_t)v[j] - PRM::P[j] - borrow;
+                    v[j] = (uint32_t)t;
+                    borrow = (t >> 63) & 1;
+                }
+            }
+        }
+        for (int j = 0; j < 8; j++) out[j] = v[j];
+    }
+    static constexpr uint32_t pow2_limb(int e, int i) {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        pow2_words(e, w);
+        const int bit = 29 * i, q = bit >> 5, o = bit & 31;
+        uint64_t two = w[q];
+        if (q + 1 < 8) two |= (uint64_t)w[q + 1] << 32;
+        return (uint32_t)(two >> o) & M29;
+    }
+};
+
+template <class PRM, int E>
+struct Pow2_29 {
+    typedef Conv29<PRM> C;
+    static constexpr uint32_t L[9] = {C::pow2_limb(E, 0), C::pow2_limb(E, 1), C::pow2_limb(E, 2), C::pow2_limb(E, 3), C::pow2_limb(E, 4),
+                                      C::pow2_limb(E, 5), C::pow2_limb(E, 6), C::pow2_limb(E, 7), C::pow2_limb(E, 8)};
+};
+template <int E, class PRM>
+__device__ __forceinline__ Fe29<PRM> const_pow2_29() {
+    Fe29<PRM> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = Pow2_29<PRM, E>::L[i];
+    return r;
+}
+
+// x * 2^256 (canonical words) -> x * 2^261, k < 2:  (v) * 2^266 * 2^-261 = 32 v
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> std_to_internal(const Fe<PRM>& a) {
+    return mul29(to29(a), const_pow2_29<266, PRM>());
+}
+// x * 2^261 (k_a <= 168) -> x * 2^256 canonical words:  a * 2^256 * 2^-261 = a / 32
+template <class PRM>
+__device__ __forceinline__ Fe<PRM> internal_to_std(const Fe29<PRM>& a) {
+    Fe<PRM> r = from29(mul29(a, const_pow2_29<256, PRM>()));
+    reduce_once(r);
+    return r;
+}
+
+}  // namespace zk

@@ -35,6 +35,7 @@
 #include <string.h>
 #include <vector>
 
+#include "ec29.hip.h"
 #include "engine.h"
 
 namespace zk {
@@ -300,16 +301,24 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __re
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
     const uint32_t* e = entries + (size_t)t * SEG0;
-    G1X acc = G1X::identity();
+    // the running sum lives on the carry-free 29-bit-limb field (ec29.hip.h); bases are read in
+    // their standard memory form and the slot is written back in it
+    G1X29 acc;
+    acc.inf = true;
     for (uint32_t k = 0; k < SEG0; k++) {
         const uint32_t y = e[k];
         if (y == SKIP_ENTRY) continue;  // padding at the end of a bucket
         G1Affine p = affine_load(bases + (y & ~SIGN_BIT));
         if (affine_is_identity(p)) continue;
         if (y & SIGN_BIT) p.y = fe_neg(p.y);
-        g1x_add_affine(acc, p.x, p.y);
+        if (!g1x29_add_affine(acc, p.x, p.y)) {
+            // same x as the running sum (doubling or cancellation): the general formulas, rarely
+            G1X s = g1x29_to_std(acc);
+            g1x_add_affine(s, p.x, p.y);
+            acc = g1x29_from_std(s);
+        }
     }
-    g1x_store(slot_pt + t, acc);
+    g1x_store(slot_pt + t, g1x29_to_std(acc));
 }
 
 // start-of-MSM reset in one launch: bucket parts = identity, bucket totals = 0, counts = 0
