@@ -111,7 +111,10 @@ def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
     return tot or None
 
 
-ALU_PEAK_GADDS = 11.7  # XYZZ mixed additions/s the integer VALU sustains (tools/ubench_alu.hip on MI355X)
+# XYZZ mixed additions/s the integer VALU sustains with the 9x29-bit carry-free field the kernel uses: register-resident
+# operands, cache-resident points, 128 additions per lane (tools/ubench_f29.hip on MI355X; the 8x32-bit
+# formulation peaks at 11.9)
+ALU_PEAK_GADDS = 15.4
 
 
 def alu_roofline(eng, k):
@@ -298,7 +301,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,  # BASELINE.json "published" is {}: the only reference number (14.846 s/proof, M1 Pro, README.md:38) is other hardware
             "host_setup": {"synthesize_s": round(wl.synth_s, 3), "keygen_s": round(wl.keygen_s, 3)},
-            "dtype": "u256-montgomery(8x32-bit limbs)",
+            "dtype": "u256-montgomery (8x32-bit limbs; 9x29-bit carry-free limbs in the bucket accumulation)",
             "data": "synthetic",
             "config": {"workload": wl.name, "k": K, "transcript": "blake2b", "multiopen": "shplonk", "proof_bytes": len(wl.proof),
                        "parallelism": "replicas:%d (one independent proof stream per GPU, no collective)" % world},
