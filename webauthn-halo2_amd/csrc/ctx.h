@@ -42,6 +42,7 @@ struct zk_ctx {
         G1X* host_buf = nullptr;  // pinned
         bool busy = false;
         uint32_t nwin = 0, cw = 0;
+        uint32_t batch = 1;       // columns of the MSM in flight (fixed-base mode), results collected together
     } lanes[MSM_LANES];
     // scratch
     Fr* scratch = nullptr;
@@ -83,6 +84,12 @@ int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size
 // lane's stream) and returns; end waits for the lane and finishes on the host.
 int ctx_msm_begin(zk_ctx* c, int lane, const Fr* d_scalars, const G1Affine* d_bases, size_t n);
 int ctx_msm_end(zk_ctx* c, int lane, G1Jac* out);
+// several columns against the same resident SRS basis in one pass (at most ctx_msm_max_batch(c) of them);
+// ctx_msm_end_batch writes one result per column, in order
+int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_t batch, const G1Affine* d_bases, size_t n);
+int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out);
+uint32_t ctx_msm_max_batch(const zk_ctx* c);
+void ctx_msm_drain(zk_ctx* c);  // error paths: wait for every MSM in flight and drop its result
 // NTT between device buffers: inverse => x 1/N; coset => zeta scaling (coeff_to_extended / extended_to_coeff)
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out);
 void pk_destroy_all(zk_ctx* c);

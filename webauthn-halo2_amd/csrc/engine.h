@@ -28,22 +28,28 @@ void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);
 int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
 
 // ---- MSM (msm.hip) ---------------------------------------------------------
-struct MsmWorkspace;  // opaque, sized for a maximum n
-MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err);
+struct MsmWorkspace;  // opaque, sized for a maximum n and a maximum number of columns per launch
+static constexpr uint32_t MSM_MAX_BATCH = 64;
+MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, uint32_t max_batch = 1);
 void msm_workspace_destroy(MsmWorkspace* ws);
 uint32_t msm_auto_window(size_t n);
 uint32_t msm_num_windows(uint32_t c);
 size_t msm_ws_max_n(const MsmWorkspace* ws);
+uint32_t msm_ws_max_batch(const MsmWorkspace* ws);
 uint32_t msm_ws_window(const MsmWorkspace* ws);
 // table[w * n + i] = 2^(c w) * bases[i] (affine), w < msm_num_windows(c)
 hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st);
-// Launches the whole device pipeline on `st`; window sums (XYZZ) are copied to
-// `host_window_sums` asynchronously.  `table` != nullptr selects the fixed-base mode
-// (one bucket set, *nwin_out = 1); otherwise *nwin_out windows need the host Horner.
-hipError_t msm_run(MsmWorkspace* ws, const Fr* scalars, const G1Affine* bases, size_t n, hipStream_t st,
-                   G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events = nullptr,
-                   const G1Affine* table = nullptr, uint32_t table_stride = 0, hipStream_t tail_st = nullptr,
-                   hipEvent_t head_done = nullptr);
+// Launches the whole device pipeline on `st`; the bit sums (XYZZ) are copied to `host_window_sums`
+// asynchronously.  `table` != nullptr selects the fixed-base mode: `batch` scalar vectors (columns) against
+// the same bases in ONE pass, one bucket set per column; *nwin_out = batch independent results, each finished
+// with msm_finish_host(sums + q * stride, 1, c).  Without a table batch must be 1 and *nwin_out windows need
+// the host Horner: msm_finish_host(sums, *nwin_out, c).
+hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t batch, const G1Affine* bases, size_t n,
+                   hipStream_t st, G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out,
+                   hipEvent_t* accum_events = nullptr, const G1Affine* table = nullptr, uint32_t table_stride = 0,
+                   hipStream_t tail_st = nullptr, hipEvent_t head_done = nullptr);
+// G1X entries per result in host_window_sums (fixed-base mode)
+uint32_t msm_sums_per_result(uint32_t c);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).
 G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
 

@@ -1,6 +1,8 @@
 // engine.hip — context, device memory and the C ABI of libzkmi355.so
 // (declarations and the reference routines each entry point replaces:
 // include/zkmi355.h).
+#include <stdlib.h>
+
 #include <new>
 
 #include "ctx.h"
@@ -66,6 +68,22 @@ int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
     return ZK_OK;
 }
 
+// columns per fixed-base launch.  Batching makes the accumulate launch bigger (fuller waves: -15 % per column
+// already at two columns of 2^19) and replaces several reduction tails by one longer one; measured best
+// (whole proofs): 2 at 2^19, growing as the columns get shorter and launch overheads dominate
+static uint32_t batch_for(size_t n) {
+    size_t b = ((size_t)1 << 20) / (n ? n : 1);
+    if (const char* e = getenv("ZKMI355_MSM_BATCH")) b = (size_t)atoi(e);  // tuning override
+    if (b < 1) b = 1;
+    if (b > MSM_MAX_BATCH) b = MSM_MAX_BATCH;
+    return (uint32_t)b;
+}
+
+uint32_t ctx_msm_max_batch(const zk_ctx* c) {
+    if (c->srs_k < 0 || !c->table_c) return 1;
+    return batch_for((size_t)1 << c->srs_k);
+}
+
 static int get_msm_ws(zk_ctx* c, int lane, size_t n, MsmWorkspace** out) {
     size_t want = 1;
     while (want < n) want <<= 1;
@@ -77,7 +95,7 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, MsmWorkspace** out) {
     }
     if (!L.ws) {
         hipError_t e;
-        L.ws = msm_workspace_create(want, 0, &e);
+        L.ws = msm_workspace_create(want, 0, &e, batch_for(want));
         if (!L.ws) {
             c->last_hip = (int)e;
             return e == hipErrorInvalidValue ? ZK_EINVAL : ZK_ENOMEM;
@@ -87,8 +105,8 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, MsmWorkspace** out) {
     return ZK_OK;
 }
 
-int ctx_msm_begin(zk_ctx* c, int lane, const Fr* d_scalars, const G1Affine* d_bases, size_t n) {
-    if (lane < 0 || lane >= zk_ctx::MSM_LANES || c->lanes[lane].busy) return ZK_EINVAL;
+int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_t batch, const G1Affine* d_bases, size_t n) {
+    if (lane < 0 || lane >= zk_ctx::MSM_LANES || c->lanes[lane].busy || batch == 0) return ZK_EINVAL;
     zk_ctx::MsmLane& L = c->lanes[lane];
     MsmWorkspace* ws;
     // commits against the resident SRS use the precomputed window tables
@@ -102,23 +120,34 @@ int ctx_msm_begin(zk_ctx* c, int lane, const Fr* d_scalars, const G1Affine* d_ba
     int rc = get_msm_ws(c, lane, table ? (size_t)stride : n, &ws);
     if (rc) return rc;
     if (table && msm_ws_window(ws) != c->table_c) table = nullptr;
+    if (batch > 1 && (!table || batch > msm_ws_max_batch(ws))) return ZK_EINVAL;
     HIPCHK(c, hipEventRecord(L.t_head[0], c->stream));
-    HIPCHK(c, msm_run(ws, d_scalars, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
+    HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
                       L.head_done));
     HIPCHK(c, hipEventRecord(L.tail_done, L.tail));
     HIPCHK(c, hipEventRecord(L.t_head[1], c->stream));
     c->msm_launches++;
     L.n = n;
+    L.batch = batch;
     L.busy = true;
     return ZK_OK;
 }
 
-int ctx_msm_end(zk_ctx* c, int lane, G1Jac* out) {
+int ctx_msm_begin(zk_ctx* c, int lane, const Fr* d_scalars, const G1Affine* d_bases, size_t n) {
+    return ctx_msm_begin_batch(c, lane, &d_scalars, 1, d_bases, n);
+}
+
+int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
     if (lane < 0 || lane >= zk_ctx::MSM_LANES || !c->lanes[lane].busy) return ZK_EINVAL;
     zk_ctx::MsmLane& L = c->lanes[lane];
     L.busy = false;
     HIPCHK(c, hipEventSynchronize(L.tail_done));
-    *out = msm_finish_host(L.host_buf, L.nwin, L.cw);
+    if (L.batch > 1 || L.nwin == L.batch) {
+        // fixed-base mode: one independent result per column
+        for (uint32_t q = 0; q < L.batch; q++) out[q] = msm_finish_host(L.host_buf + (size_t)q * msm_sums_per_result(L.cw), 1, L.cw);
+    } else {
+        out[0] = msm_finish_host(L.host_buf, L.nwin, L.cw);  // generic mode: Horner over the windows
+    }
     // timers: head (recode .. accumulate, on the context stream) and the accumulate kernel alone
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, L.t_head[0], L.t_head[1]) == hipSuccess) {
@@ -132,6 +161,19 @@ int ctx_msm_end(zk_ctx* c, int lane, G1Jac* out) {
         c->last_plain_ms[ZK_T_MSM_ACCUM] = ms;
     }
     return ZK_OK;
+}
+
+void ctx_msm_drain(zk_ctx* c) {
+    for (int q = 0; q < zk_ctx::MSM_LANES; q++)
+        if (c->lanes[q].busy) {
+            hipEventSynchronize(c->lanes[q].tail_done);
+            c->lanes[q].busy = false;
+        }
+}
+
+int ctx_msm_end(zk_ctx* c, int lane, G1Jac* out) {
+    if (lane >= 0 && lane < zk_ctx::MSM_LANES && c->lanes[lane].busy && c->lanes[lane].batch != 1) return ZK_EINVAL;
+    return ctx_msm_end_batch(c, lane, out);
 }
 
 // synchronous form (also feeds the accumulated timers used by bench.py)
@@ -189,7 +231,7 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
             hipEventCreate(&L.t_head[1]) != hipSuccess || hipEventCreate(&L.t_acc[0]) != hipSuccess ||
             hipEventCreate(&L.t_acc[1]) != hipSuccess || hipEventCreateWithFlags(&L.head_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.tail_done, hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc(&L.host_buf, 2048 * sizeof(G1X)) != hipSuccess) {
+            hipHostMalloc(&L.host_buf, (size_t)MSM_MAX_BATCH * 15 * 4 * sizeof(G1X)) != hipSuccess) {
             zk_ctx_destroy(c);
             return ZK_EHIP;
         }

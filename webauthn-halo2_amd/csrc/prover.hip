@@ -515,8 +515,9 @@ struct Prover {
         std::vector<int> lanes;
         std::deque<int> busy;
     };
-    void fifo_begin(LaneFifo& f, const Fr* poly, size_t len, int basis) {
-        if (!ok()) return;
+    void fifo_begin(LaneFifo& f, const Fr* poly, size_t len, int basis) { fifo_begin_batch(f, {poly}, len, basis); }
+    void fifo_begin_batch(LaneFifo& f, const std::vector<const Fr*>& polys, size_t len, int basis) {
+        if (!ok() || polys.empty()) return;
         if (f.busy.size() == f.lanes.size()) {
             commit_end_write(f.busy.front());
             f.busy.pop_front();
@@ -524,8 +525,23 @@ struct Prover {
         int lane = -1;
         for (int l : f.lanes)
             if (std::find(f.busy.begin(), f.busy.end(), l) == f.busy.end()) lane = l;
-        commit_begin(lane, poly, len, basis);
+        commit_begin_batch(lane, polys, len, basis);
         f.busy.push_back(lane);
+    }
+    // gathers columns into batches of the size the MSM workspaces take; flush() launches what is pending
+    struct Batcher {
+        LaneFifo* f;
+        int basis;
+        uint32_t cap;
+        std::vector<const Fr*> pend;
+    };
+    void batch_add(Batcher& b, const Fr* poly) {
+        b.pend.push_back(poly);
+        if (b.pend.size() >= b.cap) batch_flush(b);
+    }
+    void batch_flush(Batcher& b) {
+        fifo_begin_batch(*b.f, b.pend, n, b.basis);
+        b.pend.clear();
     }
     void fifo_drain(LaneFifo& f) {
         while (!f.busy.empty()) {
@@ -545,17 +561,23 @@ struct Prover {
     }
     // split commit: the MSM is enqueued on `lane` and its latency-bound tail overlaps whatever is
     // launched next; the point is written to the transcript when the lane is collected.
-    void commit_begin(int lane, const Fr* poly, size_t len, int basis) {
+    void commit_begin(int lane, const Fr* poly, size_t len, int basis) { commit_begin_batch(lane, {poly}, len, basis); }
+    // several columns against the same basis in ONE MSM pass (at most ctx_msm_max_batch of them)
+    void commit_begin_batch(int lane, const std::vector<const Fr*>& polys, size_t len, int basis) {
         if (!ok()) return;
-        int r = ctx_msm_begin(c, lane, poly, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, len);
+        int r = ctx_msm_begin_batch(c, lane, polys.data(), (uint32_t)polys.size(), basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g,
+                                    len);
         if (r) fail(r);
     }
+    // collects a lane: its commitments are written to the transcript in the order they were given
     void commit_end_write(int lane) {
         if (!ok()) return;
-        G1Jac j;
-        int r = ctx_msm_end(c, lane, &j);
+        G1Jac js[MSM_MAX_BATCH];
+        const uint32_t cnt = c->lanes[lane].batch;
+        int r = ctx_msm_end_batch(c, lane, js);
         if (r) return fail(r);
-        if (!tr->write_point(g1_jac_to_affine_host(j))) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
+        for (uint32_t q = 0; q < cnt && ok(); q++)
+            if (!tr->write_point(g1_jac_to_affine_host(js[q]))) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
     }
     // z[0] = init, z[i+1] = z[i] * t_num[i] / t_den[i]
     void grand_product(Fr* z, const Fr* init_dev) {
@@ -653,17 +675,22 @@ struct Prover {
         // The coefficient and extended-coset forms the quotient needs are produced right behind each
         // commitment's head: they need no challenge, and they keep the main stream busy while the MSM tails
         // (and the host's transcript work) would otherwise leave it idle.
+        const uint32_t max_batch = ctx_msm_max_batch(c);
         if (pipe) {
             commit_begin(0, pk->adv_val[0], n, ZK_BASIS_LAGRANGE);
-            to_coeff(pk->adv_val[0], pk->adv_poly[0]);
-            to_coset(pk->adv_poly[0], pk->adv_coset[0]);
         } else {
-            // several advice columns: keep MSM_LANES commitments in flight, collect in column order
+            // several advice columns: whole batches of columns per MSM pass, up to MSM_LANES passes in flight,
+            // each followed by its columns' transforms; collected in column order
             LaneFifo f{{0, 1, 2}, {}};
-            for (uint32_t j = 0; j < lay.n_adv && ok(); j++) {
-                fifo_begin(f, pk->adv_val[j], n, ZK_BASIS_LAGRANGE);
-                to_coeff(pk->adv_val[j], pk->adv_poly[j]);
-                to_coset(pk->adv_poly[j], pk->adv_coset[j]);
+            for (uint32_t j0 = 0; j0 < lay.n_adv && ok(); j0 += max_batch) {
+                const uint32_t j1 = std::min(lay.n_adv, j0 + max_batch);
+                std::vector<const Fr*> cols;
+                for (uint32_t j = j0; j < j1; j++) cols.push_back(pk->adv_val[j]);
+                fifo_begin_batch(f, cols, n, ZK_BASIS_LAGRANGE);
+                for (uint32_t j = j0; j < j1 && ok(); j++) {
+                    to_coeff(pk->adv_val[j], pk->adv_poly[j]);
+                    to_coset(pk->adv_poly[j], pk->adv_coset[j]);
+                }
             }
             fifo_drain(f);
         }
@@ -680,6 +707,21 @@ struct Prover {
                 theta_done = true;
             }
         };
+        // a', s' of every lookup: batches of columns per MSM pass; their transforms (and, in the pipelined
+        // case, the advice column's) follow the MSM heads so that they cover the tails
+        LaneFifo lf{pipe ? std::vector<int>{1, 2} : std::vector<int>{0, 1, 2}, {}};
+        Batcher lb{&lf, ZK_BASIS_LAGRANGE, max_batch, {}};
+        std::vector<uint32_t> due;
+        auto lookup_transforms = [&]() {
+            for (uint32_t l : due) {
+                to_coeff(pk->lk_ap[l], pk->lk_ap_poly[l]);
+                to_coset(pk->lk_ap_poly[l], pk->lk_ap_coset[l]);
+                to_coeff(pk->lk_sp[l], pk->lk_sp_poly[l]);
+                to_coset(pk->lk_sp_poly[l], pk->lk_sp_coset[l]);
+            }
+            due.clear();
+        };
+        if (!pipe) squeeze_theta();  // the advice commitments are all written: theta precedes the first a'
         for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
             const Fr* inp;
             if (lay.single) {
@@ -694,26 +736,25 @@ struct Prover {
                 hipStreamSynchronize(st) != hipSuccess)
                 return ZK_EHIP;
             if (err) {
-                for (int q = 0; q < zk_ctx::MSM_LANES; q++)
-                    if (c->lanes[q].busy) {
-                        G1Jac dummy;
-                        ctx_msm_end(c, q, &dummy);
-                    }
+                ctx_msm_drain(c);
                 return ZK_EWITNESS;  // lookup input not in table (halo2: ConstraintSystemFailure)
             }
             set_rows(pk->lk_ap[l], usable, draw(bf + 1));
             set_rows(pk->lk_sp[l], usable, draw(bf + 1));
             draw(2);
-            commit_begin(1, pk->lk_ap[l], n, ZK_BASIS_LAGRANGE);
-            commit_begin(2, pk->lk_sp[l], n, ZK_BASIS_LAGRANGE);
-            to_coeff(pk->lk_ap[l], pk->lk_ap_poly[l]);
-            to_coset(pk->lk_ap_poly[l], pk->lk_ap_coset[l]);
-            to_coeff(pk->lk_sp[l], pk->lk_sp_poly[l]);
-            to_coset(pk->lk_sp_poly[l], pk->lk_sp_coset[l]);
-            squeeze_theta();
-            commit_end_write(1);
-            commit_end_write(2);
+            batch_add(lb, pk->lk_ap[l]);
+            batch_add(lb, pk->lk_sp[l]);
+            due.push_back(l);
+            if (lb.pend.empty()) lookup_transforms();
         }
+        batch_flush(lb);
+        lookup_transforms();
+        if (pipe) {
+            to_coeff(pk->adv_val[0], pk->adv_poly[0]);
+            to_coset(pk->adv_poly[0], pk->adv_coset[0]);
+        }
+        squeeze_theta();
+        fifo_drain(lf);
         squeeze_theta();
         (void)theta;
         if (!ok()) return rc;
@@ -730,8 +771,18 @@ struct Prover {
             commit_begin(0, pk->random_poly, n, ZK_BASIS_MONOMIAL);
         }
 
-        // -- 3. permutation grand products (lanes 1 and 2: a chunk's tail overlaps the next chunk's kernels)
+        // -- 3. permutation grand products.  All z columns (permutation chunks, then lookups) are committed in
+        // batches on lanes 1 and 2; their transforms follow each batch's MSM head.
         LaneFifo zf{{1, 2}, {}};
+        Batcher zb{&zf, ZK_BASIS_LAGRANGE, max_batch, {}};
+        std::vector<std::pair<const Fr*, std::pair<Fr*, Fr*>>> zdue;  // values -> (coefficients, coset)
+        auto z_transforms = [&]() {
+            for (auto& e : zdue) {
+                to_coeff(e.first, e.second.first);
+                to_coset(e.second.first, e.second.second);
+            }
+            zdue.clear();
+        };
         {
             const Fr delta = fr_delta();
             Fr dcur = Fr::one();
@@ -758,9 +809,9 @@ struct Prover {
                 grand_product(pk->z_val[ci], init_dev);
                 set_rows(pk->z_val[ci], n - bf, draw(bf));
                 draw(1);
-                fifo_begin(zf, pk->z_val[ci], n, ZK_BASIS_LAGRANGE);
-                to_coeff(pk->z_val[ci], pk->z_poly[ci]);
-                to_coset(pk->z_poly[ci], pk->z_coset[ci]);
+                batch_add(zb, pk->z_val[ci]);
+                zdue.push_back({pk->z_val[ci], {pk->z_poly[ci], pk->z_coset[ci]}});
+                if (zb.pend.empty()) z_transforms();
             }
         }
         // -- 4. lookup grand products
@@ -770,10 +821,12 @@ struct Prover {
             grand_product(pk->lk_z[l], nullptr);
             set_rows(pk->lk_z[l], n - bf, draw(bf));
             draw(1);
-            fifo_begin(zf, pk->lk_z[l], n, ZK_BASIS_LAGRANGE);
-            to_coeff(pk->lk_z[l], pk->lk_z_poly[l]);
-            to_coset(pk->lk_z_poly[l], pk->lk_z_coset[l]);
+            batch_add(zb, pk->lk_z[l]);
+            zdue.push_back({pk->lk_z[l], {pk->lk_z_poly[l], pk->lk_z_coset[l]}});
+            if (zb.pend.empty()) z_transforms();
         }
+        batch_flush(zb);
+        z_transforms();
         fifo_drain(zf);
         if (!ok()) return rc;
 
@@ -844,13 +897,14 @@ struct Prover {
             if (r) return r;
         }
         draw(lay.n_h);  // h-piece blinds
-        for (uint32_t i = 0; i < lay.n_h && ok(); i++) {
-            const int lane = (int)(i % zk_ctx::MSM_LANES);
-            if (i >= (uint32_t)zk_ctx::MSM_LANES) commit_end_write(lane);  // oldest in flight, in order
-            commit_begin(lane, pk->h_ext + (size_t)i * n, n, ZK_BASIS_MONOMIAL);
+        {
+            // the h pieces are contiguous n-coefficient slices of the quotient: one MSM pass for all of them
+            LaneFifo hf{{0, 1, 2}, {}};
+            Batcher hb{&hf, ZK_BASIS_MONOMIAL, max_batch, {}};
+            for (uint32_t i = 0; i < lay.n_h && ok(); i++) batch_add(hb, pk->h_ext + (size_t)i * n);
+            batch_flush(hb);
+            fifo_drain(hf);
         }
-        for (uint32_t i = (lay.n_h > (uint32_t)zk_ctx::MSM_LANES ? lay.n_h - zk_ctx::MSM_LANES : 0); i < lay.n_h && ok(); i++)
-            commit_end_write((int)(i % zk_ctx::MSM_LANES));
         if (!ok()) return rc;
         const Fr x = tr->squeeze();
 
@@ -960,6 +1014,12 @@ struct Prover {
                     }
                 if (!found) sets.push_back({qq.rot, {qq}});
             }
+            // the witness polynomials need no challenge in between: all of them go through one MSM pass.  Buffers: the
+            // h pieces (free once h(X) has been combined) and two temporaries — GWC has at most six rotation sets.
+            Fr* wbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
+            if (sets.size() > 6) return ZK_ESTATE;
+            LaneFifo wf{{0, 1, 2}, {}};
+            Batcher wb{&wf, ZK_BASIS_MONOMIAL, max_batch, {}};
             size_t set_idx = 0;
             for (auto& s : sets) {
                 std::vector<Term> terms;
@@ -970,17 +1030,13 @@ struct Prover {
                     pv = fe_mul(pv, v);
                 }
                 lincomb_many(pk->t_a, terms, true, eb);
-                launch_kate_division(pk->t_a, pk->t_b, n, xrot(x, s.first), pk->t_small, pk->t_small + (n / 32 + 8), st);
-                // the witness commitments need no challenge in between: keep up to MSM_LANES in flight
-                // (t_b is consumed by the MSM's recode kernel before the next set overwrites it: stream order)
-                const int lane = (int)(set_idx % zk_ctx::MSM_LANES);
-                if (set_idx >= (size_t)zk_ctx::MSM_LANES) commit_end_write(lane);
-                commit_begin(lane, pk->t_b, n, ZK_BASIS_MONOMIAL);
+                launch_kate_division(pk->t_a, wbuf[set_idx], n, xrot(x, s.first), pk->t_small, pk->t_small + (n / 32 + 8), st);
+                batch_add(wb, wbuf[set_idx]);
                 set_idx++;
                 if (!ok()) return rc;
             }
-            for (size_t i = (set_idx > (size_t)zk_ctx::MSM_LANES ? set_idx - zk_ctx::MSM_LANES : 0); i < set_idx && ok(); i++)
-                commit_end_write((int)(i % zk_ctx::MSM_LANES));
+            batch_flush(wb);
+            fifo_drain(wf);
         } else {
             // SHPLONK: group commitments by their set of rotations
             struct CR {
@@ -1162,11 +1218,7 @@ extern "C" int zk_prove(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advi
     Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
     Prover p(c, pk, rng_seed, tr);
     rc = p.run(adv.data(), scheme);
-    for (int q = 0; q < zk_ctx::MSM_LANES; q++)  // an early error may leave commitments in flight
-        if (c->lanes[q].busy) {
-            G1Jac dummy;
-            ctx_msm_end(c, q, &dummy);
-        }
+    ctx_msm_drain(c);  // an early error may leave commitments in flight
     hipStreamSynchronize(c->stream);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;
