@@ -92,4 +92,8 @@ uint32_t ctx_msm_max_batch(const zk_ctx* c);
 void ctx_msm_drain(zk_ctx* c);  // error paths: wait for every MSM in flight and drop its result
 // NTT between device buffers: inverse => x 1/N; coset => zeta scaling (coeff_to_extended / extended_to_coeff)
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out);
+// the same transform over `batch` vectors in one launch per pass (batch <= ctx_ntt_max_batch(log_n))
+int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dsts, uint32_t batch, uint32_t log_n, bool inverse,
+                  bool coset, size_t n_out);
+uint32_t ctx_ntt_max_batch(uint32_t log_n);
 void pk_destroy_all(zk_ctx* c);

@@ -11,10 +11,15 @@
 namespace zk {
 
 // ---- NTT (ntt.hip) ---------------------------------------------------------
+static constexpr uint32_t NTT_MAX_BATCH = 32;  // vectors transformed by one launch (grid.y)
 struct NttJob {
     const Fr* src;      // n_in elements (rest of the 2^log_n vector is zero)
     Fr* dst;            // 2^log_n elements (n_out stored)
-    Fr* tmp;            // 2^log_n scratch (required when more than one pass, or src == dst)
+    Fr* tmp;            // 2^log_n scratch per vector (required when more than one pass, or src == dst)
+    // batch > 1: the same transform over srcs[b] -> dsts[b] (src / dst unused); tmp holds batch x 2^log_n
+    uint32_t batch;
+    const Fr* srcs[NTT_MAX_BATCH];
+    Fr* dsts[NTT_MAX_BATCH];
     const Fr* tw;       // twiddle table w^i, i < 2^log_n
     uint32_t log_n;
     uint32_t inverse;   // use w^-1

@@ -676,15 +676,30 @@ int zk_commit(zk_ctx* c, zk_poly h, int basis, uint64_t out[8]) {
 }  // extern "C"
 
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
+    return ctx_ntt_batch(c, &src, src_n, &dst, 1, log_n, inverse, coset, n_out);
+}
+
+uint32_t ctx_ntt_max_batch(uint32_t log_n) {
+    // scratch for the ping-pong is batch x 2^log_n elements: keep it within 2^23 (256 MiB)
+    const uint32_t cap = log_n >= 23 ? 1u : 1u << (23 - log_n);
+    return cap < NTT_MAX_BATCH ? cap : NTT_MAX_BATCH;
+}
+
+int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dsts, uint32_t batch, uint32_t log_n, bool inverse,
+                  bool coset, size_t n_out) {
     const size_t N = (size_t)1 << log_n;
-    int rc = ctx_ensure_scratch(c, N);
+    if (batch == 0 || batch > ctx_ntt_max_batch(log_n)) return ZK_EINVAL;
+    int rc = ctx_ensure_scratch(c, N * batch);
     if (rc) return rc;
     const Fr* tw;
     if ((rc = ctx_get_twiddles(c, log_n, &tw)) != ZK_OK) return rc;
     NttJob job;
     memset(&job, 0, sizeof(job));
-    job.src = src;
-    job.dst = dst;
+    job.batch = batch;
+    for (uint32_t b = 0; b < batch; b++) {
+        job.srcs[b] = srcs[b];
+        job.dsts[b] = dsts[b];
+    }
     job.tmp = c->scratch;
     job.tw = tw;
     job.log_n = log_n;

@@ -16,6 +16,7 @@
 // 1/N, coset un-scaling and truncation into the last pass's store.
 #include "field.hip.h"
 #include <stdlib.h>
+#include <string.h>
 
 #include "engine.h"
 
@@ -25,8 +26,8 @@ static constexpr int NTT_TILE_LOG = 9;   // 512 elements x 32 B = 16 KiB LDS: ma
 static constexpr int NTT_THREADS = 256;
 
 struct NttPassArgs {
-    const Fr* in;
-    Fr* out;
+    const Fr* in[NTT_MAX_BATCH];   // one vector per blockIdx.y
+    Fr* out[NTT_MAX_BATCH];
     const Fr* tw;        // w_N^i for i in [0, N)
     uint32_t log_n;
     uint32_t log_r;      // this pass's radix
@@ -44,6 +45,8 @@ struct NttPassArgs {
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fr* s = reinterpret_cast<Fr*>(smem_raw);
+    const Fr* __restrict__ vin = a.in[blockIdx.y];
+    Fr* __restrict__ vout = a.out[blockIdx.y];
 
     const uint32_t N = 1u << a.log_n;
     const uint32_t R = 1u << a.log_r;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
         const uint32_t idx = j + r * col_stride;
         Fr x;
         if (idx < a.n_in) {
-            x = fe_load(a.in + idx);
+            x = fe_load(vin + idx);
             if (a.has_pre) {
                 const uint32_t m = idx % 3;
                 if (m) x = fe_mul(x, a.pre[m]);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
             const uint32_t rb = a.log_r ? (__brev(r) >> brev_shift) : 0;
             Fr x = s[rb * T + t];
             if (a.has_post) x = fe_mul(x, a.post[dst % 3]);
-            fe_store(a.out + dst, x);
+            fe_store(vout + dst, x);
         }
     }
 }
@@ -168,31 +171,50 @@ int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]) {
 hipError_t ntt_run(const NttJob& job, hipStream_t st) {
     const uint32_t log_n = job.log_n;
     const uint32_t N = 1u << log_n;
+    const uint32_t batch = job.batch ? job.batch : 1;
+    if (batch > NTT_MAX_BATCH) return hipErrorInvalidValue;
+    const Fr* srcs[NTT_MAX_BATCH];
+    Fr* dsts[NTT_MAX_BATCH];
+    for (uint32_t b = 0; b < batch; b++) {
+        srcs[b] = job.batch ? job.srcs[b] : job.src;
+        dsts[b] = job.batch ? job.dsts[b] : job.dst;
+    }
     uint32_t bits[8];
     static const uint32_t env_r = getenv("ZKMI355_NTT_MAXR") ? (uint32_t)atoi(getenv("ZKMI355_NTT_MAXR")) : 0;  // tuning override
     const int np = ntt_plan(log_n, job.max_log_r ? job.max_log_r : (env_r ? env_r : 7), bits);
     if (np == 0) {  // N == 1
-        if (job.dst != job.src) return hipMemcpyAsync(job.dst, job.src, sizeof(Fr), hipMemcpyDeviceToDevice, st);
+        for (uint32_t b = 0; b < batch; b++)
+            if (dsts[b] != srcs[b]) {
+                hipError_t e = hipMemcpyAsync(dsts[b], srcs[b], sizeof(Fr), hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
         return hipSuccess;
     }
-    // Ping-pong so that the last pass writes job.dst and no pass runs in place:
+    // Ping-pong so that the last pass writes dst and no pass runs in place:
     // pass p writes bufs[(np - 1 - p) & 1] with bufs = {dst, tmp}.
-    const Fr* cur_in = job.src;
-    Fr* bufs[2] = {job.dst, job.tmp};
-    int which = (np & 1) ? 0 : 1;
-    if (job.tmp == nullptr && (np > 1 || job.src == job.dst)) return hipErrorInvalidValue;
-    if (job.src == job.dst && (np & 1)) {
-        // first pass would read and write dst: stage the input in tmp
-        hipError_t e = hipMemcpyAsync(job.tmp, job.src, sizeof(Fr) * (size_t)(job.n_in < N ? job.n_in : N),
-                                      hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return e;
-        cur_in = job.tmp;
+    bool inplace = false;
+    for (uint32_t b = 0; b < batch; b++) inplace = inplace || srcs[b] == dsts[b];
+    if (job.tmp == nullptr && (np > 1 || inplace)) return hipErrorInvalidValue;
+    const Fr* cur_in[NTT_MAX_BATCH];
+    for (uint32_t b = 0; b < batch; b++) {
+        cur_in[b] = srcs[b];
+        if (srcs[b] == dsts[b] && (np & 1)) {
+            // first pass would read and write dst: stage the input in tmp
+            hipError_t e = hipMemcpyAsync(job.tmp + (size_t)b * N, srcs[b], sizeof(Fr) * (size_t)(job.n_in < N ? job.n_in : N),
+                                          hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return e;
+            cur_in[b] = job.tmp + (size_t)b * N;
+        }
     }
+    int which = (np & 1) ? 0 : 1;  // 0: dst, 1: tmp
     uint32_t log_ns = 0;
     for (int p = 0; p < np; p++) {
         NttPassArgs a;
-        a.in = cur_in;
-        a.out = bufs[which];
+        memset(&a, 0, sizeof(a));
+        for (uint32_t b = 0; b < batch; b++) {
+            a.in[b] = cur_in[b];
+            a.out[b] = which ? job.tmp + (size_t)b * N : dsts[b];
+        }
         a.tw = job.tw;
         a.log_n = log_n;
         a.log_r = bits[p];
@@ -211,8 +233,8 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         }
         const uint32_t blocks = N >> (a.log_r + a.log_t);
         const size_t lds = ((size_t)sizeof(Fr) << (a.log_r + a.log_t)) + (sizeof(Fr) << a.log_r) / 2;
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(NTT_THREADS), lds, st, a);
-        cur_in = bufs[which];
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        for (uint32_t b = 0; b < batch; b++) cur_in[b] = a.out[b];
         which ^= 1;
         log_ns += bits[p];
     }

@@ -594,6 +594,36 @@ struct Prover {
             launch_prefix_product(pk->t_frac, z, n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
         }
     }
+    // Lagrange values -> coefficients -> extended coset for a set of columns, several columns per launch
+    struct Forms {
+        const Fr* val;
+        Fr* poly;
+        Fr* coset;
+    };
+    void transforms(const std::vector<Forms>& cols) {
+        if (!ok() || cols.empty()) return;
+        const uint32_t b1 = ctx_ntt_max_batch(lay.k), b2 = ctx_ntt_max_batch(lay.ext_k);
+        const Fr* src[NTT_MAX_BATCH];
+        Fr* dst[NTT_MAX_BATCH];
+        for (size_t i0 = 0; i0 < cols.size() && ok(); i0 += b1) {
+            const uint32_t cnt = (uint32_t)std::min<size_t>(b1, cols.size() - i0);
+            for (uint32_t q = 0; q < cnt; q++) {
+                src[q] = cols[i0 + q].val;
+                dst[q] = cols[i0 + q].poly;
+            }
+            int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.k, true, false, n);
+            if (r) fail(r);
+        }
+        for (size_t i0 = 0; i0 < cols.size() && ok(); i0 += b2) {
+            const uint32_t cnt = (uint32_t)std::min<size_t>(b2, cols.size() - i0);
+            for (uint32_t q = 0; q < cnt; q++) {
+                src[q] = cols[i0 + q].poly;
+                dst[q] = cols[i0 + q].coset;
+            }
+            int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.ext_k, false, true, N);
+            if (r) fail(r);
+        }
+    }
     void to_coeff(const Fr* val, Fr* poly) {
         if (!ok()) return;
         int r = ctx_ntt(c, val, n, poly, lay.k, true, false, n);  // out of place: no staging copies
@@ -687,10 +717,9 @@ struct Prover {
                 std::vector<const Fr*> cols;
                 for (uint32_t j = j0; j < j1; j++) cols.push_back(pk->adv_val[j]);
                 fifo_begin_batch(f, cols, n, ZK_BASIS_LAGRANGE);
-                for (uint32_t j = j0; j < j1 && ok(); j++) {
-                    to_coeff(pk->adv_val[j], pk->adv_poly[j]);
-                    to_coset(pk->adv_poly[j], pk->adv_coset[j]);
-                }
+                std::vector<Forms> fm;
+                for (uint32_t j = j0; j < j1; j++) fm.push_back(Forms{pk->adv_val[j], pk->adv_poly[j], pk->adv_coset[j]});
+                transforms(fm);
             }
             fifo_drain(f);
         }
@@ -712,13 +741,14 @@ struct Prover {
         LaneFifo lf{pipe ? std::vector<int>{1, 2} : std::vector<int>{0, 1, 2}, {}};
         Batcher lb{&lf, ZK_BASIS_LAGRANGE, max_batch, {}};
         std::vector<uint32_t> due;
-        auto lookup_transforms = [&]() {
+        auto lookup_transforms = [&](bool with_advice) {
+            std::vector<Forms> fm;
+            if (with_advice) fm.push_back(Forms{pk->adv_val[0], pk->adv_poly[0], pk->adv_coset[0]});
             for (uint32_t l : due) {
-                to_coeff(pk->lk_ap[l], pk->lk_ap_poly[l]);
-                to_coset(pk->lk_ap_poly[l], pk->lk_ap_coset[l]);
-                to_coeff(pk->lk_sp[l], pk->lk_sp_poly[l]);
-                to_coset(pk->lk_sp_poly[l], pk->lk_sp_coset[l]);
+                fm.push_back(Forms{pk->lk_ap[l], pk->lk_ap_poly[l], pk->lk_ap_coset[l]});
+                fm.push_back(Forms{pk->lk_sp[l], pk->lk_sp_poly[l], pk->lk_sp_coset[l]});
             }
+            transforms(fm);
             due.clear();
         };
         if (!pipe) squeeze_theta();  // the advice commitments are all written: theta precedes the first a'
@@ -745,14 +775,10 @@ struct Prover {
             batch_add(lb, pk->lk_ap[l]);
             batch_add(lb, pk->lk_sp[l]);
             due.push_back(l);
-            if (lb.pend.empty()) lookup_transforms();
+            if (lb.pend.empty()) lookup_transforms(false);
         }
         batch_flush(lb);
-        lookup_transforms();
-        if (pipe) {
-            to_coeff(pk->adv_val[0], pk->adv_poly[0]);
-            to_coset(pk->adv_poly[0], pk->adv_coset[0]);
-        }
+        lookup_transforms(pipe);
         squeeze_theta();
         fifo_drain(lf);
         squeeze_theta();
@@ -775,12 +801,9 @@ struct Prover {
         // batches on lanes 1 and 2; their transforms follow each batch's MSM head.
         LaneFifo zf{{1, 2}, {}};
         Batcher zb{&zf, ZK_BASIS_LAGRANGE, max_batch, {}};
-        std::vector<std::pair<const Fr*, std::pair<Fr*, Fr*>>> zdue;  // values -> (coefficients, coset)
+        std::vector<Forms> zdue;
         auto z_transforms = [&]() {
-            for (auto& e : zdue) {
-                to_coeff(e.first, e.second.first);
-                to_coset(e.second.first, e.second.second);
-            }
+            transforms(zdue);
             zdue.clear();
         };
         {
@@ -810,7 +833,7 @@ struct Prover {
                 set_rows(pk->z_val[ci], n - bf, draw(bf));
                 draw(1);
                 batch_add(zb, pk->z_val[ci]);
-                zdue.push_back({pk->z_val[ci], {pk->z_poly[ci], pk->z_coset[ci]}});
+                zdue.push_back(Forms{pk->z_val[ci], pk->z_poly[ci], pk->z_coset[ci]});
                 if (zb.pend.empty()) z_transforms();
             }
         }
@@ -822,7 +845,7 @@ struct Prover {
             set_rows(pk->lk_z[l], n - bf, draw(bf));
             draw(1);
             batch_add(zb, pk->lk_z[l]);
-            zdue.push_back({pk->lk_z[l], {pk->lk_z_poly[l], pk->lk_z_coset[l]}});
+            zdue.push_back(Forms{pk->lk_z[l], pk->lk_z_poly[l], pk->lk_z_coset[l]});
             if (zb.pend.empty()) z_transforms();
         }
         batch_flush(zb);
