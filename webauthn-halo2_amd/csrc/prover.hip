@@ -540,7 +540,14 @@ struct Prover {
         if (b.pend.size() >= b.cap) batch_flush(b);
     }
     void batch_flush(Batcher& b) {
-        fifo_begin_batch(*b.f, b.pend, n, b.basis);
+        if (b.pend.size() >= 4 && b.f->lanes.size() >= 2) {
+            // two passes on two lanes instead of one: the first half's reduction tail runs under the second half's head
+            const size_t h = (b.pend.size() + 1) / 2;
+            fifo_begin_batch(*b.f, std::vector<const Fr*>(b.pend.begin(), b.pend.begin() + h), n, b.basis);
+            fifo_begin_batch(*b.f, std::vector<const Fr*>(b.pend.begin() + h, b.pend.end()), n, b.basis);
+        } else {
+            fifo_begin_batch(*b.f, b.pend, n, b.basis);
+        }
         b.pend.clear();
     }
     void fifo_drain(LaneFifo& f) {
@@ -576,8 +583,29 @@ struct Prover {
         const uint32_t cnt = c->lanes[lane].batch;
         int r = ctx_msm_end_batch(c, lane, js);
         if (r) return fail(r);
+        // affine forms with ONE field inversion for the whole batch (Montgomery's trick over the z's)
+        Fq pre[MSM_MAX_BATCH];
+        Fq run = Fq::one();
+        for (uint32_t q = 0; q < cnt; q++) {
+            pre[q] = run;
+            if (!js[q].z.is_zero()) run = fe_mul(run, js[q].z);
+        }
+        Fq inv = fe_inv(run);
+        G1Affine af[MSM_MAX_BATCH];
+        for (uint32_t q = cnt; q-- > 0;) {
+            if (js[q].z.is_zero()) {
+                af[q].x = Fq::zero();
+                af[q].y = Fq::zero();
+                continue;
+            }
+            const Fq zi = fe_mul(inv, pre[q]);
+            inv = fe_mul(inv, js[q].z);
+            const Fq zi2 = fe_sqr(zi);
+            af[q].x = fe_mul(js[q].x, zi2);
+            af[q].y = fe_mul(js[q].y, fe_mul(zi2, zi));
+        }
         for (uint32_t q = 0; q < cnt && ok(); q++)
-            if (!tr->write_point(g1_jac_to_affine_host(js[q]))) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
+            if (!tr->write_point(af[q])) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
     }
     // z[0] = init, z[i+1] = z[i] * t_num[i] / t_den[i]
     void grand_product(Fr* z, const Fr* init_dev) {
