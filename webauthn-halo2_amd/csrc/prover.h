@@ -83,8 +83,22 @@ void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, 
 void launch_frac(const Fr* num, const Fr* den, Fr* frac, uint32_t n, hipStream_t st);
 void launch_prefix_product(const Fr* f, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_local,
                            Fr* tmp_tot, hipStream_t st);
-int launch_grand_product(const Fr* num, const Fr* den, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_p,
-                         Fr* tmp_r, Fr* tmp_tot, Fr* host_q, hipStream_t st);
+// one grand product of a batch (launch_gp_batch_*): z[0] = init, z[i+1] = z[i] * num[i] / den[i]
+struct GpItem {
+    const Fr* num;
+    const Fr* den;
+    Fr* loc_p;    // n: inclusive prefix products of num within 2048-element blocks
+    Fr* loc_r;    // n: inclusive suffix products of den within blocks
+    Fr* tot_p;    // blocks: block totals, then exclusive offsets
+    Fr* tot_r;
+    Fr* z;
+    uint32_t chain;  // init = the previous item's z at the chain row (permutation chunks); otherwise 1
+    uint32_t pad_;
+};
+uint32_t gp_blocks(uint32_t n);
+void launch_gp_batch_scan(const GpItem* d_items, uint32_t nprod, uint32_t n, Fr* q_dev, hipStream_t st);
+void launch_gp_batch_apply(const GpItem* d_items, uint32_t nprod, uint32_t n, uint32_t chain_row, const Fr* q_inv_dev, Fr* k_dev,
+                           Fr* init_dev, hipStream_t st);
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st);
 void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
 

@@ -103,6 +103,12 @@ struct zk_pk_rec {
     Fr* rows_host = nullptr;  // pinned ring for blinding rows (Prover::set_rows)
     LookupScratch lks{};
     uint32_t* lk_u32 = nullptr;
+    // all grand products of a proof in one batch (launch_gp_batch_*)
+    std::vector<Fr*> gp_num, gp_den, gp_loc_p, gp_loc_r;  // per product, n each
+    Fr* gp_tot = nullptr;        // 2 x blocks per product
+    Fr* gp_scal = nullptr;       // device: q, q_inv, k, init (n_prod each)
+    Fr* gp_host = nullptr;       // pinned: q and q_inv
+    GpItem* d_gp_items = nullptr;
     QuotientArgs* d_qargs = nullptr;
     EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
     uint32_t max_evals = 0;
@@ -209,6 +215,8 @@ void pk_destroy(zk_pk_rec* pk) {
     if (pk->tail_host) hipHostFree(pk->tail_host);
     if (pk->rows_host) hipHostFree(pk->rows_host);
     if (pk->lk_u32) hipFree(pk->lk_u32);
+    if (pk->gp_host) hipHostFree(pk->gp_host);
+    if (pk->d_gp_items) hipFree(pk->d_gp_items);
     if (pk->d_qargs) hipFree(pk->d_qargs);
     if (pk->d_evargs) hipFree(pk->d_evargs);
     if (pk->h_evargs) hipHostFree(pk->h_evargs);
@@ -411,6 +419,20 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->t_a = d.alloc(n);
     pk->t_b = d.alloc(n);
     pk->t_small = d.alloc(n / 16 + 8192);
+    {
+        const uint32_t nprod = lay.n_chunks + lay.n_lookups;
+        for (uint32_t p = 0; p < nprod; p++) {
+            pk->gp_num.push_back(d.alloc(n));
+            pk->gp_den.push_back(d.alloc(n));
+            pk->gp_loc_p.push_back(d.alloc(n));
+            pk->gp_loc_r.push_back(d.alloc(n));
+        }
+        pk->gp_tot = d.alloc((size_t)2 * gp_blocks(n) * nprod);
+        pk->gp_scal = d.alloc((size_t)4 * nprod);
+        if (hipHostMalloc(&pk->gp_host, (size_t)2 * nprod * sizeof(Fr)) != hipSuccess ||
+            hipMalloc(&pk->d_gp_items, nprod * sizeof(GpItem)) != hipSuccess)
+            return fail(ZK_ENOMEM);
+    }
     if (d.rc) return fail(d.rc);
     if (hipHostMalloc(&pk->tail_host, (pk->max_evals + 16) * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
     if (hipHostMalloc(&pk->rows_host, 64 * 8 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
@@ -607,21 +629,6 @@ struct Prover {
         for (uint32_t q = 0; q < cnt && ok(); q++)
             if (!tr->write_point(af[q])) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
     }
-    // z[0] = init, z[i+1] = z[i] * t_num[i] / t_den[i]
-    void grand_product(Fr* z, const Fr* init_dev) {
-        if (!ok()) return;
-        // ZKMI355_BATCH_INVERT=1 forces the fallback path (tests keep it covered)
-        const char* force = getenv("ZKMI355_BATCH_INVERT");
-        const int r = force && force[0] == '1'
-                          ? 1
-                          : launch_grand_product(pk->t_num, pk->t_den, z, n, init_dev, Fr::one(), pk->t_frac, pk->t_a,
-                                                 pk->t_small, c->host_small, st);
-        if (r < 0) return fail(ZK_EHIP);
-        if (r == 1) {  // a zero denominator: halo2's batch_invert semantics (0 -> 0)
-            launch_frac(pk->t_num, pk->t_den, pk->t_frac, n, st);
-            launch_prefix_product(pk->t_frac, z, n, init_dev, Fr::one(), pk->t_a, pk->t_small, st);
-        }
-    }
     // Lagrange values -> coefficients -> extended coset for a set of columns, several columns per launch
     struct Forms {
         const Fr* val;
@@ -764,6 +771,7 @@ struct Prover {
                 theta_done = true;
             }
         };
+        hipMemsetAsync(pk->lks.err, 0, 4, st);
         // a', s' of every lookup: batches of columns per MSM pass; their transforms (and, in the pipelined
         // case, the advice column's) follow the MSM heads so that they cover the tails
         LaneFifo lf{pipe ? std::vector<int>{1, 2} : std::vector<int>{0, 1, 2}, {}};
@@ -789,14 +797,6 @@ struct Prover {
                 inp = pk->adv_val[lay.n_gate + l];
             }
             launch_lookup_permute(inp, usable, T, pk->lks, pk->lk_ap[l], pk->lk_sp[l], st);
-            uint32_t err = 0;
-            if (hipMemcpyAsync(&err, pk->lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
-                return ZK_EHIP;
-            if (err) {
-                ctx_msm_drain(c);
-                return ZK_EWITNESS;  // lookup input not in table (halo2: ConstraintSystemFailure)
-            }
             set_rows(pk->lk_ap[l], usable, draw(bf + 1));
             set_rows(pk->lk_sp[l], usable, draw(bf + 1));
             draw(2);
@@ -807,6 +807,17 @@ struct Prover {
         }
         batch_flush(lb);
         lookup_transforms(pipe);
+        {
+            // one check for all lookups (the flag accumulates): an input outside the table is halo2's
+            // ConstraintSystemFailure; nothing has been written for the lookups yet
+            uint32_t* err = reinterpret_cast<uint32_t*>(c->host_small);
+            if (hipMemcpyAsync(err, pk->lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                return ZK_EHIP;
+            if (*err) {
+                ctx_msm_drain(c);
+                return ZK_EWITNESS;
+            }
+        }
         squeeze_theta();
         fifo_drain(lf);
         squeeze_theta();
@@ -835,9 +846,15 @@ struct Prover {
             zdue.clear();
         };
         {
+            // numerators / denominators of every product, then all scans in one batch; a zero denominator
+            // anywhere (or ZKMI355_BATCH_INVERT=1) sends every product down the batch-inversion path
+            const uint32_t nprod = lay.n_chunks + lay.n_lookups;
+            std::vector<GpItem> items(nprod);
+            std::vector<Fr*> zs;
+            const uint32_t nblk = gp_blocks(n);
             const Fr delta = fr_delta();
             Fr dcur = Fr::one();
-            for (uint32_t ci = 0; ci < lay.n_chunks && ok(); ci++) {
+            for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
                 PermArgs a;
                 memset(&a, 0, sizeof(a));
                 a.n = n;
@@ -852,29 +869,78 @@ struct Prover {
                 a.tw = tw;
                 a.beta = beta;
                 a.gamma = gamma;
-                a.num = pk->t_num;
-                a.den = pk->t_den;
+                a.num = pk->gp_num[ci];
+                a.den = pk->gp_den[ci];
                 launch_perm_numden(a, st);
-                // z[0] = previous chunk's z at row `usable` (or 1)
-                const Fr* init_dev = ci ? pk->z_val[ci - 1] + usable : nullptr;
-                grand_product(pk->z_val[ci], init_dev);
-                set_rows(pk->z_val[ci], n - bf, draw(bf));
+                zs.push_back(pk->z_val[ci]);
+            }
+            for (uint32_t l = 0; l < lay.n_lookups; l++) {
+                const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
+                const uint32_t p = lay.n_chunks + l;
+                launch_lk_numden(pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], beta, gamma, pk->gp_num[p], pk->gp_den[p], n,
+                                 st);
+                zs.push_back(pk->lk_z[l]);
+            }
+            for (uint32_t p = 0; p < nprod; p++) {
+                items[p].num = pk->gp_num[p];
+                items[p].den = pk->gp_den[p];
+                items[p].loc_p = pk->gp_loc_p[p];
+                items[p].loc_r = pk->gp_loc_r[p];
+                items[p].tot_p = pk->gp_tot + (size_t)2 * nblk * p;
+                items[p].tot_r = items[p].tot_p + nblk;
+                items[p].z = zs[p];
+                items[p].chain = (p > 0 && p < lay.n_chunks) ? 1u : 0u;  // chunk ci starts from chunk ci-1's z at row `usable`
+                items[p].pad_ = 0;
+            }
+            Fr* q_dev = pk->gp_scal;
+            Fr* qinv_dev = pk->gp_scal + nprod;
+            Fr* k_dev = pk->gp_scal + 2 * (size_t)nprod;
+            Fr* init_dev = pk->gp_scal + 3 * (size_t)nprod;
+            const char* force = getenv("ZKMI355_BATCH_INVERT");
+            bool fast = !(force && force[0] == '1');
+            if (fast) {
+                if (hipMemcpyAsync(pk->d_gp_items, items.data(), nprod * sizeof(GpItem), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
+                launch_gp_batch_scan(pk->d_gp_items, nprod, n, q_dev, st);
+                if (hipMemcpyAsync(pk->gp_host, q_dev, nprod * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return ZK_EHIP;
+                // all inverses with one field inversion
+                Fr* q = pk->gp_host;
+                Fr* qi = pk->gp_host + nprod;
+                Fr run = Fr::one();
+                for (uint32_t p = 0; p < nprod && fast; p++) {
+                    if (q[p].is_zero()) fast = false;
+                    qi[p] = run;
+                    run = fe_mul(run, q[p]);
+                }
+                if (fast) {
+                    Fr inv = fe_inv(run);
+                    for (uint32_t p = nprod; p-- > 0;) {
+                        const Fr t = fe_mul(inv, qi[p]);
+                        inv = fe_mul(inv, q[p]);
+                        qi[p] = t;
+                    }
+                    if (hipMemcpyAsync(qinv_dev, qi, nprod * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
+                    launch_gp_batch_apply(pk->d_gp_items, nprod, n, usable, qinv_dev, k_dev, init_dev, st);
+                }
+            }
+            if (!fast) {
+                // a zero denominator: halo2's batch_invert semantics (0 -> 0), product by product
+                for (uint32_t p = 0; p < nprod; p++) {
+                    launch_frac(pk->gp_num[p], pk->gp_den[p], pk->t_frac, n, st);
+                    const Fr* prev = items[p].chain ? zs[p - 1] + usable : nullptr;
+                    launch_prefix_product(pk->t_frac, zs[p], n, prev, Fr::one(), pk->t_a, pk->t_small, st);
+                }
+            }
+            // blinding rows and commitments, in halo2's order (chunks, then lookups)
+            for (uint32_t p = 0; p < nprod && ok(); p++) {
+                set_rows(zs[p], n - bf, draw(bf));
                 draw(1);
-                batch_add(zb, pk->z_val[ci]);
-                zdue.push_back(Forms{pk->z_val[ci], pk->z_poly[ci], pk->z_coset[ci]});
+                batch_add(zb, zs[p]);
+                if (p < lay.n_chunks) zdue.push_back(Forms{pk->z_val[p], pk->z_poly[p], pk->z_coset[p]});
+                else zdue.push_back(Forms{pk->lk_z[p - lay.n_chunks], pk->lk_z_poly[p - lay.n_chunks], pk->lk_z_coset[p - lay.n_chunks]});
                 if (zb.pend.empty()) z_transforms();
             }
-        }
-        // -- 4. lookup grand products
-        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
-            const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
-            launch_lk_numden(pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], beta, gamma, pk->t_num, pk->t_den, n, st);
-            grand_product(pk->lk_z[l], nullptr);
-            set_rows(pk->lk_z[l], n - bf, draw(bf));
-            draw(1);
-            batch_add(zb, pk->lk_z[l]);
-            zdue.push_back(Forms{pk->lk_z[l], pk->lk_z_poly[l], pk->lk_z_coset[l]});
-            if (zb.pend.empty()) z_transforms();
         }
         batch_flush(zb);
         z_transforms();

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void scan3_apply_kernel(const uint32_t* __rest
 
 void launch_lookup_permute(const Fr* inp, uint32_t usable, uint32_t T, LookupScratch& s, Fr* ap, Fr* sp, hipStream_t st) {
     hipMemsetAsync(s.hist, 0, (T + 1) * 4, st);
-    hipMemsetAsync(s.err, 0, 4, st);
+    // s.err accumulates over the lookups of a proof: the caller clears it once and reads it once
     hipLaunchKernelGGL(lk_hist_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, inp, usable, T, s.hist, s.err);
     hipLaunchKernelGGL(lk_flags_kernel, dim3((T + 255) / 256), dim3(256), 0, st, s.hist, T, s.present, s.absent);
     const uint32_t nblocks = (T + S3_BLOCK - 1) / S3_BLOCK;
@@ -456,30 +456,34 @@ void launch_prefix_product(const Fr* f, Fr* z, uint32_t n, const Fr* init_dev, c
     hipLaunchKernelGGL(pp_apply_kernel, dim3((n + PP_T - 1) / PP_T), dim3(PP_T), 0, st, tmp_local, tmp_tot, z, n);
 }
 
-// ---- grand product without per-element inversions ---------------------------------------------
+// ---- grand products without per-element inversions ------------------------------------------------
 // z[0] = init, z[i+1] = z[i] * num[i] / den[i]  ==>  z[i+1] = init * P_i * R_{i+1} / Q, with
 // P_i = prod_{j<=i} num_j, R_i = prod_{j>=i} den_j, Q = R_0.  Two block scans (one forward, one
-// backward) and ONE field inversion (on the host, 32 bytes each way) replace n batched inversions,
-// whose Fermat chains left the chip latency-bound.  A zero denominator (probability ~2^-230 under
-// random beta, gamma) makes Q zero: the caller then takes the batch-inversion path, which maps 0 -> 0
-// as halo2's batch_invert does.
-__global__ __launch_bounds__(PP_T) void gp_local_kernel(const Fr* __restrict__ num, const Fr* __restrict__ den,
-                                                        Fr* __restrict__ loc_p, Fr* __restrict__ loc_r,
-                                                        Fr* __restrict__ tot_p, Fr* __restrict__ tot_r, uint32_t n) {
+// backward) and ONE field inversion (on the host) replace n batched inversions, whose Fermat chains
+// left the chip latency-bound.  A zero denominator (probability ~2^-230 under random beta, gamma)
+// makes Q zero: the caller then takes the batch-inversion path (launch_frac + launch_prefix_product),
+// which maps 0 -> 0 as halo2's batch_invert does.
+// ---- all grand products of a proof at once -------------------------------------------------------
+// The same scheme with blockIdx.y = product: ONE host round trip (all Q's out, all inverses back) for
+// every permutation chunk and lookup of the proof.  A chained product (permutation chunk ci > 0) starts
+// from its predecessor's value at row `usable`; that value is a product of scan outputs, so a tiny kernel
+// walks the chain before the apply pass.
+__global__ __launch_bounds__(PP_T) void gp_local_batch_kernel(const GpItem* __restrict__ items, uint32_t n) {
+    const GpItem it = items[blockIdx.y];
     __shared__ Fr shp[PP_T], shr[PP_T];
     const uint32_t base = blockIdx.x * PP_B + threadIdx.x * PP_E;
     Fr v[PP_E], w[PP_E];
     Fr acc = Fr::one();
 #pragma unroll
     for (uint32_t k = 0; k < PP_E; k++) {
-        if (base + k < n) acc = fe_mul(acc, fe_load(num + base + k));
+        if (base + k < n) acc = fe_mul(acc, fe_load(it.num + base + k));
         v[k] = acc;
     }
     shp[threadIdx.x] = acc;
     acc = Fr::one();
 #pragma unroll
     for (int k = PP_E - 1; k >= 0; k--) {
-        if (base + k < n) acc = fe_mul(acc, fe_load(den + base + k));
+        if (base + k < n) acc = fe_mul(acc, fe_load(it.den + base + k));
         w[k] = acc;
     }
     shr[threadIdx.x] = acc;
@@ -500,33 +504,32 @@ __global__ __launch_bounds__(PP_T) void gp_local_kernel(const Fr* __restrict__ n
 #pragma unroll
     for (uint32_t k = 0; k < PP_E; k++)
         if (base + k < n) {
-            fe_store(loc_p + base + k, fe_mul(v[k], ep));
-            fe_store(loc_r + base + k, fe_mul(w[k], er));
+            fe_store(it.loc_p + base + k, fe_mul(v[k], ep));
+            fe_store(it.loc_r + base + k, fe_mul(w[k], er));
         }
-    if (threadIdx.x == PP_T - 1) fe_store(tot_p + blockIdx.x, shp[PP_T - 1]);
-    if (threadIdx.x == 0) fe_store(tot_r + blockIdx.x, shr[0]);
+    if (threadIdx.x == PP_T - 1) fe_store(it.tot_p + blockIdx.x, shp[PP_T - 1]);
+    if (threadIdx.x == 0) fe_store(it.tot_r + blockIdx.x, shr[0]);
 }
 
-// one workgroup: tot_p -> exclusive forward offsets (times init), tot_r -> exclusive backward offsets,
-// q_out = product of every denominator
-__global__ __launch_bounds__(1024) void gp_offsets_kernel(Fr* __restrict__ tot_p, Fr* __restrict__ tot_r, uint32_t nblocks,
-                                                          const Fr* __restrict__ init_ptr, Fr init_val, Fr* __restrict__ q_out) {
-    __shared__ Fr shp[1024], shr[1024];
-    const Fr init = init_ptr ? fe_load(init_ptr) : init_val;
-    const uint32_t chunk = (nblocks + 1023) / 1024;
+// one workgroup per product: block totals -> exclusive offsets (forward for P, backward for R); q_out[product] = Q
+__global__ __launch_bounds__(256) void gp_offsets_batch_kernel(const GpItem* __restrict__ items, uint32_t nblocks,
+                                                               Fr* __restrict__ q_out) {
+    const GpItem it = items[blockIdx.x];
+    __shared__ Fr shp[256], shr[256];
+    const uint32_t chunk = (nblocks + 255) / 256;
     const uint32_t lo = min(nblocks, threadIdx.x * chunk), hi = min(nblocks, lo + chunk);
     Fr ap = Fr::one(), ar = Fr::one();
     for (uint32_t i = lo; i < hi; i++) {
-        ap = fe_mul(ap, fe_load(tot_p + i));
-        ar = fe_mul(ar, fe_load(tot_r + i));
+        ap = fe_mul(ap, fe_load(it.tot_p + i));
+        ar = fe_mul(ar, fe_load(it.tot_r + i));
     }
     shp[threadIdx.x] = ap;
     shr[threadIdx.x] = ar;
     __syncthreads();
 #pragma unroll 1
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < 256; d <<= 1) {
         Fr op = Fr::one(), orr = Fr::one();
-        const bool hp = threadIdx.x >= d, hr = threadIdx.x + d < 1024;
+        const bool hp = threadIdx.x >= d, hr = threadIdx.x + d < 256;
         if (hp) op = shp[threadIdx.x - d];
         if (hr) orr = shr[threadIdx.x + d];
         __syncthreads();
@@ -534,51 +537,64 @@ __global__ __launch_bounds__(1024) void gp_offsets_kernel(Fr* __restrict__ tot_p
         if (hr) shr[threadIdx.x] = fe_mul(shr[threadIdx.x], orr);
         __syncthreads();
     }
-    if (threadIdx.x == 0) fe_store(q_out, shr[0]);
-    Fr run = fe_mul(init, threadIdx.x ? shp[threadIdx.x - 1] : Fr::one());
+    if (threadIdx.x == 0) fe_store(q_out + blockIdx.x, shr[0]);
+    Fr run = threadIdx.x ? shp[threadIdx.x - 1] : Fr::one();
     for (uint32_t i = lo; i < hi; i++) {
-        const Fr t = fe_load(tot_p + i);
-        fe_store(tot_p + i, run);
+        const Fr t = fe_load(it.tot_p + i);
+        fe_store(it.tot_p + i, run);
         run = fe_mul(run, t);
     }
-    run = threadIdx.x + 1 < 1024 ? shr[threadIdx.x + 1] : Fr::one();
+    run = threadIdx.x + 1 < 256 ? shr[threadIdx.x + 1] : Fr::one();
     for (uint32_t i = hi; i-- > lo;) {
-        const Fr t = fe_load(tot_r + i);
-        fe_store(tot_r + i, run);
+        const Fr t = fe_load(it.tot_r + i);
+        fe_store(it.tot_r + i, run);
         run = fe_mul(run, t);
     }
 }
 
-// z[0] = init; z[i+1] = q_inv * (off_p[b(i)] loc_p[i]) * (off_r[b(i+1)] loc_r[i+1])
-__global__ __launch_bounds__(PP_T) void gp_apply_kernel(const Fr* __restrict__ loc_p, const Fr* __restrict__ loc_r,
-                                                        const Fr* __restrict__ off_p, const Fr* __restrict__ off_r, Fr q_inv,
-                                                        Fr* __restrict__ z, uint32_t n) {
+// k[p] = init_p / Q_p with init_p = 1, or (chained) the predecessor's z at row `row` (1 <= row < n):
+// z_p[row] = k[p] * P_{row-1} * R_row
+__global__ void gp_chain_kernel(const GpItem* __restrict__ items, const Fr* __restrict__ q_inv, uint32_t nprod, uint32_t row,
+                                Fr* __restrict__ kout, Fr* __restrict__ init_out) {
+    if (blockIdx.x || threadIdx.x) return;
+    Fr carry = Fr::one();
+    for (uint32_t p = 0; p < nprod; p++) {
+        const GpItem it = items[p];
+        const Fr init = it.chain ? carry : Fr::one();
+        const Fr k = fe_mul(init, fe_load(q_inv + p));
+        fe_store(kout + p, k);
+        fe_store(init_out + p, init);
+        const Fr pfx = fe_mul(fe_load(it.tot_p + (row - 1) / PP_B), fe_load(it.loc_p + row - 1));
+        const Fr sfx = fe_mul(fe_load(it.tot_r + row / PP_B), fe_load(it.loc_r + row));
+        carry = fe_mul(k, fe_mul(pfx, sfx));
+    }
+}
+
+__global__ __launch_bounds__(PP_T) void gp_apply_batch_kernel(const GpItem* __restrict__ items, const Fr* __restrict__ kk,
+                                                              const Fr* __restrict__ init, uint32_t n) {
+    const GpItem it = items[blockIdx.y];
     const uint32_t i = blockIdx.x * PP_T + threadIdx.x;
     if (i >= n) return;
-    if (i == 0) fe_store(z, fe_load(off_p));  // = init
+    if (i == 0) fe_store(it.z, fe_load(init + blockIdx.y));
     if (i + 1 >= n) return;
-    const Fr pfx = fe_mul(fe_mul(fe_load(off_p + i / PP_B), q_inv), fe_load(loc_p + i));
-    const Fr sfx = fe_mul(fe_load(off_r + (i + 1) / PP_B), fe_load(loc_r + i + 1));
-    fe_store(z + i + 1, fe_mul(pfx, sfx));
+    const Fr pfx = fe_mul(fe_mul(fe_load(it.tot_p + i / PP_B), fe_load(kk + blockIdx.y)), fe_load(it.loc_p + i));
+    const Fr sfx = fe_mul(fe_load(it.tot_r + (i + 1) / PP_B), fe_load(it.loc_r + i + 1));
+    fe_store(it.z + i + 1, fe_mul(pfx, sfx));
 }
 
-// returns 0, or 1 if a denominator is zero (nothing written to z: use launch_frac + launch_prefix_product),
-// or a negative hipError-style failure.  tmp_p / tmp_r: n elements each; tmp_tot: 2 * blocks + 1 elements;
-// host_q: one pinned element.
-int launch_grand_product(const Fr* num, const Fr* den, Fr* z, uint32_t n, const Fr* init_dev, const Fr& init_val, Fr* tmp_p,
-                         Fr* tmp_r, Fr* tmp_tot, Fr* host_q, hipStream_t st) {
-    const uint32_t nblocks = (n + PP_B - 1) / PP_B;
-    Fr* tot_p = tmp_tot;
-    Fr* tot_r = tmp_tot + nblocks;
-    Fr* q = tmp_tot + 2 * nblocks;
-    hipLaunchKernelGGL(gp_local_kernel, dim3(nblocks), dim3(PP_T), 0, st, num, den, tmp_p, tmp_r, tot_p, tot_r, n);
-    hipLaunchKernelGGL(gp_offsets_kernel, dim3(1), dim3(1024), 0, st, tot_p, tot_r, nblocks, init_dev, init_val, q);
-    if (hipMemcpyAsync(host_q, q, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return -1;
-    if (host_q->is_zero()) return 1;
-    const Fr q_inv = fe_inv(*host_q);
-    hipLaunchKernelGGL(gp_apply_kernel, dim3((n + PP_T - 1) / PP_T), dim3(PP_T), 0, st, tmp_p, tmp_r, tot_p, tot_r, q_inv, z, n);
-    return 0;
+uint32_t gp_blocks(uint32_t n) { return (n + PP_B - 1) / PP_B; }
+
+// Phase 1: scans of every product; q_dev[p] = product of product p's denominators.
+void launch_gp_batch_scan(const GpItem* d_items, uint32_t nprod, uint32_t n, Fr* q_dev, hipStream_t st) {
+    const uint32_t nblocks = gp_blocks(n);
+    hipLaunchKernelGGL(gp_local_batch_kernel, dim3(nblocks, nprod), dim3(PP_T), 0, st, d_items, n);
+    hipLaunchKernelGGL(gp_offsets_batch_kernel, dim3(nprod), dim3(256), 0, st, d_items, nblocks, q_dev);
+}
+// Phase 2 (after the host inverted the q's into q_inv_dev): chain constants, then every z.
+void launch_gp_batch_apply(const GpItem* d_items, uint32_t nprod, uint32_t n, uint32_t chain_row, const Fr* q_inv_dev, Fr* k_dev,
+                           Fr* init_dev, hipStream_t st) {
+    hipLaunchKernelGGL(gp_chain_kernel, dim3(1), dim3(64), 0, st, d_items, q_inv_dev, nprod, chain_row, k_dev, init_dev);
+    hipLaunchKernelGGL(gp_apply_batch_kernel, dim3((n + PP_T - 1) / PP_T, nprod), dim3(PP_T), 0, st, d_items, k_dev, init_dev, n);
 }
 
 // ---------------------------------------------------------- Kate division ---
