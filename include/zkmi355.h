@@ -154,6 +154,8 @@ int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canoni
 #define ZK_T_QUOTIENT 2
 #define ZK_T_EVAL 3
 #define ZK_T_MSM_ACCUM 4 /* the bucket-accumulation kernel of the last MSM alone */
+#define ZK_T_MSM_COLUMNS 5 /* count only: scalar vectors (commitments) the accumulate launches served — a launch
+                              serves several columns when commitments are batched */
 #define ZK_T_COUNT 8
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
 /* accumulated HIP-event time and launch count since the last reset (ZK_T_MSM, ZK_T_MSM_ACCUM) */

@@ -158,6 +158,7 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
     if (L.n > 0 && hipEventElapsedTime(&ms, L.t_acc[0], L.t_acc[1]) == hipSuccess) {
         c->acc_ms[ZK_T_MSM_ACCUM] += ms;
         c->acc_n[ZK_T_MSM_ACCUM]++;
+        c->acc_n[ZK_T_MSM_COLUMNS] += L.batch;
         c->last_plain_ms[ZK_T_MSM_ACCUM] = ms;
     }
     return ZK_OK;

@@ -15,7 +15,7 @@ _LIB = None
 
 ZK_BASIS_MONOMIAL = 0
 ZK_BASIS_LAGRANGE = 1
-ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM = 0, 1, 2, 3, 4
+ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS = 0, 1, 2, 3, 4, 5
 
 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
