@@ -80,6 +80,7 @@ uint32_t msm_auto_window(size_t n) {
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     // measured on MI355X with whole proofs (tools/k17_timing.py, bench.py): 13 at 2^19, 12 at 2^16..2^18
     int c = lg >= 19 ? (int)lg - 6 : (lg >= 16 ? 12 : (int)lg - 5);
+    if (c > 14) c = lg >= 21 ? 15 : 14;  // 15-bit windows (two LDS sweeps per sort, 4x the bucket tail) pay from 2^21 up
     if (const char* e = getenv("ZKMI355_MSM_WINDOW")) c = atoi(e);  // tuning override
     if (c < 9) c = 9;
     if (c > 15) c = 15;  // digits are int16
@@ -629,9 +630,9 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
                    const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done) {
     if (n > ws->max_n || batch == 0 || batch > ws->max_batch) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
-    const bool fixed = table != nullptr && nb <= SORT_LDS_BUCKETS;
-    if (!fixed && batch != 1) return hipErrorInvalidValue;  // columns are batched over the resident SRS tables only
-    if (table && !fixed) table = nullptr;                   // (15-bit windows: generic path)
+    const bool fixed = table != nullptr;
+    const bool fused = fixed && nb <= SORT_LDS_BUCKETS;  // one-kernel digits + histogram; 15-bit windows take the swept sort
+    if (!fused && batch != 1) return hipErrorInvalidValue;  // columns are batched on the fused fixed-base path only
     const Fr* scalars = scalars_list[0];
     const uint32_t slices = fixed ? batch : nwin;
     const uint32_t nbt = slices * nb;
@@ -648,7 +649,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
         const uint32_t n32 = (uint32_t)n;
         const uint32_t stride = (uint32_t)ws->max_n;
         const uint32_t nchunks = (n32 + CHUNK - 1) / CHUNK;
-        if (fixed) {
+        if (fused) {
             const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
             MsmBatch mb;
             memset(&mb, 0, sizeof(mb));
