@@ -93,6 +93,10 @@ int zk_poly_copy(zk_ctx* ctx, zk_poly dst, zk_poly src);
 
 /* replaces ParamsKZG::commit / commit_lagrange (MSM against the resident SRS) + to_affine */
 int zk_commit(zk_ctx* ctx, zk_poly p, int basis, uint64_t out_affine_mont[8]);
+/* the same for `count` polynomials of one length: the columns share MSM passes (one bucket set per column, one
+ * accumulation launch for several columns) — how create_proof commits its advice columns, (a', s'), grand
+ * products and quotient pieces.  out: count x 8 limbs. */
+int zk_commit_batch(zk_ctx* ctx, const zk_poly* polys, size_t count, int basis, uint64_t* out_affine_mont);
 /* replaces EvaluationDomain::lagrange_to_coeff (in place: iNTT, x 1/n) */
 int zk_lagrange_to_coeff(zk_ctx* ctx, zk_poly p);
 /* replaces EvaluationDomain::coeff_to_lagrange (in place) */

@@ -193,6 +193,34 @@ def test_commit_tau_oracle_k19(engine):
     p.free()
 
 
+@pytest.mark.parametrize("k,count", [(10, 70), (14, 9), (17, 5), (19, 3)])
+def test_commit_batch_equals_single_commits(engine, k, count):
+    """Column-batched MSM passes (how the prover commits advice columns, grand products, h pieces): every
+    result equals the one-column commitment, both bases; columns include zeros, a sparse one and full ones;
+    `count` exceeds the per-pass batch at k = 10 and k = 19 (several passes)."""
+    n = 1 << k
+    engine.srs_setup(k)
+    rng = np.random.default_rng(k * 1000 + count)
+    polys = []
+    for j in range(count):
+        a = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+        a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        if j == 1:
+            a[:] = 0                      # the zero column commits to the identity
+        if j == 2:
+            a[:, 1:] = 0
+            a[:, 0] &= 0xFFFF             # small values: a few hot buckets
+            a[::3] = 0
+        polys.append(engine.poly(n, a))
+    for basis in (0, 1):
+        got = engine.commit_batch(polys, basis)
+        for j, p in enumerate(polys):
+            assert (got[j] == engine.commit(p, basis)).all(), (k, basis, j)
+        assert not got[1].any()
+    for p in polys:
+        p.free()
+
+
 # ------------------------------------------------------------ eval / coset ----
 
 @pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 4096, 70000])

@@ -674,6 +674,38 @@ int zk_commit(zk_ctx* c, zk_poly h, int basis, uint64_t out[8]) {
     return ZK_OK;
 }
 
+int zk_commit_batch(zk_ctx* c, const zk_poly* hs, size_t count, int basis, uint64_t* out) {
+    if (!c || !out || !hs || count == 0 || (basis != ZK_BASIS_MONOMIAL && basis != ZK_BASIS_LAGRANGE)) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->srs_k < 0) return ZK_ESTATE;
+    const size_t n = (size_t)1 << c->srs_k;
+    std::vector<const Fr*> ptrs(count);
+    size_t len = 0;
+    for (size_t i = 0; i < count; i++) {
+        PolyRec* r = find_poly(c, hs[i]);
+        if (!r || r->n > n || (i && r->n != len)) return ZK_EINVAL;  // one length per call
+        len = r->n;
+        ptrs[i] = r->ptr;
+    }
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    const G1Affine* bases = basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g;
+    const uint32_t cap = ctx_msm_max_batch(c);
+    G1Jac js[MSM_MAX_BATCH];
+    for (size_t i0 = 0; i0 < count; i0 += cap) {
+        const uint32_t cnt = (uint32_t)(count - i0 < cap ? count - i0 : cap);
+        rc = ctx_msm_begin_batch(c, 0, ptrs.data() + i0, cnt, bases, len);
+        if (rc) return rc;
+        rc = ctx_msm_end_batch(c, 0, js);
+        if (rc) return rc;
+        for (uint32_t q = 0; q < cnt; q++) {
+            const G1Affine a = g1_jac_to_affine_host(js[q]);
+            memcpy(out + (i0 + q) * 8, &a, 64);
+        }
+    }
+    return ZK_OK;
+}
+
 }  // extern "C"
 
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {

@@ -74,6 +74,7 @@ def load_library():
         "zk_poly_download": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
         "zk_poly_copy": ([vp, ctypes.c_uint64, ctypes.c_uint64], ctypes.c_int),
         "zk_commit": ([vp, ctypes.c_uint64, ctypes.c_int, u64p], ctypes.c_int),
+        "zk_commit_batch": ([vp, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.c_int, u64p], ctypes.c_int),
         "zk_lagrange_to_coeff": ([vp, ctypes.c_uint64], ctypes.c_int),
         "zk_coeff_to_lagrange": ([vp, ctypes.c_uint64], ctypes.c_int),
         "zk_coeff_to_extended": ([vp, ctypes.c_uint64, ctypes.c_uint64], ctypes.c_int),
@@ -211,6 +212,12 @@ class Engine:
     def commit(self, p, basis):
         out = np.zeros(8, dtype=np.uint64)
         self._chk(self.L.zk_commit(self.ctx, p.h, basis, _p(out)), "zk_commit")
+        return out
+
+    def commit_batch(self, polys, basis):
+        hs = (ctypes.c_uint64 * len(polys))(*[p.h for p in polys])
+        out = np.zeros((len(polys), 8), dtype=np.uint64)
+        self._chk(self.L.zk_commit_batch(self.ctx, hs, len(polys), basis, _p(out)), "zk_commit_batch")
         return out
 
     def lagrange_to_coeff(self, p):
