@@ -479,22 +479,36 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
 // ---------------------------------------------------------------- reduce ---
 // sum_j j * B_j = sum_t 2^t * G_t with G_t = sum of the buckets whose multiplier j has
 // bit t set: c tree reductions per bucket set instead of 2^(c-1) scalar multiplications.
-// grid = slices * c * BITSUM_SPLIT workgroups, each covering a quarter of the buckets;
-// the host adds the BITSUM_SPLIT partials and runs the c-term Horner.
-static constexpr uint32_t BITSUM_SPLIT = 4;
-static constexpr uint32_t BITSUM_THREADS = 512;
-__global__ __launch_bounds__(BITSUM_THREADS) void msm_bitsum_kernel(const G1X* __restrict__ part, uint32_t parts, uint32_t nb,
-                                                                    uint32_t c, G1X* __restrict__ out) {
-    __shared__ G1X sh[BITSUM_THREADS / 64];
-    const uint32_t q = blockIdx.x % BITSUM_SPLIT;
-    const uint32_t st = blockIdx.x / BITSUM_SPLIT;
+// grid = slices * c * split workgroups of THREADS lanes, one multiplier per lane: the shape follows the
+// bucket count (2^(c-1) / 2 multipliers per bit: 4 x 512 lanes at c = 13, 1 x 128 at c = 9), so that the
+// tree is no deeper than the data and small bucket sets do not launch idle waves.  The host adds the
+// `split` partials of a bit and runs the c-term Horner.
+static constexpr uint32_t BITSUM_MAX_SPLIT = 4;
+static uint32_t bitsum_threads(uint32_t nb) {
+    uint32_t t = nb >> 1;  // multipliers per bit
+    if (t < 64) t = 64;
+    if (t > 512) t = 512;
+    return t;
+}
+static uint32_t bitsum_split(uint32_t nb) {
+    uint32_t s = (nb >> 1) / 512;
+    if (s < 1) s = 1;
+    if (s > BITSUM_MAX_SPLIT) s = BITSUM_MAX_SPLIT;
+    return s;
+}
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X* __restrict__ part, uint32_t parts, uint32_t nb,
+                                                             uint32_t c, uint32_t split, G1X* __restrict__ out) {
+    __shared__ G1X sh[THREADS / 64];
+    const uint32_t q = blockIdx.x % split;
+    const uint32_t st = blockIdx.x / split;
     const uint32_t slice = st / c, t = st - slice * c;
     G1X acc = G1X::identity();
     // the multipliers j in [1, nb] with bit t set, enumerated densely (no lane idles on a clear bit):
     // t < c-1: j = i with a 1 inserted at bit t, i < nb/2;  t = c-1: j = nb only
     const uint32_t items = t + 1 < c ? nb >> 1 : 1;
 #pragma unroll 1
-    for (uint32_t i = q * BITSUM_THREADS + threadIdx.x; i < items; i += BITSUM_THREADS * BITSUM_SPLIT) {
+    for (uint32_t i = q * THREADS + threadIdx.x; i < items; i += THREADS * split) {
         const uint32_t j = t + 1 < c ? (((i >> t) << (t + 1)) | (1u << t) | (i & ((1u << t) - 1))) : nb;
         const G1X* src = part + ((size_t)slice * nb + (j - 1)) * parts;
 #pragma unroll 1
@@ -504,14 +518,16 @@ __global__ __launch_bounds__(BITSUM_THREADS) void msm_bitsum_kernel(const G1X* _
         }
     }
     group_sum(acc, 64);
-    const uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) g1x_store(sh + wave, acc);
-    __syncthreads();
-    if (wave == 0) {
-        acc = (threadIdx.x < BITSUM_THREADS / 64) ? g1x_load(sh + threadIdx.x) : G1X::identity();
-        group_sum(acc, BITSUM_THREADS / 64);
-        if (threadIdx.x == 0) g1x_store(out + blockIdx.x, acc);
+    if (THREADS > 64) {
+        const uint32_t wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) g1x_store(sh + wave, acc);
+        __syncthreads();
+        if (wave == 0) {
+            acc = (threadIdx.x < THREADS / 64) ? g1x_load(sh + threadIdx.x) : G1X::identity();
+            group_sum(acc, THREADS / 64);
+        }
     }
+    if (threadIdx.x == 0) g1x_store(out + blockIdx.x, acc);
 }
 
 // ------------------------------------------------------ fixed-base tables ---
@@ -602,7 +618,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
-    MSM_TRY(hipMalloc(&ws->bit_sum, slices * c * BITSUM_SPLIT * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->bit_sum, slices * c * BITSUM_MAX_SPLIT * sizeof(G1X)));
     return ws;
 }
 
@@ -705,22 +721,30 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
             hipLaunchKernelGGL(msm_gather_kernel<4>, dim3((ngroups * 4 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
                                ws->partial, parts, ngroups, ws->part);
     }
-    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(slices * c * BITSUM_SPLIT), dim3(BITSUM_THREADS), 0, ts, ws->part, parts, nb, c,
-                       ws->bit_sum);
+    const uint32_t bt = bitsum_threads(nb), bs = bitsum_split(nb);
+    if (bt == 512)
+        hipLaunchKernelGGL(msm_bitsum_kernel<512>, dim3(slices * c * bs), dim3(512), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+    else if (bt == 256)
+        hipLaunchKernelGGL(msm_bitsum_kernel<256>, dim3(slices * c * bs), dim3(256), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+    else if (bt == 128)
+        hipLaunchKernelGGL(msm_bitsum_kernel<128>, dim3(slices * c * bs), dim3(128), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+    else
+        hipLaunchKernelGGL(msm_bitsum_kernel<64>, dim3(slices * c * bs), dim3(64), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * BITSUM_SPLIT * sizeof(G1X),
+    return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * bs * sizeof(G1X),
                           hipMemcpyDeviceToHost, ts);
 }
 
-// bit_sums[(w * c + t) * BITSUM_SPLIT + q]: partials of G_{w,t};
+// bit_sums[(w * c + t) * split + q]: partials of G_{w,t}, split = bitsum_split(2^(c-1));
 // result = sum_w 2^(c w) sum_t 2^t G_{w,t}  (Horner over all bit positions)
-uint32_t msm_sums_per_result(uint32_t c) { return c * BITSUM_SPLIT; }
+uint32_t msm_sums_per_result(uint32_t c) { return c * bitsum_split(1u << (c - 1)); }
 
 G1Jac msm_finish_host(const G1X* bit_sums, uint32_t nwin, uint32_t c) {
+    const uint32_t split = bitsum_split(1u << (c - 1));
     G1X acc = G1X::identity();
     for (int q = (int)(nwin * c) - 1; q >= 0; q--) {
         if (!acc.is_identity()) acc = g1x_dbl(acc);
-        for (uint32_t k = 0; k < BITSUM_SPLIT; k++) g1x_add(acc, bit_sums[(size_t)q * BITSUM_SPLIT + k]);
+        for (uint32_t k = 0; k < split; k++) g1x_add(acc, bit_sums[(size_t)q * split + k]);
     }
     return g1x_to_jac(acc);
 }

@@ -553,20 +553,40 @@ __global__ __launch_bounds__(256) void gp_offsets_batch_kernel(const GpItem* __r
 }
 
 // k[p] = init_p / Q_p with init_p = 1, or (chained) the predecessor's z at row `row` (1 <= row < n):
-// z_p[row] = k[p] * P_{row-1} * R_row
-__global__ void gp_chain_kernel(const GpItem* __restrict__ items, const Fr* __restrict__ q_inv, uint32_t nprod, uint32_t row,
-                                Fr* __restrict__ kout, Fr* __restrict__ init_out) {
-    if (blockIdx.x || threadIdx.x) return;
-    Fr carry = Fr::one();
-    for (uint32_t p = 0; p < nprod; p++) {
+// z_p[row] = k[p] * P_{row-1} * R_row.  The chained products are the leading run of the list (the
+// permutation chunks): init_p = prod_{j<p} (P_{j,row-1} R_{j,row} / Q_j) — one lane per product and a
+// block scan.  nprod <= 256.
+__global__ __launch_bounds__(256) void gp_chain_kernel(const GpItem* __restrict__ items, const Fr* __restrict__ q_inv, uint32_t nprod,
+                                                       uint32_t row, Fr* __restrict__ kout, Fr* __restrict__ init_out) {
+    __shared__ Fr sh[256];
+    const uint32_t p = threadIdx.x;
+    Fr v = Fr::one(), qi = Fr::one();
+    bool chained_next = false;  // does product p + 1 start from this one?
+    if (p < nprod) {
         const GpItem it = items[p];
-        const Fr init = it.chain ? carry : Fr::one();
-        const Fr k = fe_mul(init, fe_load(q_inv + p));
-        fe_store(kout + p, k);
+        qi = fe_load(q_inv + p);
+        chained_next = p + 1 < nprod && items[p + 1].chain;
+        if (chained_next) {
+            const Fr pfx = fe_mul(fe_load(it.tot_p + (row - 1) / PP_B), fe_load(it.loc_p + row - 1));
+            const Fr sfx = fe_mul(fe_load(it.tot_r + row / PP_B), fe_load(it.loc_r + row));
+            v = fe_mul(qi, fe_mul(pfx, sfx));
+        }
+    }
+    sh[p] = v;  // 1 outside the chain: the inclusive scan below is then the chain's running product
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        Fr o = Fr::one();
+        const bool has = p >= d;
+        if (has) o = sh[p - d];
+        __syncthreads();
+        if (has) sh[p] = fe_mul(sh[p], o);
+        __syncthreads();
+    }
+    if (p < nprod) {
+        const Fr init = (p && items[p].chain) ? sh[p - 1] : Fr::one();
         fe_store(init_out + p, init);
-        const Fr pfx = fe_mul(fe_load(it.tot_p + (row - 1) / PP_B), fe_load(it.loc_p + row - 1));
-        const Fr sfx = fe_mul(fe_load(it.tot_r + row / PP_B), fe_load(it.loc_r + row));
-        carry = fe_mul(k, fe_mul(pfx, sfx));
+        fe_store(kout + p, fe_mul(init, qi));
     }
 }
 
@@ -593,7 +613,7 @@ void launch_gp_batch_scan(const GpItem* d_items, uint32_t nprod, uint32_t n, Fr*
 // Phase 2 (after the host inverted the q's into q_inv_dev): chain constants, then every z.
 void launch_gp_batch_apply(const GpItem* d_items, uint32_t nprod, uint32_t n, uint32_t chain_row, const Fr* q_inv_dev, Fr* k_dev,
                            Fr* init_dev, hipStream_t st) {
-    hipLaunchKernelGGL(gp_chain_kernel, dim3(1), dim3(64), 0, st, d_items, q_inv_dev, nprod, chain_row, k_dev, init_dev);
+    hipLaunchKernelGGL(gp_chain_kernel, dim3(1), dim3(256), 0, st, d_items, q_inv_dev, nprod, chain_row, k_dev, init_dev);
     hipLaunchKernelGGL(gp_apply_batch_kernel, dim3((n + PP_T - 1) / PP_T, nprod), dim3(PP_T), 0, st, d_items, k_dev, init_dev, n);
 }
 
