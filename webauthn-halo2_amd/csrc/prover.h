@@ -100,6 +100,14 @@ uint32_t gp_blocks(uint32_t n);
 void launch_gp_batch_scan(const GpItem* d_items, uint32_t nprod, uint32_t n, Fr* q_dev, hipStream_t st);
 void launch_gp_batch_apply(const GpItem* d_items, uint32_t nprod, uint32_t n, uint32_t chain_row, const Fr* q_inv_dev, Fr* k_dev,
                            Fr* init_dev, hipStream_t st);
+// a short run of rows of one column (blinding rows), staged on the host
+struct RowEntry {
+    Fr vals[8];
+    Fr* dst;
+    uint32_t count;
+    uint32_t pad_;
+};
+void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t st);
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st);
 void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
 

@@ -85,6 +85,8 @@ struct Layout {
 
 }  // namespace
 
+static constexpr uint32_t ROWS_CAP = 512, ROWS_BLOCKS = 16;  // staged row writes per flush / flushes per ring
+
 struct zk_pk_rec {
     Layout lay;
     std::vector<Fr*> dev;  // every device allocation (freed together)
@@ -100,7 +102,8 @@ struct zk_pk_rec {
     Fr *random_poly = nullptr, *h_ext = nullptr, *h_comb = nullptr;
     Fr *t_num = nullptr, *t_den = nullptr, *t_frac = nullptr, *t_a = nullptr, *t_b = nullptr, *t_small = nullptr;
     Fr* tail_host = nullptr;  // pinned staging for evaluations / scalars
-    Fr* rows_host = nullptr;  // pinned ring for blinding rows (Prover::set_rows)
+    RowEntry* rows_host = nullptr;  // pinned: ROWS_BLOCKS blocks of ROWS_CAP staged row writes (Prover::set_rows)
+    RowEntry* rows_dev = nullptr;
     LookupScratch lks{};
     uint32_t* lk_u32 = nullptr;
     // all grand products of a proof in one batch (launch_gp_batch_*)
@@ -214,6 +217,7 @@ void pk_destroy(zk_pk_rec* pk) {
     for (Fr* p : pk->dev) hipFree(p);
     if (pk->tail_host) hipHostFree(pk->tail_host);
     if (pk->rows_host) hipHostFree(pk->rows_host);
+    if (pk->rows_dev) hipFree(pk->rows_dev);
     if (pk->lk_u32) hipFree(pk->lk_u32);
     if (pk->gp_host) hipHostFree(pk->gp_host);
     if (pk->d_gp_items) hipFree(pk->d_gp_items);
@@ -435,7 +439,9 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     }
     if (d.rc) return fail(d.rc);
     if (hipHostMalloc(&pk->tail_host, (pk->max_evals + 16) * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
-    if (hipHostMalloc(&pk->rows_host, 64 * 8 * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->rows_host, (size_t)ROWS_BLOCKS * ROWS_CAP * sizeof(RowEntry)) != hipSuccess ||
+        hipMalloc(&pk->rows_dev, (size_t)ROWS_BLOCKS * ROWS_CAP * sizeof(RowEntry)) != hipSuccess)
+        return fail(ZK_ENOMEM);
     if (hipHostMalloc(&pk->h_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess ||
         hipMalloc(&pk->d_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess)
         return fail(ZK_ENOMEM);
@@ -506,8 +512,7 @@ struct Prover {
     const Fr *tw, *tw_ext;
     Fr omega, omega_inv;
     int rc = ZK_OK;
-    static constexpr uint32_t ROWS_RING = 64, ROWS_SLOT = 8;  // slots of BLINDING_FACTORS + 1 elements
-    uint32_t rows_slot = 0;
+    uint32_t rows_block = 0, rows_count = 0;  // staged row writes: current block of the ring, entries in it
 
     Prover(zk_ctx* c_, zk_pk_rec* pk_, const uint8_t seed[32], Transcript* t)
         : c(c_), pk(pk_), lay(pk_->lay), st(c_->stream), rng(seed), tr(t), n(pk_->lay.n), N(4 * pk_->lay.n) {}
@@ -518,18 +523,31 @@ struct Prover {
     }
 
     // ---- device helpers
-    // blinding rows: staged through a ring of pinned slots so the host does not wait for the stream
-    // (it only does when the ring wraps)
+    // Blinding rows are staged on the host and written by rows_flush() — one upload and one launch for all
+    // the columns of a phase — before the first kernel that reads those columns (commit_begin_batch and
+    // transforms() flush; other readers call rows_flush() themselves).
     void set_rows(Fr* col, uint32_t first, const std::vector<Fr>& vals) {
         if (!ok()) return;
-        if (vals.size() > ROWS_SLOT) return fail(ZK_ESTATE);
-        if (rows_slot == ROWS_RING) {
+        if (vals.size() > 8) return fail(ZK_ESTATE);
+        if (rows_count == ROWS_CAP) rows_flush();
+        RowEntry& e = pk->rows_host[(size_t)rows_block * ROWS_CAP + rows_count++];
+        memcpy(e.vals, vals.data(), vals.size() * sizeof(Fr));
+        e.dst = col + first;
+        e.count = (uint32_t)vals.size();
+        e.pad_ = 0;
+    }
+    void rows_flush() {
+        if (!ok() || rows_count == 0) return;
+        RowEntry* h = pk->rows_host + (size_t)rows_block * ROWS_CAP;
+        RowEntry* d = pk->rows_dev + (size_t)rows_block * ROWS_CAP;
+        if (hipMemcpyAsync(d, h, rows_count * sizeof(RowEntry), hipMemcpyHostToDevice, st) != hipSuccess) return fail(ZK_EHIP);
+        launch_scatter_rows(d, rows_count, st);
+        rows_count = 0;
+        if (++rows_block == ROWS_BLOCKS) {
+            // the ring wraps: the oldest block's upload must have been consumed before it is overwritten
             if (hipStreamSynchronize(st) != hipSuccess) return fail(ZK_EHIP);
-            rows_slot = 0;
+            rows_block = 0;
         }
-        Fr* slot = pk->rows_host + (size_t)rows_slot++ * ROWS_SLOT;
-        memcpy(slot, vals.data(), vals.size() * sizeof(Fr));
-        if (hipMemcpyAsync(col + first, slot, vals.size() * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) fail(ZK_EHIP);
     }
     // commitments in flight over a set of MSM lanes, collected (written to the transcript) in the
     // order they were begun
@@ -593,6 +611,7 @@ struct Prover {
     void commit_begin(int lane, const Fr* poly, size_t len, int basis) { commit_begin_batch(lane, {poly}, len, basis); }
     // several columns against the same basis in ONE MSM pass (at most ctx_msm_max_batch of them)
     void commit_begin_batch(int lane, const std::vector<const Fr*>& polys, size_t len, int basis) {
+        rows_flush();
         if (!ok()) return;
         int r = ctx_msm_begin_batch(c, lane, polys.data(), (uint32_t)polys.size(), basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g,
                                     len);
@@ -636,6 +655,7 @@ struct Prover {
         Fr* coset;
     };
     void transforms(const std::vector<Forms>& cols) {
+        rows_flush();
         if (!ok() || cols.empty()) return;
         const uint32_t b1 = ctx_ntt_max_batch(lay.k), b2 = ctx_ntt_max_batch(lay.ext_k);
         const Fr* src[NTT_MAX_BATCH];
@@ -1233,6 +1253,7 @@ struct Prover {
                     return ZK_EHIP;
                 for (size_t t = 0; t < pts.size(); t++) lowc[t] = fe_sub(pk->tail_host[t], rsum[t]);
                 set_rows(pk->t_a, 0, lowc);
+                rows_flush();
                 Fr* src = pk->t_a;
                 Fr* dst = pk->t_b;
                 for (const Fr& z : pts) {

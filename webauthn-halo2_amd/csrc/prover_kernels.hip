@@ -617,6 +617,15 @@ void launch_gp_batch_apply(const GpItem* d_items, uint32_t nprod, uint32_t n, ui
     hipLaunchKernelGGL(gp_apply_batch_kernel, dim3((n + PP_T - 1) / PP_T, nprod), dim3(PP_T), 0, st, d_items, k_dev, init_dev, n);
 }
 
+// ---- staged row writes: blinding rows of many columns in one upload + one launch --------------------
+__global__ __launch_bounds__(64) void scatter_rows_kernel(const RowEntry* __restrict__ e) {
+    const RowEntry* r = e + blockIdx.x;
+    if (threadIdx.x < r->count) fe_store(r->dst + threadIdx.x, fe_load(r->vals + threadIdx.x));
+}
+void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t st) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(count), dim3(64), 0, st, d_entries);
+}
+
 // ---------------------------------------------------------- Kate division ---
 // q = (p - p(z)) / (X - z):  q[i-1] = p[i] + z*q[i], q[n-1] = 0.  Chunks of KD_L
 // coefficients per thread: (1) chunk value c_t = sum_i p[tL+i] z^i, (2) suffix Horner
