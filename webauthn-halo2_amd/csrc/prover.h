@@ -22,6 +22,8 @@ struct LincombArgs {
     Fr* out;
     uint32_t n, count, accumulate, sub0;
     Fr sub0_val;  // subtracted from coefficient 0
+    uint32_t sub_low_n, pad_[3];
+    Fr sub_low[8];  // subtracted from coefficients 0 .. sub_low_n - 1 (a low-degree remainder polynomial)
     const Fr* in[MAX_LC];
     uint32_t len[MAX_LC];
     uint32_t unit[MAX_LC];  // coefficient is 1
@@ -108,7 +110,11 @@ struct RowEntry {
     uint32_t pad_;
 };
 void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t st);
-void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st);
+static constexpr uint32_t KD_MAX_BATCH = 6;  // divisions per launch (SHPLONK / GWC have at most six rotation sets)
+uint32_t kate_division_scratch(uint32_t n);  // elements of scratch per division
+void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* scratch, hipStream_t st);
+void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, uint32_t count, uint32_t n, Fr* scratch,
+                                hipStream_t st);
 void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
 
 // poly.hip

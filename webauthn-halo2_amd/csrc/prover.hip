@@ -101,6 +101,7 @@ struct zk_pk_rec {
         lk_in_coset;
     Fr *random_poly = nullptr, *h_ext = nullptr, *h_comb = nullptr;
     Fr *t_num = nullptr, *t_den = nullptr, *t_frac = nullptr, *t_a = nullptr, *t_b = nullptr, *t_small = nullptr;
+    Fr* kd_scratch = nullptr;  // Kate divisions: KD_MAX_BATCH x kate_division_scratch(n)
     Fr* tail_host = nullptr;  // pinned staging for evaluations / scalars
     RowEntry* rows_host = nullptr;  // pinned: ROWS_BLOCKS blocks of ROWS_CAP staged row writes (Prover::set_rows)
     RowEntry* rows_dev = nullptr;
@@ -423,6 +424,7 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->t_a = d.alloc(n);
     pk->t_b = d.alloc(n);
     pk->t_small = d.alloc(n / 16 + 8192);
+    pk->kd_scratch = d.alloc((size_t)KD_MAX_BATCH * kate_division_scratch(n));
     {
         const uint32_t nprod = lay.n_chunks + lay.n_lookups;
         for (uint32_t p = 0; p < nprod; p++) {
@@ -705,7 +707,8 @@ struct Prover {
         const Fr* poly;
         Fr c;
     };
-    void lincomb_many(Fr* out, const std::vector<Term>& terms, bool sub0, const Fr& sub0_val, bool accumulate_first = false) {
+    void lincomb_many(Fr* out, const std::vector<Term>& terms, bool sub0, const Fr& sub0_val, bool accumulate_first = false,
+                      const std::vector<Fr>* sub_low = nullptr) {
         size_t done = 0;
         bool first = !accumulate_first;
         do {
@@ -726,6 +729,10 @@ struct Prover {
             if (done == terms.size() && sub0) {
                 a.sub0 = 1;
                 a.sub0_val = sub0_val;
+            }
+            if (done == terms.size() && sub_low) {
+                a.sub_low_n = (uint32_t)sub_low->size();
+                for (size_t t = 0; t < sub_low->size(); t++) a.sub_low[t] = (*sub_low)[t];
             }
             launch_lincomb(a, st);
             first = false;
@@ -1158,6 +1165,7 @@ struct Prover {
             LaneFifo wf{{0, 1, 2}, {}};
             Batcher wb{&wf, ZK_BASIS_MONOMIAL, max_batch, {}};
             size_t set_idx = 0;
+            Fr pts[6];
             for (auto& s : sets) {
                 std::vector<Term> terms;
                 Fr pv = Fr::one(), eb = Fr::zero();
@@ -1166,12 +1174,14 @@ struct Prover {
                     eb = fe_add(eb, fe_mul(pv, qq.eval));
                     pv = fe_mul(pv, v);
                 }
-                lincomb_many(pk->t_a, terms, true, eb);
-                launch_kate_division(pk->t_a, wbuf[set_idx], n, xrot(x, s.first), pk->t_small, pk->t_small + (n / 32 + 8), st);
-                batch_add(wb, wbuf[set_idx]);
+                lincomb_many(wbuf[set_idx], terms, true, eb);
+                pts[set_idx] = xrot(x, s.first);
                 set_idx++;
                 if (!ok()) return rc;
             }
+            // every set's (sum v^i p_i - sum v^i e_i) / (X - point) in one batched division, in place
+            launch_kate_division_batch(wbuf, wbuf, pts, (uint32_t)set_idx, n, pk->kd_scratch, st);
+            for (size_t i = 0; i < set_idx; i++) batch_add(wb, wbuf[i]);
             batch_flush(wb);
             fifo_drain(wf);
         } else {
@@ -1229,11 +1239,15 @@ struct Prover {
             const Fr v = tr->squeeze();
             std::vector<std::vector<Fr>> low(com.size());
             auto com_index = [&](CR* p) { return (size_t)(p - &com[0]); };
-            // h(X) = sum_i v^i * ( sum_j y^j (P_ij - R_ij) ) / Z_i
-            Fr pv = Fr::one();
-            Fr* hx = pk->t_frac;  // accumulates h(X)
-            bool first_set = true;
-            for (auto& rs : rsets) {
+            // h(X) = sum_i v^i * ( sum_j y^j (P_ij - R_ij) ) / Z_i.  Every rotation set has its own buffer (the h pieces
+            // are free by now); step s divides, in ONE batched launch, every set that still has a point left by it.
+            Fr* hx = pk->t_frac;  // h(X)
+            Fr* sbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
+            if (rsets.size() > 6) return ZK_ESTATE;
+            std::vector<std::vector<Fr>> set_pts;
+            size_t max_pts = 0;
+            for (size_t si = 0; si < rsets.size(); si++) {
+                auto& rs = rsets[si];
                 std::vector<Fr> pts;
                 for (int r : rs.rots) pts.push_back(xrot(x, r));
                 std::vector<Term> terms;
@@ -1245,34 +1259,32 @@ struct Prover {
                     for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
                     py = fe_mul(py, yc);
                 }
-                lincomb_many(pk->t_a, terms, false, Fr::zero());
-                // subtract sum_j y^j R_j(X) (degree < |set|) from the low coefficients
-                std::vector<Fr> lowc(pts.size());
-                if (hipMemcpyAsync(pk->tail_host, pk->t_a, pts.size() * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess)
-                    return ZK_EHIP;
-                for (size_t t = 0; t < pts.size(); t++) lowc[t] = fe_sub(pk->tail_host[t], rsum[t]);
-                set_rows(pk->t_a, 0, lowc);
-                rows_flush();
-                Fr* src = pk->t_a;
-                Fr* dst = pk->t_b;
-                for (const Fr& z : pts) {
-                    launch_kate_division(src, dst, n, z, pk->t_small, pk->t_small + (n / 32 + 8), st);
-                    std::swap(src, dst);
+                // sum_j y^j P_j(X) minus sum_j y^j R_j(X) (degree < |set|: a few low coefficients, known on the host)
+                if (pts.size() > 8) return ZK_ESTATE;
+                lincomb_many(sbuf[si], terms, false, Fr::zero(), false, &rsum);
+                max_pts = std::max(max_pts, pts.size());
+                set_pts.push_back(pts);
+            }
+            for (size_t step = 0; step < max_pts; step++) {
+                Fr* bufs[6];
+                Fr zs[6];
+                uint32_t cnt = 0;
+                for (size_t si = 0; si < rsets.size(); si++)
+                    if (step < set_pts[si].size()) {
+                        bufs[cnt] = sbuf[si];
+                        zs[cnt] = set_pts[si][step];
+                        cnt++;
+                    }
+                launch_kate_division_batch(bufs, bufs, zs, cnt, n, pk->kd_scratch, st);
+            }
+            {
+                std::vector<Term> terms;
+                Fr pv = Fr::one();
+                for (size_t si = 0; si < rsets.size(); si++) {
+                    terms.push_back(Term{sbuf[si], pv});
+                    pv = fe_mul(pv, v);
                 }
-                LincombArgs acc;
-                memset(&acc, 0, sizeof(acc));
-                acc.out = hx;
-                acc.n = n;
-                acc.count = 1;
-                acc.accumulate = first_set ? 0 : 1;
-                acc.in[0] = src;
-                acc.len[0] = n;
-                acc.c[0] = pv;
-                acc.unit[0] = first_set ? 1 : 0;
-                launch_lincomb(acc, st);
-                first_set = false;
-                pv = fe_mul(pv, v);
+                lincomb_many(hx, terms, false, Fr::zero());
             }
             commit_write(hx, n, ZK_BASIS_MONOMIAL);
             if (!ok()) return rc;
@@ -1280,7 +1292,7 @@ struct Prover {
             // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
             std::vector<Term> terms;
             Fr sub = Fr::zero();
-            pv = Fr::one();
+            Fr pv = Fr::one();
             std::vector<Fr> z_diffs;
             for (auto& rs : rsets) {
                 std::vector<Fr> diffs;
@@ -1302,7 +1314,7 @@ struct Prover {
             const Fr zt = vanishing_eval(all_pts, u);
             terms.push_back(Term{hx, fe_neg(zt)});
             lincomb_many(pk->t_a, terms, true, sub);
-            launch_kate_division(pk->t_a, pk->t_b, n, u, pk->t_small, pk->t_small + (n / 32 + 8), st);
+            launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
             launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
             commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
         }

@@ -10,6 +10,8 @@
 // poly), `arithmetic::kate_division` and the polynomial sums in
 // `poly/kzg/multiopen/{gwc,shplonk}/prover.rs` (SURVEY.md §8a a9, §8f-2, §8f-3;
 // reached from halo2-circuits/src/ecc/ecdsa_p256.rs:366-373,416-423).
+#include <string.h>
+
 #include "prover.h"
 
 namespace zk {
@@ -44,6 +46,7 @@ __global__ void lincomb_kernel(LincombArgs a) {
         }
     }
     if (i == 0 && a.sub0) acc = fe_sub(acc, a.sub0_val);
+    if (i < a.sub_low_n) acc = fe_sub(acc, a.sub_low[i]);
     fe_store(a.out + i, acc);
 }
 void launch_lincomb(const LincombArgs& a, hipStream_t st) {
@@ -630,12 +633,40 @@ void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t 
 // q = (p - p(z)) / (X - z):  q[i-1] = p[i] + z*q[i], q[n-1] = 0.  Chunks of KD_L
 // coefficients per thread: (1) chunk value c_t = sum_i p[tL+i] z^i, (2) suffix Horner
 // over chunks carry_t = c_{t+1} + z^L carry_{t+1}, (3) replay each chunk from its carry.
+// Up to KD_MAX_BATCH independent divisions per launch (blockIdx.y): SHPLONK divides every rotation
+// set's polynomial by that set's next point in the same step.  q may be p (in place).
 static constexpr uint32_t KD_L = 32;
+static constexpr uint32_t KD_BLK = 256;
 
-__global__ void kd_chunk_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, Fr* __restrict__ cval) {
+struct KdPtrs {
+    const Fr* p[KD_MAX_BATCH];
+    Fr* q[KD_MAX_BATCH];
+    Fr z[KD_MAX_BATCH];
+};
+struct KdStep {
+    Fr step[KD_MAX_BATCH][8];  // Z^(2^j), j = 0..7, Z = z^KD_L
+};
+struct KdTop {
+    Fr top[KD_MAX_BATCH][12];  // (Z^256)^(2^j)
+};
+struct KdZ {
+    Fr Z[KD_MAX_BATCH];
+};
+
+// per-division scratch: cval[m] | suf[m] | agg[nblk] | G[nblk] | zpow[256]
+__host__ __device__ inline uint32_t kd_scratch_elems(uint32_t n) {
+    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
+    return 2 * m + 2 * nblk + 256;
+}
+uint32_t kate_division_scratch(uint32_t n) { return kd_scratch_elems(n); }
+
+__global__ void kd_chunk_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = t * KD_L;
     if (base >= n) return;
+    const Fr* __restrict__ p = a.p[blockIdx.y];
+    const Fr z = a.z[blockIdx.y];
+    Fr* cval = scratch + (size_t)blockIdx.y * kd_scratch_elems(n);
     const uint32_t top = min(n, base + KD_L);
     Fr acc = Fr::zero();
     for (uint32_t i = top; i-- > base;) acc = fe_add(fe_mul(acc, z), fe_load(p + i));
@@ -648,16 +679,12 @@ __global__ void kd_chunk_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, Fr* 
 //                  block aggregate S_B = suf[first]
 //   kd_top         G_B = S_{B+1} + Z^256 G_{B+1} (carry entering block B from above), one workgroup
 //   kd_apply       K_t = suf[t+1] (same block) + Z^(last_in_block - t) G_B
-static constexpr uint32_t KD_BLK = 256;
-
-struct KdPowers {
-    Fr step[8];   // Z^(2^j), j = 0..7
-    Fr top[12];   // (Z^256)^(2^j)
-};
-
-__global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(const Fr* __restrict__ cval, uint32_t m, KdPowers pw,
-                                                               Fr* __restrict__ suf, Fr* __restrict__ agg) {
+__global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(KdStep pw, uint32_t n, Fr* __restrict__ scratch) {
     __shared__ Fr sh[KD_BLK];
+    const uint32_t m = (n + KD_L - 1) / KD_L;
+    Fr* cval = scratch + (size_t)blockIdx.y * kd_scratch_elems(n);
+    Fr* suf = cval + m;
+    Fr* agg = suf + m;
     const uint32_t t = blockIdx.x * KD_BLK + threadIdx.x;
     Fr v = t < m ? fe_load(cval + t) : Fr::zero();
     sh[threadIdx.x] = v;
@@ -669,7 +696,7 @@ __global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(const Fr* __restr
         if (has) o = sh[threadIdx.x + d];
         __syncthreads();
         if (has) {
-            v = fe_add(v, fe_mul(o, pw.step[j]));
+            v = fe_add(v, fe_mul(o, pw.step[blockIdx.y][j]));
             sh[threadIdx.x] = v;
         }
         __syncthreads();
@@ -678,9 +705,12 @@ __global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(const Fr* __restr
     if (threadIdx.x == 0) fe_store(agg + blockIdx.x, v);
 }
 
-// G[B] = sum_{B' > B} S_{B'} (Z^256)^(B'-B-1); nblk <= 1024
-__global__ __launch_bounds__(1024) void kd_top_kernel(const Fr* __restrict__ agg, uint32_t nblk, KdPowers pw, Fr* __restrict__ G) {
+// G[B] = sum_{B' > B} S_{B'} (Z^256)^(B'-B-1); nblk <= 1024.  blockIdx.x = division.
+__global__ __launch_bounds__(1024) void kd_top_kernel(KdTop pw, uint32_t n, Fr* __restrict__ scratch) {
     __shared__ Fr sh[1024];
+    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
+    Fr* agg = scratch + (size_t)blockIdx.x * kd_scratch_elems(n) + 2 * m;
+    Fr* G = agg + nblk;
     // inclusive suffix scan of S with multiplier Z^256, then shift by one
     Fr v = threadIdx.x < nblk ? fe_load(agg + threadIdx.x) : Fr::zero();
     sh[threadIdx.x] = v;
@@ -692,7 +722,7 @@ __global__ __launch_bounds__(1024) void kd_top_kernel(const Fr* __restrict__ agg
         if (has) o = sh[threadIdx.x + d];
         __syncthreads();
         if (has) {
-            v = fe_add(v, fe_mul(o, pw.top[j]));
+            v = fe_add(v, fe_mul(o, pw.top[blockIdx.x][j]));
             sh[threadIdx.x] = v;
         }
         __syncthreads();
@@ -700,27 +730,36 @@ __global__ __launch_bounds__(1024) void kd_top_kernel(const Fr* __restrict__ agg
     if (threadIdx.x < nblk) fe_store(G + threadIdx.x, threadIdx.x + 1 < nblk ? sh[threadIdx.x + 1] : Fr::zero());
 }
 
-__global__ void kd_apply_kernel(const Fr* __restrict__ p, uint32_t n, Fr z, const Fr* __restrict__ suf,
-                                const Fr* __restrict__ G, const Fr* __restrict__ zpow, uint32_t m, Fr* __restrict__ q) {
+__global__ void kd_apply_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = t * KD_L;
     if (base >= n) return;
+    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
+    const Fr* __restrict__ p = a.p[blockIdx.y];
+    Fr* __restrict__ q = a.q[blockIdx.y];
+    const Fr z = a.z[blockIdx.y];
+    const Fr* suf = scratch + (size_t)blockIdx.y * kd_scratch_elems(n) + m;
+    const Fr* G = suf + m + nblk;
+    const Fr* zpow = G + nblk;
     const uint32_t top = min(n, base + KD_L);
     // carry into chunk t: chunks above it in the same block + everything above the block
     const uint32_t blk = t / KD_BLK;
     const uint32_t last = min(m, (blk + 1) * KD_BLK) - 1;
     Fr run = (t < last) ? fe_load(suf + t + 1) : Fr::zero();
     run = fe_add(run, fe_mul(fe_load(zpow + (last - t)), fe_load(G + blk)));
-    // run = q[top - 1]; walk down: q[i-1] = p[i] + z q[i]
+    // run = q[top - 1]; walk down: q[i-1] = p[i] + z q[i]  (p[i] is read before q[i] is written: q may be p)
     for (uint32_t i = top; i-- > base;) {
+        const Fr pi = fe_load(p + i);
         fe_store(q + i, run);
-        run = fe_add(fe_mul(run, z), fe_load(p + i));
+        run = fe_add(fe_mul(run, z), pi);
     }
 }
 
-// zpow[i] = Z^i, i < 256 (one workgroup)
-__global__ __launch_bounds__(256) void kd_zpow_kernel(Fr Z, Fr* __restrict__ zpow) {
-    Fr acc = Fr::one(), base = Z;
+// zpow[i] = Z^i, i < 256 (one workgroup per division)
+__global__ __launch_bounds__(256) void kd_zpow_kernel(KdZ zz, uint32_t n, Fr* __restrict__ scratch) {
+    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
+    Fr* zpow = scratch + (size_t)blockIdx.x * kd_scratch_elems(n) + 2 * m + 2 * nblk;
+    Fr acc = Fr::one(), base = zz.Z[blockIdx.x];
     for (uint32_t e = threadIdx.x; e; e >>= 1) {
         if (e & 1) acc = fe_mul(acc, base);
         base = fe_sqr(base);
@@ -728,33 +767,46 @@ __global__ __launch_bounds__(256) void kd_zpow_kernel(Fr Z, Fr* __restrict__ zpo
     fe_store(zpow + threadIdx.x, acc);
 }
 
-// tmp: cval[m] | suf[m] | agg[nblk] | G[nblk] | zpow[256]  (m = ceil(n / 32), nblk = ceil(m / 256) <= 1024)
-void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* tmp_c, Fr* tmp_carry, hipStream_t st) {
+// `count` <= KD_MAX_BATCH divisions q[i] = (p[i] - p[i](z[i])) / (X - z[i]); scratch: count * kate_division_scratch(n)
+void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, uint32_t count, uint32_t n, Fr* scratch,
+                                hipStream_t st) {
     const uint32_t m = (n + KD_L - 1) / KD_L;
     const uint32_t nblk = (m + KD_BLK - 1) / KD_BLK;
-    Fr* cval = tmp_c;
-    Fr* suf = tmp_carry;
-    Fr* agg = suf + m;
-    Fr* G = agg + nblk;
-    Fr* zpow = G + nblk;
-    Fr Z = z;
-    for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^32
-    KdPowers pw;
-    Fr cur = Z;
-    for (int j = 0; j < 8; j++) {
-        pw.step[j] = cur;
-        cur = fe_sqr(cur);
+    KdPtrs pt;
+    KdStep stp;
+    KdTop tp;
+    KdZ zz;
+    memset(&pt, 0, sizeof(pt));
+    memset(&stp, 0, sizeof(stp));
+    memset(&tp, 0, sizeof(tp));
+    memset(&zz, 0, sizeof(zz));
+    for (uint32_t b = 0; b < count; b++) {
+        pt.p[b] = p[b];
+        pt.q[b] = q[b];
+        pt.z[b] = z[b];
+        Fr Z = z[b];
+        for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^32
+        zz.Z[b] = Z;
+        Fr cur = Z;
+        for (int j = 0; j < 8; j++) {
+            stp.step[b][j] = cur;
+            cur = fe_sqr(cur);
+        }
+        // cur = Z^256
+        for (int j = 0; j < 12; j++) {
+            tp.top[b][j] = cur;
+            cur = fe_sqr(cur);
+        }
     }
-    // cur = Z^256
-    for (int j = 0; j < 12; j++) {
-        pw.top[j] = cur;
-        cur = fe_sqr(cur);
-    }
-    hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, cval);
-    hipLaunchKernelGGL(kd_zpow_kernel, dim3(1), dim3(256), 0, st, Z, zpow);
-    hipLaunchKernelGGL(kd_block_scan_kernel, dim3(nblk), dim3(KD_BLK), 0, st, cval, m, pw, suf, agg);
-    hipLaunchKernelGGL(kd_top_kernel, dim3(1), dim3(1024), 0, st, agg, nblk, pw, G);
-    hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256), dim3(256), 0, st, p, n, z, suf, G, zpow, m, q);
+    hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st, pt, n, scratch);
+    hipLaunchKernelGGL(kd_zpow_kernel, dim3(count), dim3(256), 0, st, zz, n, scratch);
+    hipLaunchKernelGGL(kd_block_scan_kernel, dim3(nblk, count), dim3(KD_BLK), 0, st, stp, n, scratch);
+    hipLaunchKernelGGL(kd_top_kernel, dim3(count), dim3(1024), 0, st, tp, n, scratch);
+    hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st, pt, n, scratch);
+}
+
+void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* scratch, hipStream_t st) {
+    launch_kate_division_batch(&p, &q, &z, 1, n, scratch, st);
 }
 
 }  // namespace zk
