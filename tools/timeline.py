@@ -30,8 +30,11 @@ for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:18]:
 for k, (d, c) in agg.items():
     tot += d
 print("sum", tot / 1e6)
-tails = ("msm_gather1", "msm_gather<16u>", "msm_gather<4u>", "msm_bitsum")
-main = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, nm(r)) for r in seg if nm(r) not in tails]
+def is_tail(k):
+    return k.startswith("msm_gather") or k.startswith("msm_bitsum")
+
+
+main = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, nm(r)) for r in seg if not is_tail(nm(r))]
 allk = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, nm(r)) for r in seg]
 
 
