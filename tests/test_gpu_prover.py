@@ -21,6 +21,10 @@ SHAPES = {
     "k18like": (2, 1, 1, 6, 4),
     "wide": (3, 2, 2, 8, 6),
     "idle": (5, 2, 2, 7, 5, 2),  # two trailing gate columns never enabled (the k <= 13 bench rows)
+    # k >= 10: the SRS window tables exist, so commitments go through the column-batched MSM passes (and the
+    # batched transforms / grand products / divisions) that the full-size proofs use
+    "k10batched": (3, 2, 1, 10, 8),
+    "k10single": (1, 1, 1, 10, 9),
 }
 KIND = {"evm": E.ZK_TRANSCRIPT_EVM, "blake2b": E.ZK_TRANSCRIPT_BLAKE2B}
 
