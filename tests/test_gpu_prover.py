@@ -159,6 +159,7 @@ BENCH_ROWS = [
     (13, 68, 12, 1, 12, 24960, 1),
     (12, 139, 24, 2, 11, 50496, 2),
     (11, 291, 53, 4, 10, 106496, 3),
+    (20, 1, 1, 1, 19, 960, 0),  # not a reference row: one size above BASELINE's k=19 (same single-column shape)
 ]
 
 
