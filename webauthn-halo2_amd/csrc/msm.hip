@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void msm_sort_kernel(const int16_t* __restrict
 // ---- fixed-base mode: every window feeds ONE bucket set, so a workgroup owns a chunk of scalars with
 // ALL their windows: digit extraction and the LDS histogram are one kernel, and the scatter re-reads the
 // digits it wrote (5 launches per MSM head instead of 10).
-static constexpr uint32_t FCHUNK = 1024;  // scalars per workgroup (x nwin entries)
+#ifndef ZK_FCHUNK
+#define ZK_FCHUNK 1024
+#endif
+static constexpr uint32_t FCHUNK = ZK_FCHUNK;  // scalars per workgroup (x nwin entries)
 
 __device__ __forceinline__ uint32_t msm_digits_of(const uint32_t* L, uint32_t c, uint32_t nwin, uint32_t i, uint32_t stride,
                                                   int16_t* __restrict__ digits, uint32_t* hist) {
@@ -261,14 +264,34 @@ __global__ __launch_bounds__(256) void msm_scatter_fixed_kernel(const int16_t* _
     }
     __syncthreads();
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    constexpr uint32_t PER = FCHUNK / 256;  // scalars per thread
+    // the digits of window w + 1 are loaded while those of window w are scattered (the loop is otherwise a
+    // chain of load -> LDS atomic -> store latencies at two waves per SIMD)
+    int32_t cur[PER], nxt[PER];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t i = lo + threadIdx.x + q * 256;
+        cur[q] = i < hi ? digits[i] : 0;
+    }
     for (uint32_t w = 0; w < nwin; w++) {
-        const int16_t* dg = digits + (size_t)w * stride;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-            const int32_t d = dg[i];
+        if (w + 1 < nwin) {
+            const int16_t* dg = digits + (size_t)(w + 1) * stride;
+#pragma unroll
+            for (uint32_t q = 0; q < PER; q++) {
+                const uint32_t i = lo + threadIdx.x + q * 256;
+                nxt[q] = i < hi ? dg[i] : 0;
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            const int32_t d = cur[q];
             if (d == 0) continue;
+            const uint32_t i = lo + threadIdx.x + q * 256;
             const uint32_t pos = atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
             entries[pos] = (w * table_stride + i) | (d < 0 ? SIGN_BIT : 0);
         }
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) cur[q] = nxt[q];
     }
 }
 
