@@ -35,8 +35,15 @@ struct ChaChaKey {
 };
 
 struct LookupScratch {
-    uint32_t *hist, *present, *absent, *off, *dex, *aex, *err;  // T + 1 entries each (err: 1)
-    uint32_t* bsum;  // 3 x ceil(T / 1024) block sums
+    uint32_t *hist, *present, *absent, *off, *dex, *aex;  // lookup 0's arrays, T + 1 entries each
+    uint32_t* bsum;    // 3 x ceil(T / 1024) block sums
+    uint32_t* err;     // one flag for all lookups
+    uint32_t stride;   // words between the arrays of consecutive lookups
+};
+struct LkPtrs {
+    const Fr* inp[MAX_LOOKUPS];
+    Fr* ap[MAX_LOOKUPS];
+    Fr* sp[MAX_LOOKUPS];
 };
 
 struct PermArgs {
@@ -79,7 +86,7 @@ void launch_lincomb(const LincombArgs& a, hipStream_t st);
 void launch_scale(Fr* a, const Fr& c, uint32_t n, hipStream_t st);
 void launch_chacha_fr(const ChaChaKey& key, uint64_t start_block, Fr* out, uint32_t count, hipStream_t st);
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t st);
-void launch_lookup_permute(const Fr* inp, uint32_t usable, uint32_t T, LookupScratch& s, Fr* ap, Fr* sp, hipStream_t st);
+void launch_lookup_permute(const LkPtrs& ptrs, uint32_t count, uint32_t usable, uint32_t T, LookupScratch& s, hipStream_t st);
 void launch_perm_numden(const PermArgs& a, hipStream_t st);
 void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, const Fr& beta, const Fr& gamma, Fr* num,
                       Fr* den, uint32_t n, hipStream_t st);

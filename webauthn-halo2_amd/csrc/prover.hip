@@ -450,8 +450,10 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     pk->ev_scratch = d.alloc((size_t)pk->max_evals * eval_blocks(n));
     pk->ev_out = d.alloc(pk->max_evals);
     if (d.rc) return fail(d.rc);
-    if (hipMalloc(&pk->lk_u32, (size_t)(T + 2) * 6 * 4 + 16 + (size_t)3 * (T / 1024 + 2) * 4) != hipSuccess) return fail(ZK_ENOMEM);
     {
+        // per lookup: six arrays of T + 2 words and 3 x blocks block sums; one error flag for all
+        const uint32_t stride = 6 * (T + 2) + 3 * (T / 1024 + 2);
+        if (hipMalloc(&pk->lk_u32, ((size_t)stride * lay.n_lookups + 4) * 4) != hipSuccess) return fail(ZK_ENOMEM);
         uint32_t* b = pk->lk_u32;
         pk->lks.hist = b;
         pk->lks.present = b + (T + 2);
@@ -459,8 +461,9 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
         pk->lks.off = b + 3 * (T + 2);
         pk->lks.dex = b + 4 * (T + 2);
         pk->lks.aex = b + 5 * (T + 2);
-        pk->lks.err = b + 6 * (T + 2);
-        pk->lks.bsum = b + 6 * (T + 2) + 4;
+        pk->lks.bsum = b + 6 * (T + 2);
+        pk->lks.stride = stride;
+        pk->lks.err = b + (size_t)stride * lay.n_lookups;
     }
     if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess) return fail(ZK_ENOMEM);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
@@ -815,15 +818,23 @@ struct Prover {
             due.clear();
         };
         if (!pipe) squeeze_theta();  // the advice commitments are all written: theta precedes the first a'
-        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
-            const Fr* inp;
-            if (lay.single) {
-                launch_mul(pk->lk_in[l], pk->fixed_val[lay.fx_qlookup], pk->adv_val[0], n, st);
-                inp = pk->lk_in[l];
-            } else {
-                inp = pk->adv_val[lay.n_gate + l];
+        {
+            // every lookup's permuted input / table pair in one set of launches (blockIdx.y = lookup)
+            LkPtrs lp;
+            memset(&lp, 0, sizeof(lp));
+            for (uint32_t l = 0; l < lay.n_lookups; l++) {
+                if (lay.single) {
+                    launch_mul(pk->lk_in[l], pk->fixed_val[lay.fx_qlookup], pk->adv_val[0], n, st);
+                    lp.inp[l] = pk->lk_in[l];
+                } else {
+                    lp.inp[l] = pk->adv_val[lay.n_gate + l];
+                }
+                lp.ap[l] = pk->lk_ap[l];
+                lp.sp[l] = pk->lk_sp[l];
             }
-            launch_lookup_permute(inp, usable, T, pk->lks, pk->lk_ap[l], pk->lk_sp[l], st);
+            launch_lookup_permute(lp, lay.n_lookups, usable, T, pk->lks, st);
+        }
+        for (uint32_t l = 0; l < lay.n_lookups && ok(); l++) {
             set_rows(pk->lk_ap[l], usable, draw(bf + 1));
             set_rows(pk->lk_sp[l], usable, draw(bf + 1));
             draw(2);

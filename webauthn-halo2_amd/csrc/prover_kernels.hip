@@ -136,8 +136,12 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t 
 // rows 0..T-1 and zeros up to the usable rows (halo2-lib RangeConfig; known answer
 // K2).  hist[v] = multiplicity of v in the first `usable` input rows; err set if an
 // input is not a table element (halo2: Error::ConstraintSystemFailure).
-__global__ __launch_bounds__(256) void lk_hist_kernel(const Fr* __restrict__ inp, uint32_t usable, uint32_t T,
-                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ err) {
+// All lookups of a proof go through these kernels together: blockIdx.y = lookup, whose scratch arrays sit
+// `stride` words after the previous lookup's.
+__global__ __launch_bounds__(256) void lk_hist_kernel(LkPtrs ptrs, uint32_t usable, uint32_t T, uint32_t* __restrict__ hist0,
+                                                      uint32_t stride, uint32_t* __restrict__ err) {
+    const Fr* __restrict__ inp = ptrs.inp[blockIdx.y];
+    uint32_t* __restrict__ hist = hist0 + (size_t)blockIdx.y * stride;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t val = 0xffffffffu;  // not a table element / out of range
     if (i < usable) {
@@ -159,8 +163,11 @@ __global__ __launch_bounds__(256) void lk_hist_kernel(const Fr* __restrict__ inp
 }
 
 // present[v] = hist[v] > 0 ; absent[v] = (v >= 1 && hist[v] == 0)
-__global__ void lk_flags_kernel(const uint32_t* __restrict__ hist, uint32_t T, uint32_t* __restrict__ present,
-                                uint32_t* __restrict__ absent) {
+__global__ void lk_flags_kernel(const uint32_t* __restrict__ hist0, uint32_t T, uint32_t* __restrict__ present0,
+                                uint32_t* __restrict__ absent0, uint32_t stride) {
+    const uint32_t* __restrict__ hist = hist0 + (size_t)blockIdx.y * stride;
+    uint32_t* __restrict__ present = present0 + (size_t)blockIdx.y * stride;
+    uint32_t* __restrict__ absent = absent0 + (size_t)blockIdx.y * stride;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= T) return;
     const uint32_t h = hist[v];
@@ -175,9 +182,15 @@ __device__ __forceinline__ Fr small_to_mont(uint32_t v) {
 }
 
 // off: exclusive scan of hist (T+1); dex: exclusive scan of present (T+1); aex: exclusive scan of absent (T+1)
-__global__ void lk_fill_kernel(uint32_t usable, uint32_t T, const uint32_t* __restrict__ hist,
-                               const uint32_t* __restrict__ off, const uint32_t* __restrict__ dex,
-                               const uint32_t* __restrict__ aex, Fr* __restrict__ ap, Fr* __restrict__ sp) {
+__global__ void lk_fill_kernel(uint32_t usable, uint32_t T, const uint32_t* __restrict__ hist0,
+                               const uint32_t* __restrict__ off0, const uint32_t* __restrict__ dex0,
+                               const uint32_t* __restrict__ aex0, uint32_t stride, LkPtrs ptrs) {
+    const uint32_t* __restrict__ hist = hist0 + (size_t)blockIdx.y * stride;
+    const uint32_t* __restrict__ off = off0 + (size_t)blockIdx.y * stride;
+    const uint32_t* __restrict__ dex = dex0 + (size_t)blockIdx.y * stride;
+    const uint32_t* __restrict__ aex = aex0 + (size_t)blockIdx.y * stride;
+    Fr* __restrict__ ap = ptrs.ap[blockIdx.y];
+    Fr* __restrict__ sp = ptrs.sp[blockIdx.y];
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= usable) return;
     // largest v with off[v] <= p
@@ -216,9 +229,14 @@ __global__ void lk_fill_kernel(uint32_t usable, uint32_t T, const uint32_t* __re
 // (1) per-block sums, (2) one small block scans the block sums, (3) block-local scan + offset.
 static constexpr uint32_t S3_BLOCK = 1024;  // elements per block (256 threads x 4)
 
-__global__ __launch_bounds__(256) void scan3_sums_kernel(const uint32_t* __restrict__ a0, const uint32_t* __restrict__ a1,
-                                                         const uint32_t* __restrict__ a2, uint32_t m,
-                                                         uint32_t* __restrict__ bsum /* [3][nblocks] */, uint32_t nblocks) {
+__global__ __launch_bounds__(256) void scan3_sums_kernel(const uint32_t* __restrict__ b0, const uint32_t* __restrict__ b1,
+                                                         const uint32_t* __restrict__ b2, uint32_t m,
+                                                         uint32_t* __restrict__ bsum0 /* [3][nblocks] */, uint32_t nblocks,
+                                                         uint32_t stride) {
+    const uint32_t* __restrict__ a0 = b0 + (size_t)blockIdx.y * stride;
+    const uint32_t* __restrict__ a1 = b1 + (size_t)blockIdx.y * stride;
+    const uint32_t* __restrict__ a2 = b2 + (size_t)blockIdx.y * stride;
+    uint32_t* __restrict__ bsum = bsum0 + (size_t)blockIdx.y * stride;
     __shared__ uint32_t sh[3][256];
     const uint32_t base = blockIdx.x * S3_BLOCK + threadIdx.x * 4;
     uint32_t s0 = 0, s1 = 0, s2 = 0;
@@ -240,8 +258,9 @@ __global__ __launch_bounds__(256) void scan3_sums_kernel(const uint32_t* __restr
     if (threadIdx.x < 3) bsum[threadIdx.x * nblocks + blockIdx.x] = sh[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(1024) void scan3_top_kernel(uint32_t* __restrict__ bsum, uint32_t nblocks) {
-    // exclusive scan of each of the 3 rows in place; nblocks <= 1024 * 8
+__global__ __launch_bounds__(1024) void scan3_top_kernel(uint32_t* __restrict__ bsum0, uint32_t nblocks, uint32_t stride) {
+    // exclusive scan of each of the 3 rows in place; nblocks <= 1024 * 8; blockIdx.x = lookup
+    uint32_t* __restrict__ bsum = bsum0 + (size_t)blockIdx.x * stride;
     __shared__ uint32_t part[1024];
     for (int q = 0; q < 3; q++) {
         uint32_t* row = bsum + q * nblocks;
@@ -267,11 +286,19 @@ __global__ __launch_bounds__(1024) void scan3_top_kernel(uint32_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void scan3_apply_kernel(const uint32_t* __restrict__ a0, const uint32_t* __restrict__ a1,
-                                                          const uint32_t* __restrict__ a2, uint32_t m,
-                                                          const uint32_t* __restrict__ bsum, uint32_t nblocks,
-                                                          uint32_t* __restrict__ o0, uint32_t* __restrict__ o1,
-                                                          uint32_t* __restrict__ o2) {
+__global__ __launch_bounds__(256) void scan3_apply_kernel(const uint32_t* __restrict__ b0, const uint32_t* __restrict__ b1,
+                                                          const uint32_t* __restrict__ b2, uint32_t m,
+                                                          const uint32_t* __restrict__ bsum0, uint32_t nblocks,
+                                                          uint32_t* __restrict__ p0, uint32_t* __restrict__ p1,
+                                                          uint32_t* __restrict__ p2, uint32_t stride) {
+    const size_t shift = (size_t)blockIdx.y * stride;
+    const uint32_t* __restrict__ a0 = b0 + shift;
+    const uint32_t* __restrict__ a1 = b1 + shift;
+    const uint32_t* __restrict__ a2 = b2 + shift;
+    const uint32_t* __restrict__ bsum = bsum0 + shift;
+    uint32_t* __restrict__ o0 = p0 + shift;
+    uint32_t* __restrict__ o1 = p1 + shift;
+    uint32_t* __restrict__ o2 = p2 + shift;
     __shared__ uint32_t sh[3][256];
     const uint32_t base = blockIdx.x * S3_BLOCK + threadIdx.x * 4;
     uint32_t v[3][4];
@@ -307,17 +334,20 @@ __global__ __launch_bounds__(256) void scan3_apply_kernel(const uint32_t* __rest
     }
 }
 
-void launch_lookup_permute(const Fr* inp, uint32_t usable, uint32_t T, LookupScratch& s, Fr* ap, Fr* sp, hipStream_t st) {
-    hipMemsetAsync(s.hist, 0, (T + 1) * 4, st);
+// `count` lookups at once; s: the scratch of lookup 0, lookup l's arrays `s.stride` words further each
+void launch_lookup_permute(const LkPtrs& ptrs, uint32_t count, uint32_t usable, uint32_t T, LookupScratch& s, hipStream_t st) {
+    hipMemsetAsync(s.hist, 0, ((size_t)(count - 1) * s.stride + T + 1) * 4, st);  // every hist (the other arrays are rewritten)
     // s.err accumulates over the lookups of a proof: the caller clears it once and reads it once
-    hipLaunchKernelGGL(lk_hist_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, inp, usable, T, s.hist, s.err);
-    hipLaunchKernelGGL(lk_flags_kernel, dim3((T + 255) / 256), dim3(256), 0, st, s.hist, T, s.present, s.absent);
+    hipLaunchKernelGGL(lk_hist_kernel, dim3((usable + 255) / 256, count), dim3(256), 0, st, ptrs, usable, T, s.hist, s.stride, s.err);
+    hipLaunchKernelGGL(lk_flags_kernel, dim3((T + 255) / 256, count), dim3(256), 0, st, s.hist, T, s.present, s.absent, s.stride);
     const uint32_t nblocks = (T + S3_BLOCK - 1) / S3_BLOCK;
-    hipLaunchKernelGGL(scan3_sums_kernel, dim3(nblocks), dim3(256), 0, st, s.hist, s.present, s.absent, T, s.bsum, nblocks);
-    hipLaunchKernelGGL(scan3_top_kernel, dim3(1), dim3(1024), 0, st, s.bsum, nblocks);
-    hipLaunchKernelGGL(scan3_apply_kernel, dim3(nblocks), dim3(256), 0, st, s.hist, s.present, s.absent, T, s.bsum, nblocks,
-                       s.off, s.dex, s.aex);
-    hipLaunchKernelGGL(lk_fill_kernel, dim3((usable + 255) / 256), dim3(256), 0, st, usable, T, s.hist, s.off, s.dex, s.aex, ap, sp);
+    hipLaunchKernelGGL(scan3_sums_kernel, dim3(nblocks, count), dim3(256), 0, st, s.hist, s.present, s.absent, T, s.bsum, nblocks,
+                       s.stride);
+    hipLaunchKernelGGL(scan3_top_kernel, dim3(count), dim3(1024), 0, st, s.bsum, nblocks, s.stride);
+    hipLaunchKernelGGL(scan3_apply_kernel, dim3(nblocks, count), dim3(256), 0, st, s.hist, s.present, s.absent, T, s.bsum, nblocks,
+                       s.off, s.dex, s.aex, s.stride);
+    hipLaunchKernelGGL(lk_fill_kernel, dim3((usable + 255) / 256, count), dim3(256), 0, st, usable, T, s.hist, s.off, s.dex, s.aex,
+                       s.stride, ptrs);
 }
 
 // -------------------------------------------------------- grand products ----
