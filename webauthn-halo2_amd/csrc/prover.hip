@@ -560,7 +560,6 @@ struct Prover {
         std::vector<int> lanes;
         std::deque<int> busy;
     };
-    void fifo_begin(LaneFifo& f, const Fr* poly, size_t len, int basis) { fifo_begin_batch(f, {poly}, len, basis); }
     void fifo_begin_batch(LaneFifo& f, const std::vector<const Fr*>& polys, size_t len, int basis) {
         if (!ok() || polys.empty()) return;
         if (f.busy.size() == f.lanes.size()) {
@@ -684,27 +683,6 @@ struct Prover {
             if (r) fail(r);
         }
     }
-    void to_coeff(const Fr* val, Fr* poly) {
-        if (!ok()) return;
-        int r = ctx_ntt(c, val, n, poly, lay.k, true, false, n);  // out of place: no staging copies
-        if (r) fail(r);
-    }
-    void to_coset(const Fr* poly, Fr* coset) {
-        if (!ok()) return;
-        int r = ctx_ntt(c, poly, n, coset, lay.ext_k, false, true, N);
-        if (r) fail(r);
-    }
-    Fr eval(const Fr* poly, uint32_t len, const Fr& x) {
-        if (!ok()) return Fr::zero();
-        const uint32_t blocks = eval_blocks(len);
-        launch_eval(poly, len, x, c->small, st);
-        if (hipMemcpyAsync(c->host_small, c->small + blocks, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) {
-            fail(ZK_EHIP);
-            return Fr::zero();
-        }
-        return *c->host_small;
-    }
     // out = sum_j c_j * in_j (- sub0 on coefficient 0), any number of inputs: MAX_LC per launch
     struct Term {
         const Fr* poly;
@@ -747,6 +725,13 @@ struct Prover {
     }
     const Fr* col_val(const Col& col) const { return col.fixed ? pk->fixed_val[col.idx] : pk->adv_val[col.idx]; }
     const Fr* col_coset(const Col& col) const { return col.fixed ? pk->fixed_coset[col.idx] : pk->adv_coset[col.idx]; }
+
+    // an opening: polynomial, rotation of the point, value
+    struct Q {
+        const Fr* poly;
+        int rot;
+        Fr eval;
+    };
 
     // ------------------------------------------------------------------ run ---
     int run(const Fr* const* advice_dev, int scheme) {
@@ -1064,11 +1049,6 @@ struct Prover {
         const Fr x = tr->squeeze();
 
         // -- 7. evaluations: every opened value in ONE batched launch, then written in transcript order
-        struct Q {
-            const Fr* poly;
-            int rot;
-            Fr eval;
-        };
         // h(X) = sum x^(n i) h_i(X)
         const Fr xn = fr_pow(x, n);
         {
@@ -1156,179 +1136,186 @@ struct Prover {
         if (!ok()) return rc;
 
         // -- 8. multi-open
-        if (scheme == ZK_SCHEME_GWC) {
-            const Fr v = tr->squeeze();
-            std::vector<std::pair<int, std::vector<Q>>> sets;
-            for (auto& qq : queries) {
-                bool found = false;
-                for (auto& s : sets)
-                    if (s.first == qq.rot) {
-                        s.second.push_back(qq);
-                        found = true;
-                        break;
-                    }
-                if (!found) sets.push_back({qq.rot, {qq}});
-            }
-            // the witness polynomials need no challenge in between: all of them go through one MSM pass.  Buffers: the
-            // h pieces (free once h(X) has been combined) and two temporaries — GWC has at most six rotation sets.
-            Fr* wbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
-            if (sets.size() > 6) return ZK_ESTATE;
-            LaneFifo wf{{0, 1, 2}, {}};
-            Batcher wb{&wf, ZK_BASIS_MONOMIAL, max_batch, {}};
-            size_t set_idx = 0;
-            Fr pts[6];
-            for (auto& s : sets) {
-                std::vector<Term> terms;
-                Fr pv = Fr::one(), eb = Fr::zero();
-                for (auto& qq : s.second) {
-                    terms.push_back(Term{qq.poly, pv});
-                    eb = fe_add(eb, fe_mul(pv, qq.eval));
-                    pv = fe_mul(pv, v);
+        return scheme == ZK_SCHEME_GWC ? open_gwc(queries, x, max_batch) : open_shplonk(queries, x);
+    }
+
+    // GWC (ProverGWC, halo2_proofs poly/kzg/multiopen/gwc): one witness polynomial per rotation
+    int open_gwc(const std::vector<Q>& queries, const Fr& x, uint32_t max_batch) {
+        const Fr v = tr->squeeze();
+        std::vector<std::pair<int, std::vector<Q>>> sets;
+        for (auto& qq : queries) {
+            bool found = false;
+            for (auto& s : sets)
+                if (s.first == qq.rot) {
+                    s.second.push_back(qq);
+                    found = true;
+                    break;
                 }
-                lincomb_many(wbuf[set_idx], terms, true, eb);
-                pts[set_idx] = xrot(x, s.first);
-                set_idx++;
-                if (!ok()) return rc;
-            }
-            // every set's (sum v^i p_i - sum v^i e_i) / (X - point) in one batched division, in place
-            launch_kate_division_batch(wbuf, wbuf, pts, (uint32_t)set_idx, n, pk->kd_scratch, st);
-            for (size_t i = 0; i < set_idx; i++) batch_add(wb, wbuf[i]);
-            batch_flush(wb);
-            fifo_drain(wf);
-        } else {
-            // SHPLONK: group commitments by their set of rotations
-            struct CR {
-                const Fr* poly;
-                std::vector<int> rots;
-                std::vector<Fr> evals;
-            };
-            std::vector<CR> com;
-            for (auto& qq : queries) {
-                CR* hit = nullptr;
-                for (auto& cr : com)
-                    if (cr.poly == qq.poly) hit = &cr;
-                if (!hit) {
-                    com.push_back(CR{qq.poly, {}, {}});
-                    hit = &com.back();
-                }
-                hit->rots.push_back(qq.rot);
-                hit->evals.push_back(qq.eval);
-            }
-            auto pt_less = [&](int ra, int rb) { return fr_less(xrot(x, ra), xrot(x, rb)); };
-            struct RS {
-                std::vector<int> rots;  // sorted by point value (BTreeSet<Fr>)
-                std::vector<CR*> coms;
-            };
-            std::vector<RS> rsets;
-            std::vector<int> all_rots;
-            for (auto& cr : com) {
-                // sort this commitment's (rot, eval) pairs by point
-                std::vector<size_t> order(cr.rots.size());
-                for (size_t i = 0; i < order.size(); i++) order[i] = i;
-                std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pt_less(cr.rots[a], cr.rots[b]); });
-                std::vector<int> r2;
-                std::vector<Fr> e2;
-                for (size_t i : order) {
-                    r2.push_back(cr.rots[i]);
-                    e2.push_back(cr.evals[i]);
-                }
-                cr.rots = r2;
-                cr.evals = e2;
-                for (int r : cr.rots)
-                    if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
-                RS* hit = nullptr;
-                for (auto& rs : rsets)
-                    if (rs.rots == cr.rots) hit = &rs;
-                if (!hit) {
-                    rsets.push_back(RS{cr.rots, {}});
-                    hit = &rsets.back();
-                }
-                hit->coms.push_back(&cr);
-            }
-            std::sort(all_rots.begin(), all_rots.end(), pt_less);
-            const Fr yc = tr->squeeze();
-            const Fr v = tr->squeeze();
-            std::vector<std::vector<Fr>> low(com.size());
-            auto com_index = [&](CR* p) { return (size_t)(p - &com[0]); };
-            // h(X) = sum_i v^i * ( sum_j y^j (P_ij - R_ij) ) / Z_i.  Every rotation set has its own buffer (the h pieces
-            // are free by now); step s divides, in ONE batched launch, every set that still has a point left by it.
-            Fr* hx = pk->t_frac;  // h(X)
-            Fr* sbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
-            if (rsets.size() > 6) return ZK_ESTATE;
-            std::vector<std::vector<Fr>> set_pts;
-            size_t max_pts = 0;
-            for (size_t si = 0; si < rsets.size(); si++) {
-                auto& rs = rsets[si];
-                std::vector<Fr> pts;
-                for (int r : rs.rots) pts.push_back(xrot(x, r));
-                std::vector<Term> terms;
-                std::vector<Fr> rsum(pts.size(), Fr::zero());
-                Fr py = Fr::one();
-                for (CR* cr : rs.coms) {
-                    low[com_index(cr)] = lagrange_interpolate(pts, cr->evals);
-                    terms.push_back(Term{cr->poly, py});
-                    for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
-                    py = fe_mul(py, yc);
-                }
-                // sum_j y^j P_j(X) minus sum_j y^j R_j(X) (degree < |set|: a few low coefficients, known on the host)
-                if (pts.size() > 8) return ZK_ESTATE;
-                lincomb_many(sbuf[si], terms, false, Fr::zero(), false, &rsum);
-                max_pts = std::max(max_pts, pts.size());
-                set_pts.push_back(pts);
-            }
-            for (size_t step = 0; step < max_pts; step++) {
-                Fr* bufs[6];
-                Fr zs[6];
-                uint32_t cnt = 0;
-                for (size_t si = 0; si < rsets.size(); si++)
-                    if (step < set_pts[si].size()) {
-                        bufs[cnt] = sbuf[si];
-                        zs[cnt] = set_pts[si][step];
-                        cnt++;
-                    }
-                launch_kate_division_batch(bufs, bufs, zs, cnt, n, pk->kd_scratch, st);
-            }
-            {
-                std::vector<Term> terms;
-                Fr pv = Fr::one();
-                for (size_t si = 0; si < rsets.size(); si++) {
-                    terms.push_back(Term{sbuf[si], pv});
-                    pv = fe_mul(pv, v);
-                }
-                lincomb_many(hx, terms, false, Fr::zero());
-            }
-            commit_write(hx, n, ZK_BASIS_MONOMIAL);
-            if (!ok()) return rc;
-            const Fr u = tr->squeeze();
-            // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
+            if (!found) sets.push_back({qq.rot, {qq}});
+        }
+        // the witness polynomials need no challenge in between: all of them go through one MSM pass.  Buffers: the
+        // h pieces (free once h(X) has been combined) and two temporaries — GWC has at most six rotation sets.
+        Fr* wbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
+        if (sets.size() > 6) return ZK_ESTATE;
+        LaneFifo wf{{0, 1, 2}, {}};
+        Batcher wb{&wf, ZK_BASIS_MONOMIAL, max_batch, {}};
+        size_t set_idx = 0;
+        Fr pts[6];
+        for (auto& s : sets) {
             std::vector<Term> terms;
-            Fr sub = Fr::zero();
-            Fr pv = Fr::one();
-            std::vector<Fr> z_diffs;
-            for (auto& rs : rsets) {
-                std::vector<Fr> diffs;
-                for (int r : all_rots)
-                    if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(xrot(x, r));
-                const Fr zi = vanishing_eval(diffs, u);
-                z_diffs.push_back(zi);
-                Fr py = Fr::one();
-                for (CR* cr : rs.coms) {
-                    const Fr coef = fe_mul(fe_mul(pv, zi), py);
-                    terms.push_back(Term{cr->poly, coef});
-                    sub = fe_add(sub, fe_mul(coef, eval_small(low[com_index(cr)], u)));
-                    py = fe_mul(py, yc);
-                }
+            Fr pv = Fr::one(), eb = Fr::zero();
+            for (auto& qq : s.second) {
+                terms.push_back(Term{qq.poly, pv});
+                eb = fe_add(eb, fe_mul(pv, qq.eval));
                 pv = fe_mul(pv, v);
             }
-            std::vector<Fr> all_pts;
-            for (int r : all_rots) all_pts.push_back(xrot(x, r));
-            const Fr zt = vanishing_eval(all_pts, u);
-            terms.push_back(Term{hx, fe_neg(zt)});
-            lincomb_many(pk->t_a, terms, true, sub);
-            launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
-            launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
-            commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
+            lincomb_many(wbuf[set_idx], terms, true, eb);
+            pts[set_idx] = xrot(x, s.first);
+            set_idx++;
+            if (!ok()) return rc;
         }
+        // every set's (sum v^i p_i - sum v^i e_i) / (X - point) in one batched division, in place
+        launch_kate_division_batch(wbuf, wbuf, pts, (uint32_t)set_idx, n, pk->kd_scratch, st);
+        for (size_t i = 0; i < set_idx; i++) batch_add(wb, wbuf[i]);
+        batch_flush(wb);
+        fifo_drain(wf);
+        return rc;
+    }
+
+    // SHPLONK (ProverSHPLONK, poly/kzg/multiopen/shplonk)
+    int open_shplonk(const std::vector<Q>& queries, const Fr& x) {
+        // SHPLONK: group commitments by their set of rotations
+        struct CR {
+            const Fr* poly;
+            std::vector<int> rots;
+            std::vector<Fr> evals;
+        };
+        std::vector<CR> com;
+        for (auto& qq : queries) {
+            CR* hit = nullptr;
+            for (auto& cr : com)
+                if (cr.poly == qq.poly) hit = &cr;
+            if (!hit) {
+                com.push_back(CR{qq.poly, {}, {}});
+                hit = &com.back();
+            }
+            hit->rots.push_back(qq.rot);
+            hit->evals.push_back(qq.eval);
+        }
+        auto pt_less = [&](int ra, int rb) { return fr_less(xrot(x, ra), xrot(x, rb)); };
+        struct RS {
+            std::vector<int> rots;  // sorted by point value (BTreeSet<Fr>)
+            std::vector<CR*> coms;
+        };
+        std::vector<RS> rsets;
+        std::vector<int> all_rots;
+        for (auto& cr : com) {
+            // sort this commitment's (rot, eval) pairs by point
+            std::vector<size_t> order(cr.rots.size());
+            for (size_t i = 0; i < order.size(); i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pt_less(cr.rots[a], cr.rots[b]); });
+            std::vector<int> r2;
+            std::vector<Fr> e2;
+            for (size_t i : order) {
+                r2.push_back(cr.rots[i]);
+                e2.push_back(cr.evals[i]);
+            }
+            cr.rots = r2;
+            cr.evals = e2;
+            for (int r : cr.rots)
+                if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
+            RS* hit = nullptr;
+            for (auto& rs : rsets)
+                if (rs.rots == cr.rots) hit = &rs;
+            if (!hit) {
+                rsets.push_back(RS{cr.rots, {}});
+                hit = &rsets.back();
+            }
+            hit->coms.push_back(&cr);
+        }
+        std::sort(all_rots.begin(), all_rots.end(), pt_less);
+        const Fr yc = tr->squeeze();
+        const Fr v = tr->squeeze();
+        std::vector<std::vector<Fr>> low(com.size());
+        auto com_index = [&](CR* p) { return (size_t)(p - &com[0]); };
+        // h(X) = sum_i v^i * ( sum_j y^j (P_ij - R_ij) ) / Z_i.  Every rotation set has its own buffer (the h pieces
+        // are free by now); step s divides, in ONE batched launch, every set that still has a point left by it.
+        Fr* hx = pk->t_frac;  // h(X)
+        Fr* sbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
+        if (rsets.size() > 6) return ZK_ESTATE;
+        std::vector<std::vector<Fr>> set_pts;
+        size_t max_pts = 0;
+        for (size_t si = 0; si < rsets.size(); si++) {
+            auto& rs = rsets[si];
+            std::vector<Fr> pts;
+            for (int r : rs.rots) pts.push_back(xrot(x, r));
+            std::vector<Term> terms;
+            std::vector<Fr> rsum(pts.size(), Fr::zero());
+            Fr py = Fr::one();
+            for (CR* cr : rs.coms) {
+                low[com_index(cr)] = lagrange_interpolate(pts, cr->evals);
+                terms.push_back(Term{cr->poly, py});
+                for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
+                py = fe_mul(py, yc);
+            }
+            // sum_j y^j P_j(X) minus sum_j y^j R_j(X) (degree < |set|: a few low coefficients, known on the host)
+            if (pts.size() > 8) return ZK_ESTATE;
+            lincomb_many(sbuf[si], terms, false, Fr::zero(), false, &rsum);
+            max_pts = std::max(max_pts, pts.size());
+            set_pts.push_back(pts);
+        }
+        for (size_t step = 0; step < max_pts; step++) {
+            Fr* bufs[6];
+            Fr zs[6];
+            uint32_t cnt = 0;
+            for (size_t si = 0; si < rsets.size(); si++)
+                if (step < set_pts[si].size()) {
+                    bufs[cnt] = sbuf[si];
+                    zs[cnt] = set_pts[si][step];
+                    cnt++;
+                }
+            launch_kate_division_batch(bufs, bufs, zs, cnt, n, pk->kd_scratch, st);
+        }
+        {
+            std::vector<Term> terms;
+            Fr pv = Fr::one();
+            for (size_t si = 0; si < rsets.size(); si++) {
+                terms.push_back(Term{sbuf[si], pv});
+                pv = fe_mul(pv, v);
+            }
+            lincomb_many(hx, terms, false, Fr::zero());
+        }
+        commit_write(hx, n, ZK_BASIS_MONOMIAL);
+        if (!ok()) return rc;
+        const Fr u = tr->squeeze();
+        // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
+        std::vector<Term> terms;
+        Fr sub = Fr::zero();
+        Fr pv = Fr::one();
+        std::vector<Fr> z_diffs;
+        for (auto& rs : rsets) {
+            std::vector<Fr> diffs;
+            for (int r : all_rots)
+                if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(xrot(x, r));
+            const Fr zi = vanishing_eval(diffs, u);
+            z_diffs.push_back(zi);
+            Fr py = Fr::one();
+            for (CR* cr : rs.coms) {
+                const Fr coef = fe_mul(fe_mul(pv, zi), py);
+                terms.push_back(Term{cr->poly, coef});
+                sub = fe_add(sub, fe_mul(coef, eval_small(low[com_index(cr)], u)));
+                py = fe_mul(py, yc);
+            }
+            pv = fe_mul(pv, v);
+        }
+        std::vector<Fr> all_pts;
+        for (int r : all_rots) all_pts.push_back(xrot(x, r));
+        const Fr zt = vanishing_eval(all_pts, u);
+        terms.push_back(Term{hx, fe_neg(zt)});
+        lincomb_many(pk->t_a, terms, true, sub);
+        launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
+        launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
+        commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
         return rc;
     }
 };
