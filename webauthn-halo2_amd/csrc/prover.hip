@@ -726,6 +726,67 @@ struct Prover {
     const Fr* col_val(const Col& col) const { return col.fixed ? pk->fixed_val[col.idx] : pk->adv_val[col.idx]; }
     const Fr* col_coset(const Col& col) const { return col.fixed ? pk->fixed_coset[col.idx] : pk->adv_coset[col.idx]; }
 
+    // h(X) on the extended coset (one lane per row, quotient.hip), divided by X^n - 1, back to coefficients:
+    // the first (degree - 1) * n coefficients of h_ext are the h pieces
+    int quotient(const Fr& beta, const Fr& gamma, const Fr& y) {
+        QuotientArgs q;
+        memset(&q, 0, sizeof(q));
+        q.log_ext = lay.ext_k;
+        q.n_gate = lay.n_gate;
+        q.n_adv = lay.n_adv;
+        q.n_chunks = lay.n_chunks;
+        q.chunk_len = lay.chunk_len;
+        q.n_perm = (uint32_t)lay.perm_cols.size();
+        q.n_lookups = lay.n_lookups;
+        q.single = lay.single ? 1 : 0;
+        q.last_rot = lay.last_rot;
+        q.fx_table = lay.fx_table;
+        q.fx_qlookup = lay.fx_qlookup;
+        for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = pk->adv_coset[j];
+        for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
+        for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.fx_sel[j];
+        const Fr delta = fr_delta();
+        Fr dcur = beta;
+        for (uint32_t p = 0; p < q.n_perm; p++) {
+            q.sigma[p] = pk->sigma_coset[p];
+            q.perm_val[p] = col_coset(lay.perm_cols[p]);
+            q.delta_pow[p] = dcur;
+            dcur = fe_mul(dcur, delta);
+        }
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) q.z[ci] = pk->z_coset[ci];
+        for (uint32_t l = 0; l < lay.n_lookups; l++) {
+            q.lk_z[l] = pk->lk_z_coset[l];
+            q.lk_a[l] = pk->lk_ap_coset[l];
+            q.lk_s[l] = pk->lk_sp_coset[l];
+            q.lk_in[l] = lay.single ? nullptr : pk->adv_coset[lay.n_gate + l];
+        }
+        q.l0 = pk->l0_coset;
+        q.l_last = pk->l_last_coset;
+        q.l_active = pk->l_active_coset;
+        q.tw_ext = tw_ext;
+        q.zeta = c->zeta;
+        q.beta = beta;
+        q.gamma = gamma;
+        q.y = y;
+        // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
+        const Fr zn = fr_pow(c->zeta, n);
+        const Fr w4 = fr_pow(fr_omega(lay.ext_k), n);
+        Fr cur = zn;
+        for (int i = 0; i < 4; i++) {
+            q.t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
+            cur = fe_mul(cur, w4);
+        }
+        q.out = pk->h_ext;
+        hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
+        hipMemcpyAsync(pk->d_qargs, &q, sizeof(q), hipMemcpyHostToDevice, st);
+        launch_quotient_dev(pk->d_qargs, lay.ext_k, st);
+        hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
+        c->ev_valid[ZK_T_QUOTIENT] = true;
+        int r = ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
+        if (r) return r;
+        return ZK_OK;
+    }
+
     // an opening: polynomial, rotation of the point, value
     struct Q {
         const Fr* poly;
@@ -979,63 +1040,7 @@ struct Prover {
 
         // -- 6. quotient (every coefficient / coset form was produced behind its commitment above)
         if (!ok()) return rc;
-        {
-            QuotientArgs q;
-            memset(&q, 0, sizeof(q));
-            q.log_ext = lay.ext_k;
-            q.n_gate = lay.n_gate;
-            q.n_adv = lay.n_adv;
-            q.n_chunks = lay.n_chunks;
-            q.chunk_len = lay.chunk_len;
-            q.n_perm = (uint32_t)lay.perm_cols.size();
-            q.n_lookups = lay.n_lookups;
-            q.single = lay.single ? 1 : 0;
-            q.last_rot = lay.last_rot;
-            q.fx_table = lay.fx_table;
-            q.fx_qlookup = lay.fx_qlookup;
-            for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = pk->adv_coset[j];
-            for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
-            for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.fx_sel[j];
-            const Fr delta = fr_delta();
-            Fr dcur = beta;
-            for (uint32_t p = 0; p < q.n_perm; p++) {
-                q.sigma[p] = pk->sigma_coset[p];
-                q.perm_val[p] = col_coset(lay.perm_cols[p]);
-                q.delta_pow[p] = dcur;
-                dcur = fe_mul(dcur, delta);
-            }
-            for (uint32_t ci = 0; ci < lay.n_chunks; ci++) q.z[ci] = pk->z_coset[ci];
-            for (uint32_t l = 0; l < lay.n_lookups; l++) {
-                q.lk_z[l] = pk->lk_z_coset[l];
-                q.lk_a[l] = pk->lk_ap_coset[l];
-                q.lk_s[l] = pk->lk_sp_coset[l];
-                q.lk_in[l] = lay.single ? nullptr : pk->adv_coset[lay.n_gate + l];
-            }
-            q.l0 = pk->l0_coset;
-            q.l_last = pk->l_last_coset;
-            q.l_active = pk->l_active_coset;
-            q.tw_ext = tw_ext;
-            q.zeta = c->zeta;
-            q.beta = beta;
-            q.gamma = gamma;
-            q.y = y;
-            // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
-            const Fr zn = fr_pow(c->zeta, n);
-            const Fr w4 = fr_pow(fr_omega(lay.ext_k), n);
-            Fr cur = zn;
-            for (int i = 0; i < 4; i++) {
-                q.t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
-                cur = fe_mul(cur, w4);
-            }
-            q.out = pk->h_ext;
-            hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
-            hipMemcpyAsync(pk->d_qargs, &q, sizeof(q), hipMemcpyHostToDevice, st);
-            launch_quotient_dev(pk->d_qargs, lay.ext_k, st);
-            hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
-            c->ev_valid[ZK_T_QUOTIENT] = true;
-            int r = ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
-            if (r) return r;
-        }
+        if (int r = quotient(beta, gamma, y)) return r;
         draw(lay.n_h);  // h-piece blinds
         {
             // the h pieces are contiguous n-coefficient slices of the quotient: one MSM pass for all of them
