@@ -114,6 +114,7 @@ struct zk_pk_rec {
     Fr* gp_host = nullptr;       // pinned: q and q_inv
     GpItem* d_gp_items = nullptr;
     QuotientArgs* d_qargs = nullptr;
+    QuotientArgs* h_qargs = nullptr;  // pinned staging of the same
     EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
     uint32_t max_evals = 0;
     Fr *ev_scratch = nullptr, *ev_out = nullptr;
@@ -223,6 +224,7 @@ void pk_destroy(zk_pk_rec* pk) {
     if (pk->gp_host) hipHostFree(pk->gp_host);
     if (pk->d_gp_items) hipFree(pk->d_gp_items);
     if (pk->d_qargs) hipFree(pk->d_qargs);
+    if (pk->h_qargs) hipHostFree(pk->h_qargs);
     if (pk->d_evargs) hipFree(pk->d_evargs);
     if (pk->h_evargs) hipHostFree(pk->h_evargs);
     delete pk;
@@ -465,7 +467,8 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
         pk->lks.stride = stride;
         pk->lks.err = b + (size_t)stride * lay.n_lookups;
     }
-    if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess || hipHostMalloc(&pk->h_qargs, sizeof(QuotientArgs)) != hipSuccess)
+        return fail(ZK_ENOMEM);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
     const uint64_t h = c->next_handle++;
     c->pks[h] = pk;
@@ -729,7 +732,7 @@ struct Prover {
     // h(X) on the extended coset (one lane per row, quotient.hip), divided by X^n - 1, back to coefficients:
     // the first (degree - 1) * n coefficients of h_ext are the h pieces
     int quotient(const Fr& beta, const Fr& gamma, const Fr& y) {
-        QuotientArgs q;
+        QuotientArgs& q = *pk->h_qargs;  // pinned: the upload below does not stall the host (the previous proof is complete)
         memset(&q, 0, sizeof(q));
         q.log_ext = lay.ext_k;
         q.n_gate = lay.n_gate;
