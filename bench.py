@@ -184,8 +184,8 @@ def cpu_baseline(eng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKMI355_INFLIGHT", "2")),
                     help="independent proof pipelines per GPU (each its own zk_ctx + host thread); the K timed steps are "
