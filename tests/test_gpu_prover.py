@@ -234,3 +234,40 @@ def test_reference_api_mirror(engine, tmp_path):
     assert os.path.getsize(vkp) == 12 + (6 + 6) * 64 + 32
     eng.close()
     api._STATE.clear()
+
+
+def test_concurrent_pipelines_are_deterministic():
+    """bench.py runs two proof pipelines (own context + host thread each) on one GPU: concurrent proofs of the
+    same witness and seed must be the bytes a lone pipeline produces (k = 10: batched table path)."""
+    import threading
+    A, L, F, k, lb = 3, 2, 1, 10, 8
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    asg = zk.circuit.synthesize(p, 0x5EED0019)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    seed = b"\x33" * 32
+
+    def pipeline(out, reps):
+        eng = zk.Engine(0)
+        eng.srs_setup(k)
+        pk = eng.keygen(p, fixed, asg.copies)
+        polys = []
+        for col in asg.advice:
+            h = eng.poly(1 << k)
+            eng.upload_canonical(h, asg.to_limbs(col))
+            polys.append(h)
+        for _ in range(reps):
+            out.append(eng.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM))
+            out.append(eng.prove(pk, polys, seed, E.ZK_TRANSCRIPT_BLAKE2B))
+        eng.close()
+
+    ref = []
+    pipeline(ref, 1)
+    outs = [[], []]
+    ths = [threading.Thread(target=pipeline, args=(o, 6)) for o in outs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for o in outs:
+        assert len(o) == 12
+        assert all(o[i] == ref[i % 2] for i in range(12))
