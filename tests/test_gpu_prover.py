@@ -159,7 +159,8 @@ BENCH_ROWS = [
     (13, 68, 12, 1, 12, 24960, 1),
     (12, 139, 24, 2, 11, 50496, 2),
     (11, 291, 53, 4, 10, 106496, 3),
-    (20, 1, 1, 1, 19, 960, 0),  # not a reference row: one size above BASELINE's k=19 (same single-column shape)
+    (20, 1, 1, 1, 19, 960, 0),  # not reference rows: above BASELINE's k=19 (same single-column shape); k=21 is
+    (21, 1, 1, 1, 20, 960, 0),  # the size of the stress config and takes the 15-bit-window MSM path
 ]
 
 
