@@ -47,6 +47,9 @@ struct zk_ctx {
     // scratch
     Fr* scratch = nullptr;
     size_t scratch_n = 0;
+    // device staging of the fine-grained seam (zk_msm_bn254 / zk_ntt_bn254_fr): grow-only, reused across calls
+    void* seam_buf[2] = {nullptr, nullptr};
+    size_t seam_bytes[2] = {0, 0};
     Fr* small = nullptr;  // 2048 + 8 elements for reductions
     Fr* host_small = nullptr;  // pinned, 8 elements
     // polys

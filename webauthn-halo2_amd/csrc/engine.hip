@@ -84,6 +84,24 @@ uint32_t ctx_msm_max_batch(const zk_ctx* c) {
     return batch_for((size_t)1 << c->srs_k);
 }
 
+// device staging buffer `which` of at least `bytes` (kept for the next call: a Rust host patched at best_multiexp /
+// best_fft calls the seam a dozen times per proof with the same sizes)
+static int seam_buffer(zk_ctx* c, int which, size_t bytes, void** out) {
+    if (c->seam_bytes[which] < bytes) {
+        if (c->seam_buf[which]) hipFree(c->seam_buf[which]);
+        c->seam_buf[which] = nullptr;
+        c->seam_bytes[which] = 0;
+        hipError_t e = hipMalloc(&c->seam_buf[which], bytes);
+        if (e != hipSuccess) {
+            c->last_hip = (int)e;
+            return ZK_ENOMEM;
+        }
+        c->seam_bytes[which] = bytes;
+    }
+    *out = c->seam_buf[which];
+    return ZK_OK;
+}
+
 static int get_msm_ws(zk_ctx* c, int lane, size_t n, MsmWorkspace** out) {
     size_t want = 1;
     while (want < n) want <<= 1;
@@ -269,6 +287,8 @@ void zk_ctx_destroy(zk_ctx* c) {
     }
     if (c->host_small) hipHostFree(c->host_small);
     if (c->scratch) hipFree(c->scratch);
+    for (int i = 0; i < 2; i++)
+        if (c->seam_buf[i]) hipFree(c->seam_buf[i]);
     if (c->small) hipFree(c->small);
     for (int i = 0; i < ZK_T_COUNT; i++)
         for (int j = 0; j < 2; j++)
@@ -341,19 +361,13 @@ int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size
     }
     Fr* d_s = nullptr;
     G1Affine* d_b = nullptr;
-    if (hipMalloc(&d_s, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
-    if (hipMalloc(&d_b, n * sizeof(G1Affine)) != hipSuccess) {
-        hipFree(d_s);
-        return ZK_ENOMEM;
-    }
-    rc = ZK_OK;
+    if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_s)) || (rc = seam_buffer(c, 1, n * sizeof(G1Affine), (void**)&d_b)))
+        return rc;
     if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess)
         rc = ZK_EHIP;
     if (rc == ZK_OK) rc = ctx_msm_device(c, d_s, d_b, n, &res);
     hipStreamSynchronize(c->stream);
-    hipFree(d_s);
-    hipFree(d_b);
     if (rc == ZK_OK) memcpy(out, &res, 96);
     return rc;
 }
@@ -383,12 +397,10 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
     }
     if (rc) return rc;
     Fr *d_a = nullptr, *d_t = nullptr;
-    if (hipMalloc(&d_a, n * sizeof(Fr)) != hipSuccess || hipMalloc(&d_t, n * sizeof(Fr)) != hipSuccess) {
-        hipFree(d_a);
+    if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_a)) || (rc = seam_buffer(c, 1, n * sizeof(Fr), (void**)&d_t))) {
         hipFree(own_tw);
-        return ZK_ENOMEM;
+        return rc;
     }
-    rc = ZK_OK;
     NttJob job;
     memset(&job, 0, sizeof(job));
     job.src = d_a;
@@ -419,8 +431,6 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
     }
     hipStreamSynchronize(c->stream);
     if (rc == ZK_OK) memcpy(a, tmp.data(), n * sizeof(Fr));
-    hipFree(d_a);
-    hipFree(d_t);
     hipFree(own_tw);
     return rc;
 }
