@@ -74,7 +74,10 @@ int zk_ntt_bn254_fr(zk_ctx* ctx, uint64_t* a_mont /* 2^log_n x 4 */, const uint6
  * (ecdsa_p256.rs:258,338,388): s = Fr::from_u512(first 64 keystream bytes);
  * g[i] = [s^i]G1, g_lagrange[i] = [L_i(s)]G1, both generated on the device. */
 int zk_srs_setup(zk_ctx* ctx, uint32_t k, const uint8_t seed[32]);
-/* replaces ParamsKZG::read: adopt caller-supplied bases (n = 2^k points each, affine Montgomery) */
+/* replaces ParamsKZG::read: adopt caller-supplied bases (n = 2^k points each, affine Montgomery).  The two arrays
+ * are remembered by address: a later zk_msm_bn254 over the same array (what best_multiexp(coeffs, &params.g_lagrange)
+ * is in the Rust host) skips the upload of the bases and runs on the resident window tables.  They must stay
+ * unmodified while the SRS is loaded (they are the SRS); evenly spaced sample points are re-checked on every call. */
 int zk_srs_load(zk_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange);
 int zk_srs_export(zk_ctx* ctx, int basis, uint64_t* out_affine_mont /* n x 8 */, size_t first, size_t count);
 int zk_srs_k(const zk_ctx* ctx); /* -1 if none */

@@ -90,3 +90,25 @@ def test_two_contexts_two_threads():
     for i in range(3):
         want = srs.g1_of_scalar(srs.commit_scalar_monomial([(j * (i + 3)) % F.R for j in range(1024)]))
         assert all(r == want for r in res[i])
+
+
+def test_seam_over_the_loaded_srs_arrays():
+    """zk_msm_bn254 over the very arrays zk_srs_load was given runs on the resident window tables (no upload of
+    the bases); any other array — equal content elsewhere, or the same array modified at an unsampled point — takes
+    the general path.  All three give the right sum."""
+    eng = zk.Engine(0)
+    k = 12
+    n = 1 << k
+    eng.srs_setup(k)
+    g, gl = eng.srs_export(0, 0, n), eng.srs_export(1, 0, n)
+    eng.srs_load(k, g, gl)
+    rng = np.random.default_rng(5)
+    s = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    s[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    want = cops.jac_to_affine_ints(cops.msm(s, gl))
+    assert cops.jac_to_affine_ints(eng.msm(s, gl)) == want            # aliased: resident tables
+    assert cops.jac_to_affine_ints(eng.msm(s, gl.copy())) == want     # same content, another array: uploaded
+    gl2 = gl.copy()
+    gl2[5] = gl2[7]                                                   # differs at a point no sample looks at
+    assert cops.jac_to_affine_ints(eng.msm(s, gl2)) == cops.jac_to_affine_ints(cops.msm(s, gl2))
+    eng.close()

@@ -31,6 +31,11 @@ struct zk_ctx {
     G1Affine* g_table = nullptr;           // window multiples of g / g_lagrange (fixed-base MSM)
     G1Affine* g_lagrange_table = nullptr;
     uint32_t table_c = 0;
+    // The host arrays zk_srs_load was given (the Rust host's params.g / params.g_lagrange): when the fine-grained seam
+    // is called with the same array again it uses the resident copy.  256 sampled points guard against the array
+    // having been rewritten in the meantime.
+    const void* srs_host[2] = {nullptr, nullptr};
+    std::vector<G1Affine> srs_sample[2];
     // MSM lanes: each in-flight MSM owns a workspace, a tail stream and a pinned result buffer
     static constexpr int MSM_LANES = 3;
     struct MsmLane {

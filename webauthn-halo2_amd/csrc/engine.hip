@@ -346,6 +346,8 @@ int zk_timer_stats(zk_ctx* c, int which, double* total_ms, uint64_t* count) {
 
 // ---- fine-grained seam -------------------------------------------------------
 
+static bool seam_is_resident_basis(const zk_ctx* c, int b, const uint64_t* bases, size_t n);
+
 int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out[12]) {
     if (!c || !out || (n && (!scalars || !bases))) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -361,11 +363,15 @@ int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size
     }
     Fr* d_s = nullptr;
     G1Affine* d_b = nullptr;
-    if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_s)) || (rc = seam_buffer(c, 1, n * sizeof(G1Affine), (void**)&d_b)))
-        return rc;
-    if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess)
-        rc = ZK_EHIP;
+    if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_s))) return rc;
+    // the host's own copy of the resident SRS: no upload of the bases, window-table MSM
+    if (seam_is_resident_basis(c, 1, bases, n)) d_b = c->g_lagrange;
+    else if (seam_is_resident_basis(c, 0, bases, n)) d_b = c->g;
+    if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
+    if (!d_b && rc == ZK_OK) {
+        if ((rc = seam_buffer(c, 1, n * sizeof(G1Affine), (void**)&d_b))) return rc;
+        if (hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
+    }
     if (rc == ZK_OK) rc = ctx_msm_device(c, d_s, d_b, n, &res);
     hipStreamSynchronize(c->stream);
     if (rc == ZK_OK) memcpy(out, &res, 96);
@@ -436,6 +442,7 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
 }
 
 // ---- SRS ---------------------------------------------------------------------
+static constexpr uint32_t SRS_SAMPLES = 256;
 
 // window-multiple tables of both bases for the fixed-base MSM (k >= 10; smaller SRS use the generic path)
 static int srs_build_tables(zk_ctx* c, uint32_t k) {
@@ -454,11 +461,37 @@ static int srs_build_tables(zk_ctx* c, uint32_t k) {
         return ZK_EHIP;
     }
     c->table_c = cw;
+    // fingerprints of the two bases (SRS_SAMPLES evenly spaced points each) for zk_msm_bn254
+    for (int b = 0; b < 2; b++) {
+        c->srs_sample[b].resize(SRS_SAMPLES);
+        const G1Affine* src = b ? c->g_lagrange : c->g;
+        if (hipMemcpy2D(c->srs_sample[b].data(), sizeof(G1Affine), src, (size_t)(n / SRS_SAMPLES) * sizeof(G1Affine), sizeof(G1Affine),
+                        SRS_SAMPLES, hipMemcpyDeviceToHost) != hipSuccess) {
+            c->srs_sample[b].clear();
+            return ZK_EHIP;
+        }
+    }
     return ZK_OK;
+}
+
+// Is the host array `bases` (n points) the one zk_srs_load was given as basis b?  A Rust host patched at
+// best_multiexp passes &params.g / &params.g_lagrange on every call: the same array it loaded the SRS from.  Then the
+// upload of the bases is skipped and the window-table MSM runs on the resident copy.  The sampled points are a guard
+// against the array having been rewritten since (the contract of zk_srs_load: the arrays are the SRS, immutable).
+static bool seam_is_resident_basis(const zk_ctx* c, int b, const uint64_t* bases, size_t n) {
+    if (c->srs_k < 0 || !c->table_c || n != ((size_t)1 << c->srs_k) || c->srs_sample[b].size() != SRS_SAMPLES) return false;
+    if (c->srs_host[b] != (const void*)bases) return false;
+    const size_t step = n / SRS_SAMPLES;
+    for (uint32_t j = 0; j < SRS_SAMPLES; j++)
+        if (memcmp(bases + (size_t)j * step * 8, &c->srs_sample[b][j], sizeof(G1Affine)) != 0) return false;
+    return true;
 }
 
 static int srs_alloc(zk_ctx* c, uint32_t k) {
     if (k < 1 || k > 24) return ZK_EINVAL;
+    c->srs_sample[0].clear();
+    c->srs_sample[1].clear();
+    c->srs_host[0] = c->srs_host[1] = nullptr;
     const size_t n = (size_t)1 << k;
     if (c->g) hipFree(c->g);
     if (c->g_lagrange) hipFree(c->g_lagrange);
@@ -563,6 +596,8 @@ int zk_srs_load(zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl) {
     HIPCHK(c, hipMemcpy(c->g_lagrange, gl, bytes, hipMemcpyHostToDevice));
     if ((rc = srs_build_tables(c, k)) != ZK_OK) return rc;
     c->srs_k = (int)k;
+    c->srs_host[0] = g;
+    c->srs_host[1] = gl;
     return ZK_OK;
 }
 
