@@ -1,5 +1,5 @@
 import sys,os,time
-sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),"oracle")]
+sys.path.insert(0, os.getcwd())
 import numpy as np, webauthn_halo2_amd as zk
 from webauthn_halo2_amd import engine as E
 p=zk.circuit.K17; eng=zk.Engine(0); eng.srs_setup(17)

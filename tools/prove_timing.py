@@ -1,12 +1,11 @@
 """Single-proof wall clock for the BASELINE shapes (k=17 server default, k=19) x (Blake2b+SHPLONK,
-Keccak+GWC), one proof at a time on one GPU; each proof is checked by the oracle verifier."""
+Keccak+GWC), one proof at a time on one GPU (the proofs themselves are verified in tests/test_gpu_prover.py)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path.insert(0, ROOT)
 import numpy as np
 import webauthn_halo2_amd as zk
 from webauthn_halo2_amd import engine as E
-from zkoracle import cops, plonk
 
 out = {}
 for name, p in (("k17", zk.circuit.K17), ("k19", zk.circuit.K19)):
@@ -18,16 +17,12 @@ for name, p in (("k17", zk.circuit.K17), ("k19", zk.circuit.K19)):
     polys = []
     for col in asg.advice:
         h = eng.poly(1 << k); eng.upload_canonical(h, asg.to_limbs(col)); polys.append(h)
-    sh = plonk.Shape(k, p.num_advice, p.num_lookup_advice, p.num_fixed, p.lookup_bits)
-    fc, pc, tr = eng.vk_export(pk)
-    vk = plonk.VerifyingKey(sh, cops.affine_arr_to_ints(fc), cops.affine_arr_to_ints(pc), cops.fr_ints(tr.reshape(1, 4))[0])
     for tname, tk in (("blake2b_shplonk", E.ZK_TRANSCRIPT_BLAKE2B), ("evm_gwc", E.ZK_TRANSCRIPT_EVM)):
         for _ in range(2):
             eng.prove(pk, polys, bytes(32), tk)
         ts = []
         for i in range(8):
             t0 = time.perf_counter(); pf = eng.prove(pk, polys, i.to_bytes(32, "little"), tk); ts.append((time.perf_counter() - t0) * 1e3)
-        assert plonk.verify(vk, pf, "evm" if tk == E.ZK_TRANSCRIPT_EVM else "blake2b")
         out[f"{name}_{tname}"] = {"ms_min": round(min(ts), 2), "ms_median": round(sorted(ts)[len(ts) // 2], 2), "proof_bytes": len(pf)}
     out[f"{name}_setup"] = {"srs_setup_s": round(t_srs, 3), "keygen_s": round(t_key, 3)}
     eng.close()
