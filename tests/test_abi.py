@@ -46,6 +46,15 @@ def test_product_does_not_reference_oracle():
                     # prover_smoke() is the smoke-test checker hook: the only place allowed to reach the oracle
                     src = src[:src.index("def prover_smoke")]
                 assert "zkoracle" not in src and "liboracle" not in src, f
+    # measurement tools stand on the engine alone as well
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh", ".hip")):
+            src = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "zkoracle" not in src and "liboracle" not in src, f
+    # bench.py: only the cpu_baseline leg may
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    lo, hi = src.index("def cpu_baseline"), src.index("def main")
+    assert "zkoracle" not in src[:lo] + src[hi:] and "liboracle" not in src[:lo] + src[hi:]
 
 
 def test_header_is_plain_c():
