@@ -1,20 +1,27 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark: WebAuthn ES256 (secp256r1 ECDSA circuit) proofs/sec at k=19.
 
-One "step" = one pass of the create_proof hot path over one synthetic witness of
-the k=19 shape (BASELINE.json configs[1]), inputs resident in HBM.
-N>1: independent proofs, one per GPU (replicas only, no collective on the data
-path — SURVEY.md §8e); torch.distributed (RCCL) is used for the barrier and the
-max-over-ranks clock only.
+One "step" = one pass of the create_proof hot path over one job of the k=19 batch workload
+(BASELINE.json configs[1] / configs[3]): job i is an independent synthetic witness of seed
+0x5eed0019 + i, its advice column resident in HBM when the clock starts.  Rank r of N proves jobs r, r + N,
+r + 2N, ... (round-robin, one proof stream per GPU, replicas only — SURVEY.md §8e); the K timed steps of a rank
+are K DISTINCT jobs drained through webauthn-halo2_amd/batch.py, so `--gpus 8 --steps 32` IS the 256-proof
+batch of configs[3].
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-`roofline` for the dominant kernel (HIP events on the engine's own stream) and
-`cpu_baseline` (the oracle's C restatement of best_multiexp / best_fft timed on
-the host cores; the reference Rust prover cannot be built here — no toolchain).
+Launch: `python bench.py --gpus N ...`.  With N > 1 and no WORLD_SIZE in the environment the script starts its
+own N per-device workers (one process per GPU through torch.distributed.run on 127.0.0.1) and relays rank 0's
+line — no external launcher needed; launched under torchrun it is a worker.  torch.distributed (RCCL) is used
+for the barrier and the max-over-ranks clock only; there is no collective on the data path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant kernel
+(HIP events on the engine's own stream) and `cpu_baseline` (a whole create_proof by the oracle's CPU port on the
+host cores; the reference Rust prover cannot be built here — no toolchain).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,70 +34,74 @@ import numpy as np  # noqa: E402
 
 K = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOAD = ("batch of independent proofs, k=19 (bench_ecdsa.config row 1: A=1,L=1,F=1,lookup_bits=18), Blake2b+SHPLONK, "
+            "synthetic same-shape witnesses (job i: seed 0x5eed0019+i, jobs round-robin over ranks and pipelines), one resident "
+            "proving key per pipeline")
 
 
 class ProofWorkload:
-    """BASELINE.json configs[1]: one secp256r1-ECDSA-shape proof at k=19 (1 advice / 1 lookup /
-    1 fixed column config, lookup_bits 18), Blake2b transcript + SHPLONK, whole create_proof on the
-    device: 12 MSM(2^19), 5 iNTT(2^19), 5 coset NTT(2^21), quotient over 2^21 rows, inverse coset
-    NTT, 18 evaluations, multi-open.  Witness: synthetic satisfying assignment of the same column
-    shape (the real secp256r1 witness generation stays on the host and needs the
-    Rust chips), uploaded before the timed region."""
+    """This rank's share of the batch: `inflight` pipelines (own zk_ctx + host thread each) on one GPU, their jobs
+    synthesized on the host (process pool) and shipped to HBM before the clock starts."""
 
-    name = "single-proof k=19 (bench_ecdsa.config row 1: A=1,L=1,F=1,lookup_bits=18), Blake2b+SHPLONK, synthetic same-shape witnesses (job seeds 0x5eed0019+i, round-robin over ranks), one resident proving key"
+    def __init__(self, device, rank, world, inflight, steps, warmup):
+        from webauthn_halo2_amd import batch, circuit, engine as E
 
-    def __init__(self, eng, rank, world_size):
-        from webauthn_halo2_amd import circuit, engine as E
-
-        self.eng = eng
-        self.E = E
+        self.batch, self.E = batch, E
         p = circuit.K19
-        n = 1 << K
-        eng.srs_setup(K)
-        from webauthn_halo2_amd import batch
-
-        # one proving key (the circuit is witness-independent), several independent witnesses:
-        # rank r of N proves jobs r, r + N, ... (BASELINE config 4), each with its own RNG stream
-        self.jobs = batch.assign(range(2 * world_size * 2), rank, world_size)[:2]
+        # rank r proves jobs r, r + N, ...: `steps` timed jobs, all distinct (warm-up re-proves the first ones)
+        self.jobs = [rank + world * j for j in range(max(steps, 1))]
+        self.warm = self.jobs[:max(1, min(len(self.jobs), warmup * inflight))]
         t0 = time.time()
-        asgs = [circuit.synthesize(p, batch.job_seed(j)) for j in self.jobs]
-        self.synth_s = (time.time() - t0) / len(asgs)
-        fixed = np.stack([asgs[0].to_limbs(c) for c in asgs[0].fixed])
+        wit = batch.synthesize_jobs(p, self.jobs)
+        self.synth_s = (time.time() - t0) / len(self.jobs)
+        fixed, copies = batch.structure(p)
         t0 = time.time()
-        self.pk = eng.keygen(p, fixed, asgs[0].copies)
-        self.keygen_s = time.time() - t0
-        self.advice = []
-        for asg in asgs:
-            cols = []
-            for col in asg.advice:
-                h = eng.poly(n)
-                eng.upload_canonical(h, asg.to_limbs(col))
-                cols.append(h)
-            self.advice.append(cols)
-        self.ctr = 0
-        self.proof = b""
+        self.pipes = [batch.Pipeline(device, p, fixed, copies) for _ in range(inflight)]
+        self.keygen_s = (time.time() - t0) / inflight
+        for q, pl in enumerate(self.pipes):
+            for j in self.jobs[q::inflight]:
+                pl.load(j, wit[j])
+        self.engs = [pl.eng for pl in self.pipes]
+        self.proofs = {}
 
-    def step(self):
-        adv = self.advice[self.ctr % len(self.advice)]
-        self.ctr += 1
-        seed = (self.jobs[0] * 1000003 + self.ctr).to_bytes(32, "little")
-        self.proof = self.eng.prove(self.pk, adv, seed, self.E.ZK_TRANSCRIPT_BLAKE2B)
-        self.eng.sync()
+    def run(self, jobs):
+        """Drain `jobs` over the pipelines (job j lives on pipeline index(j) % inflight)."""
+        self.proofs.update(self.batch.run(self.pipes, jobs, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True))
+        for e in self.engs:
+            e.sync()
+
+    def single(self):
+        """One proof alone on the GPU (single-proof wall clock, the second half of BASELINE.json's metric)."""
+        j = self.jobs[0]
+        t1 = time.perf_counter()
+        self.pipes[0].prove(j, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
+        self.engs[0].sync()
+        return (time.perf_counter() - t1) * 1e3
+
+    def close(self):
+        for pl in self.pipes:
+            pl.close()
 
 
 class FakeWorkload:
-    """CPU stand-in used only by the world_size-2 gloo test of the N>1 launch / timing logic
-    (tests/test_multiproc.py): no engine, no GPU; a step is a fixed sleep."""
+    """CPU stand-in used only by the gloo tests of the N>1 launch / timing logic (tests/test_multiproc.py):
+    no engine, no GPU; a step is a fixed sleep."""
 
-    name = "fake (distributed-logic test only)"
     synth_s = keygen_s = 0.0
-    proof = b"\0" * 960
 
-    def __init__(self, rank):
+    def __init__(self, rank, world, steps):
         self.rank = rank
+        self.jobs = [rank + world * j for j in range(steps)]
+        self.warm = self.jobs[:1]
+        self.proofs = {}
 
-    def step(self):
-        time.sleep(0.01 * (1 + self.rank))
+    def run(self, jobs):
+        for j in jobs:
+            time.sleep(0.01 * (1 + self.rank))
+            self.proofs[j] = b"\0" * 960
+
+    def close(self):
+        pass
 
 
 def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
@@ -101,7 +112,7 @@ def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*proof_k19_pmc_hbm.csv")))
     if not files:
         return None
     tot = 0.0
@@ -111,16 +122,20 @@ def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
     return tot or None
 
 
-# XYZZ mixed additions/s the integer VALU sustains with the 9x29-bit carry-free field the kernel uses: register-resident
-# operands, cache-resident points, 128 additions per lane (tools/ubench_f29.hip on MI355X; the 8x32-bit
-# formulation peaks at 11.9)
-ALU_PEAK_GADDS = 15.4
+# Hardware ceiling of the bucket accumulation: the only wide integer multiplier of CDNA4 is v_mad_u64_u32, issued at
+# MAD_CYCLES cycles per wave64 instruction per SIMD (tools/ubench_isa.hip on MI355X, profiles/r2_ubench_isa.txt: independent
+# mads, 4 waves/SIMD).  One XYZZ mixed addition is 8M + 2S = 10 field products; a product on the carry-free 9x29-bit
+# form is 81 (a*b) + 81 (m*p) multiply-adds and nothing cheaper exists on this ISA (8x32-bit limbs: 128 + carries).
+MAD_CYCLES = 4.7
+SIMDS, CLOCK_GHZ = 1024, 2.4
+MADS_PER_ADD = 10 * 162
+ALU_PEAK_GADDS = SIMDS * CLOCK_GHZ / MAD_CYCLES * 64 / MADS_PER_ADD  # = 20.7 G mixed adds/s
 
 
 def alu_roofline(eng, k):
     """The dominant kernel against the roofline that actually bounds it: one commitment of a uniformly
-    random column (what 11 of the 12 MSMs of a proof are), bucket additions per second."""
-    import numpy as np
+    random column (what 9 of the 12 MSMs of a proof are), bucket additions per second against the multiply-add
+    issue rate of the chip."""
     n = 1 << k
     rng = np.random.default_rng(0x19)
     col = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
@@ -137,48 +152,58 @@ def alu_roofline(eng, k):
     ms /= max(cnt, 1)
     adds = n * windows * (1.0 - 2.0 ** -c)  # a signed digit is zero with probability 2^-c
     achieved = adds / (ms * 1e-3) / 1e9
-    return {"kernel": "msm_accumulate_kernel", "bound": "int-valu", "achieved": achieved, "peak": ALU_PEAK_GADDS,
-            "unit": "G mixed adds/s", "frac": achieved / ALU_PEAK_GADDS, "avg_launch_ms": ms, "window_bits": c,
-            "adds_per_launch": adds}
+    return {"kernel": "msm_accumulate_kernel", "bound": "int-valu (v_mad_u64_u32 issue rate)", "achieved": achieved,
+            "peak": ALU_PEAK_GADDS, "unit": "G mixed adds/s", "frac": achieved / ALU_PEAK_GADDS, "avg_launch_ms": ms,
+            "window_bits": c, "adds_per_launch": adds,
+            "peak_model": "%d SIMDs x %.1f GHz / %.1f cycles per wave64 v_mad_u64_u32 x 64 lanes / %d mads per mixed add"
+            % (SIMDS, CLOCK_GHZ, MAD_CYCLES, MADS_PER_ADD)}
 
 
-def cpu_baseline(eng):
-    """Oracle C restatement (halo2 best_multiexp / best_fft) on the host cores:
-    one MSM(2^19) + one NTT(2^19) + one NTT(2^21), scaled to the per-proof operator counts."""
-    from zkoracle import cops, field as F
+def cpu_baseline(budget_s=30.0):
+    """One WHOLE create_proof on the host cores by the oracle's CPU port (oracle/zkoracle/fastprover.py: the
+    reference's algorithms restated — thread-chunked Pippenger best_multiexp for every commitment, radix-2
+    best_fft, row-parallel evaluate_h, Horner evaluations, SHPLONK — C kernels under a Python driver), same
+    workload shape as the timed GPU steps.  Bounded sample: one k=17 proof (seconds), extrapolated to k=19 only
+    if a k=19 proof does not fit the budget."""
+    from zkoracle import fastprover
 
-    n = 1 << K
-    cores = os.cpu_count() or 1
-    bases = eng.srs_export(0, 0, n)
-    s = np.frombuffer(np.random.default_rng(5).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
-    s[:, 3] &= 0x0FFFFFFFFFFFFFFF
-    def best(fn, thread_options):
-        """fastest of a few thread counts (the port spawns a thread team per call/stage: on a many-core
-        host the full core count is not always the fastest choice) — the baseline gets its best case"""
-        bt, bn = None, None
-        for nt in thread_options:
-            t0 = time.time()
-            fn(nt)
-            dt = time.time() - t0
-            if bt is None or dt < bt:
-                bt, bn = dt, nt
-        return bt, bn
+    return fastprover.cpu_baseline(K, budget_s)
 
-    opts = sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True)
-    t_msm, n_msm = best(lambda nt: cops.msm(s, bases, nt), opts)
-    t_ntt19, n_ntt = best(lambda nt: cops.ntt(s, F.omega(K), K, nt), opts)
-    big = np.concatenate([s, s, s, s])
-    t_ntt21, _ = best(lambda nt: cops.ntt(big, F.omega(K + 2), K + 2, nt), opts)
-    per_proof = 12 * t_msm + 5 * t_ntt19 + 6 * t_ntt21
-    return {
-        "value": 1.0 / per_proof,
-        "unit": "proofs/s",
-        "cores": n_msm,  # threads of the fastest configuration actually used
-        "kind": "port",
-        "sample": "host has %d cores; oracle C port of halo2 best_multiexp/best_fft, best of thread counts %s: 1xMSM(2^19)=%.2fs (%d thr), 1xNTT(2^19)=%.3fs (%d thr), 1xNTT(2^21)=%.3fs; "
-        "scaled to 12 MSM + 5 NTT(2^19) + 6 NTT(2^21) per proof (quotient/eval not included); "
-        "the reference Rust prover cannot be built on this node (no cargo/rustc)" % (cores, opts, t_msm, n_msm, t_ntt19, n_ntt, t_ntt21),
-    }
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, fake):
+    """--gpus N > 1 without a launcher: start N per-device workers of this very script (one process per GPU,
+    torch.distributed.run, 127.0.0.1 rendezvous) and relay rank 0's JSON line.  N is clamped to the devices that
+    exist; the line's n_gpus is the number of workers actually used."""
+    n = args.gpus
+    if not fake:
+        import webauthn_halo2_amd as zk
+
+        have = zk.load_library().zk_device_count()
+        if have < 1:
+            raise SystemExit("bench.py: no gfx950 device (no CPU fallback exists)")
+        n = min(n, have)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--inflight", str(args.inflight)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    if n > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port())] + cmd[1:]
+    env = dict(os.environ, ZKMI355_BENCH_WORKER="1")
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    for l in out.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if out.returncode != 0 or len(lines) != 1:
+        raise SystemExit("bench.py: worker launch failed (rc %d)" % out.returncode)
+    print(lines[0])
 
 
 def main():
@@ -187,15 +212,18 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKMI355_INFLIGHT", "2")),
+    ap.add_argument("--inflight", type=int, default=2,
                     help="independent proof pipelines per GPU (each its own zk_ctx + host thread); the K timed steps are "
                          "shared among them.  1 = strictly one proof at a time (single-proof latency).")
     args = ap.parse_args()
 
+    fake = os.environ.get("ZKMI355_BENCH_FAKE") == "1"  # CPU test of the launch/timing logic only
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and os.environ.get("ZKMI355_BENCH_WORKER") != "1":
+        return self_launch(args, fake)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    fake = os.environ.get("ZKMI355_BENCH_FAKE") == "1"  # CPU test of the launch/timing logic only
     dist = None
     torch = None
     if world > 1:
@@ -209,23 +237,18 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    nfl = max(1, args.inflight)
     if fake:
-        eng = None
-        wl = FakeWorkload(rank)
+        wl = FakeWorkload(rank, world, args.steps)
     else:
-        import webauthn_halo2_amd as zk
-
         # independent proof streams: replicas, no data-path collective.  `inflight` pipelines share one GPU so
         # that the latency-bound phases of one proof (transcript round trips, reduction tails) overlap the
         # throughput-bound kernels of another.
-        nfl = max(1, args.inflight)
-        engs = [zk.Engine(local_rank) for _ in range(nfl)]
-        wls = [ProofWorkload(e, rank * nfl + i, world * nfl) for i, e in enumerate(engs)]
-        eng, wl = engs[0], wls[0]
+        wl = ProofWorkload(local_rank, rank, world, nfl, args.steps, args.warmup)
 
     def barrier():
-        if eng is not None:
-            for e in engs:
+        if not fake:
+            for e in wl.engs:
                 e.sync()
         if dist is not None:
             if not fake:
@@ -234,41 +257,21 @@ def main():
             if not fake:
                 torch.cuda.synchronize()
 
-    import threading
-
-    def run_steps(count):
-        """`count` steps in total, shared by the in-flight pipelines (one host thread each)."""
-        if fake or len(wls) == 1:
-            for _ in range(count):
-                wl.step()
-            return
-        share = [count // len(wls) + (1 if i < count % len(wls) else 0) for i in range(len(wls))]
-        ths = [threading.Thread(target=lambda w=w, c=c: [w.step() for _ in range(c)]) for w, c in zip(wls, share)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-
-    if fake:
-        wls = [wl]
-    run_steps(args.warmup * (1 if fake else len(wls)))
+    for _ in range(1 if fake else max(1, (args.warmup * nfl + len(wl.warm) - 1) // len(wl.warm))):
+        wl.run(wl.warm)
     single_ms = None
-    if eng is not None:
-        # single-proof wall clock (the second half of BASELINE.json's metric): one proof alone on the GPU
+    if not fake:
         barrier()
-        singles = []
-        for _ in range(3):
-            t1 = time.perf_counter()
-            wl.step()
-            singles.append((time.perf_counter() - t1) * 1e3)
-        single_ms = sorted(singles)[1]  # median of three
-        for e in engs:
+        single_ms = sorted(wl.single() for _ in range(3))[1]  # median of three
+        for e in wl.engs:
             e.timer_reset()
+    wl.proofs.clear()
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    wl.run(wl.jobs[:args.steps])  # EXACTLY K steps on this rank: K distinct jobs
     barrier()
     elapsed = time.perf_counter() - t0
+    assert len(wl.proofs) == args.steps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if fake else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,11 +280,13 @@ def main():
     if rank == 0 and fake:
         print(json.dumps({"metric": "webauthn_es256_proofs_per_sec_k19", "value": world * args.steps / elapsed,
                           "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "data": "fake"}))
+                          "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "data": "fake",
+                          "jobs_total": world * args.steps}))
     elif rank == 0:
         n = 1 << K
+        eng = wl.engs[0]
         acc_total = acc_n = msm_total = msm_n = cols = 0
-        for e in engs:
+        for e in wl.engs:
             a, b = e.timer_stats(4)  # ZK_T_MSM_ACCUM
             acc_total, acc_n = acc_total + a, acc_n + b
             a, b = e.timer_stats(0)
@@ -289,7 +294,8 @@ def main():
             cols += e.timer_stats(5)[1]  # ZK_T_MSM_COLUMNS: commitments are batched, a launch serves 1-2 columns here
         accum_ms = acc_total / max(acc_n, 1)
         cols_per_launch = cols / max(acc_n, 1)
-        assert len(wl.proof) == 960  # halo2-circuits/src/results/ecdsa_bench.csv:2
+        assert all(len(p) == 960 for p in wl.proofs.values())  # halo2-circuits/src/results/ecdsa_bench.csv:2
+        assert len(set(wl.proofs.values())) == len(wl.proofs)  # distinct jobs -> distinct proofs: nothing cached
         alg_bytes = 96.0 * n * cols_per_launch  # MSM(n) = 32 B scalar + 64 B base per point, per column
         achieved = alg_bytes / (accum_ms * 1e-3) / 1e9
         out = {
@@ -301,14 +307,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "single_proof_ms": single_ms,
-            "inflight_per_gpu": len(wls),
+            "inflight_per_gpu": nfl,
+            "jobs_total": world * args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,  # BASELINE.json "published" is {}: the only reference number (14.846 s/proof, M1 Pro, README.md:38) is other hardware
-            "host_setup": {"synthesize_s": round(wl.synth_s, 3), "keygen_s": round(wl.keygen_s, 3)},
+            "host_setup": {"synthesize_s_per_job": round(wl.synth_s, 3), "keygen_s": round(wl.keygen_s, 3)},
             "dtype": "u256-montgomery (8x32-bit limbs; 9x29-bit carry-free limbs in the bucket accumulation)",
             "data": "synthetic",
-            "config": {"workload": wl.name, "k": K, "transcript": "blake2b", "multiopen": "shplonk", "proof_bytes": len(wl.proof),
+            "config": {"workload": WORKLOAD, "k": K, "transcript": "blake2b", "multiopen": "shplonk", "proof_bytes": 960,
                        "parallelism": "replicas:%d (one independent proof stream per GPU, no collective)" % world},
             "roofline": {
                 "kernel": "msm_accumulate_kernel",
@@ -328,21 +335,20 @@ def main():
         out["roofline"]["alu"] = alu_roofline(eng, K)
         # BASELINE.json configs[2]: the same proof with the EVM (Keccak) transcript and GWC, as /prove_evm makes it
         best = 1e9
+        pl = wl.pipes[0]
         for i in range(3):
             t1 = time.perf_counter()
-            pe = eng.prove(wl.pk, wl.advice[0], bytes([i + 1]) * 32, wl.E.ZK_TRANSCRIPT_EVM)
+            pe = pl.eng.prove(pl.pk, pl.resident[wl.jobs[0]], bytes([i + 1]) * 32, wl.E.ZK_TRANSCRIPT_EVM)
             best = min(best, time.perf_counter() - t1)
         assert len(pe) == 1536
         out["single_proof_evm_ms"] = best * 1e3
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(eng)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if eng is not None:
-        for e in engs:
-            e.close()
+    wl.close()
 
 
 if __name__ == "__main__":

@@ -44,6 +44,7 @@ extern "C" {
 #define ZK_ESTATE (-5)   /* missing prerequisite (SRS / key not loaded) */
 #define ZK_EWITNESS (-6) /* witness violates the circuit (lookup input not in table): halo2's
                             Error::ConstraintSystemFailure */
+#define ZK_EINTERNAL (-7) /* a C++ exception was stopped at the boundary (nothing is ever thrown across it) */
 
 typedef struct zk_ctx zk_ctx;
 typedef uint64_t zk_poly; /* opaque device-resident vector of Fr; 0 is never valid */
@@ -58,12 +59,25 @@ void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_strerror(int code);
 int zk_last_hip_error(const zk_ctx* ctx); /* raw hipError_t of the last ZK_EHIP */
 int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
+/* tuning options (measurement tools, tests); value 0 restores the built-in choice.  The engine reads no
+ * environment variables. */
+#define ZK_OPT_MSM_WINDOW 1          /* signed window bits of the fixed-base MSM, 9..15; takes effect at the next SRS load */
+#define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..64 */
+#define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..9 */
+#define ZK_OPT_GP_BATCH_INVERT 4     /* 1: grand products always take halo2's batch_invert form (the fallback path) */
+int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------
  * replaces halo2_proofs::arithmetic::best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1 */
 int zk_msm_bn254(zk_ctx* ctx, const uint64_t* scalars_mont /* n x 4 */,
                  const uint64_t* bases_affine_mont /* n x 8 */, size_t n,
                  uint64_t out_jacobian_mont[12]);
+/* the same product over the RESIDENT SRS: replaces the body of ParamsKZG::commit (basis g: best_multiexp(&coeffs,
+ * &self.g[..n])) / ParamsKZG::commit_lagrange (basis g_lagrange), where the Rust host knows by construction which
+ * basis it multiplies against.  Only the n <= 2^k scalars are uploaded; the MSM runs on the window tables built at
+ * zk_srs_setup / zk_srs_load / zk_srs_read.  (zk_msm_bn254 never guesses: it always uploads its bases.) */
+int zk_msm_srs(zk_ctx* ctx, int basis /* ZK_BASIS_* */, const uint64_t* scalars_mont /* n x 4 */, size_t n,
+               uint64_t out_jacobian_mont[12]);
 /* replaces halo2_proofs::arithmetic::best_fft(a: &mut [Fr], omega: Fr, log_n: u32); in place,
  * natural order in and out */
 int zk_ntt_bn254_fr(zk_ctx* ctx, uint64_t* a_mont /* 2^log_n x 4 */, const uint64_t omega_mont[4],
@@ -74,10 +88,9 @@ int zk_ntt_bn254_fr(zk_ctx* ctx, uint64_t* a_mont /* 2^log_n x 4 */, const uint6
  * (ecdsa_p256.rs:258,338,388): s = Fr::from_u512(first 64 keystream bytes);
  * g[i] = [s^i]G1, g_lagrange[i] = [L_i(s)]G1, both generated on the device. */
 int zk_srs_setup(zk_ctx* ctx, uint32_t k, const uint8_t seed[32]);
-/* replaces ParamsKZG::read: adopt caller-supplied bases (n = 2^k points each, affine Montgomery).  The two arrays
- * are remembered by address: a later zk_msm_bn254 over the same array (what best_multiexp(coeffs, &params.g_lagrange)
- * is in the Rust host) skips the upload of the bases and runs on the resident window tables.  They must stay
- * unmodified while the SRS is loaded (they are the SRS); evenly spaced sample points are re-checked on every call. */
+/* adopt caller-supplied bases (the in-memory ParamsKZG of a Rust host: params.g / params.g_lagrange, n = 2^k points
+ * each, affine Montgomery).  The arrays are copied; nothing is remembered about them.  Loading an SRS invalidates
+ * every proving key made under the previous one (zk_prove / zk_vk_export return ZK_ESTATE for them). */
 int zk_srs_load(zk_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange);
 int zk_srs_export(zk_ctx* ctx, int basis, uint64_t* out_affine_mont /* n x 8 */, size_t first, size_t count);
 int zk_srs_k(const zk_ctx* ctx); /* -1 if none */
@@ -135,8 +148,13 @@ typedef uint64_t zk_pk; /* opaque: proving key + verifying key + prover workspac
  * holds the fixed columns (n_fix x n x 4 limbs, canonical integers, column order: constants, range
  * table, selectors); `copies` the copy constraints as (perm_col_a, row_a, perm_col_b, row_b) with
  * permutation columns ordered [constants..., gate advice..., lookup advice...].  Needs the SRS of k. */
-int zk_keygen(zk_ctx* ctx, const zk_circuit_params* params, const uint64_t* fixed_canonical,
+int zk_keygen(zk_ctx* ctx, const zk_circuit_params* params, const uint64_t* fixed_canonical /* n_fixed_columns x n x 4 */,
+              size_t n_fixed_columns /* must equal the shape's fixed-column count: ZK_EINVAL otherwise */,
               const uint32_t* copies, size_t n_copies, zk_pk* out);
+/* the vk digest every transcript starts with (halo2 `vk.transcript_repr`, a Blake2b hash of the pinned vk's Debug
+ * form that only the Rust host can compute): zk_keygen stamps a stand-in; the host sets the real value here
+ * (Montgomery image).  zk_pk_read / zk_vk_read take it from the key file's vk instead. */
+int zk_pk_set_transcript_repr(zk_ctx* ctx, zk_pk pk, const uint64_t transcript_repr_mont[4]);
 int zk_pk_free(zk_ctx* ctx, zk_pk pk);
 /* the VerifyingKey half: commitments (affine Montgomery) and transcript_repr; counts = {n_fixed, n_perm} */
 int zk_vk_export(zk_ctx* ctx, zk_pk pk, uint64_t* fixed_commitments, uint64_t* perm_commitments,

@@ -92,10 +92,10 @@ def test_two_contexts_two_threads():
         assert all(r == want for r in res[i])
 
 
-def test_seam_over_the_loaded_srs_arrays():
-    """zk_msm_bn254 over the very arrays zk_srs_load was given runs on the resident window tables (no upload of
-    the bases); any other array — equal content elsewhere, or the same array modified at an unsampled point — takes
-    the general path.  All three give the right sum."""
+def test_resident_srs_seam_is_explicit():
+    """zk_msm_srs (ParamsKZG::commit / commit_lagrange of a Rust host) multiplies host scalars against the RESIDENT
+    basis; zk_msm_bn254 never guesses which basis it was given and always uploads its bases — so an array the host
+    mutated in place after zk_srs_load (same address, stale resident copy) can never be served from the tables."""
     eng = zk.Engine(0)
     k = 12
     n = 1 << k
@@ -106,9 +106,62 @@ def test_seam_over_the_loaded_srs_arrays():
     s = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
     s[:, 3] &= 0x0FFFFFFFFFFFFFFF
     want = cops.jac_to_affine_ints(cops.msm(s, gl))
-    assert cops.jac_to_affine_ints(eng.msm(s, gl)) == want            # aliased: resident tables
-    assert cops.jac_to_affine_ints(eng.msm(s, gl.copy())) == want     # same content, another array: uploaded
-    gl2 = gl.copy()
-    gl2[5] = gl2[7]                                                   # differs at a point no sample looks at
-    assert cops.jac_to_affine_ints(eng.msm(s, gl2)) == cops.jac_to_affine_ints(cops.msm(s, gl2))
+    assert cops.jac_to_affine_ints(eng.msm_srs(s, E.ZK_BASIS_LAGRANGE)) == want   # resident tables, scalars uploaded
+    assert cops.jac_to_affine_ints(eng.msm(s, gl)) == want                        # general path: bases uploaded
+    assert cops.jac_to_affine_ints(eng.msm_srs(s[:1000], E.ZK_BASIS_MONOMIAL)) == cops.jac_to_affine_ints(cops.msm(s[:1000], g[:1000]))
+    gl[5] = gl[7]  # the host rewrites ITS array in place (same address) after the load
+    assert cops.jac_to_affine_ints(eng.msm(s, gl)) == cops.jac_to_affine_ints(cops.msm(s, gl))  # sees the new content
+    assert cops.jac_to_affine_ints(eng.msm_srs(s, E.ZK_BASIS_LAGRANGE)) == want                 # resident copy untouched
+    with pytest.raises(zk.ZkError):
+        eng.msm_srs(np.zeros((n + 1, 4), dtype=np.uint64), E.ZK_BASIS_LAGRANGE)  # longer than the SRS
+    eng.close()
+
+
+def test_srs_reload_invalidates_keys():
+    """A proving key belongs to the SRS it was made under: after zk_srs_setup / zk_srs_load replaces the SRS
+    (same k, other secret) zk_prove and zk_vk_export refuse the old key with ZK_ESTATE instead of emitting a proof
+    whose vk commitments belong to the old SRS."""
+    eng = zk.Engine(0)
+    params = zk.circuit.CircuitParams(degree=7, num_advice=1, num_lookup_advice=1, num_fixed=1, lookup_bits=5)
+    asg = zk.circuit.synthesize(params, 1)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    eng.srs_setup(7)
+    pk = eng.keygen(params, fixed, asg.copies)
+    h = eng.poly(128)
+    eng.upload_canonical(h, asg.to_limbs(asg.advice[0]))
+    assert len(eng.prove(pk, [h], bytes(32))) > 0
+    eng.srs_setup(7, b"\x01" * 32)
+    with pytest.raises(zk.ZkError) as e:
+        eng.prove(pk, [h], bytes(32))
+    assert e.value.code == -5
+    with pytest.raises(zk.ZkError) as e:
+        eng.vk_export(pk)
+    assert e.value.code == -5
+    pk2 = eng.keygen(params, fixed, asg.copies)
+    assert len(eng.prove(pk2, [h], bytes(32))) > 0
+    eng.close()
+
+
+def test_keygen_validates_its_inputs():
+    eng = zk.Engine(0)
+    eng.srs_setup(7)
+    params = zk.circuit.CircuitParams(degree=7, num_advice=1, num_lookup_advice=1, num_fixed=1, lookup_bits=5)
+    asg = zk.circuit.synthesize(params, 1)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    with pytest.raises(ValueError):
+        eng.keygen(params, fixed[:, :64], asg.copies)          # wrong row count (Python-side shape check)
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(params, fixed[:-1], asg.copies)             # one fixed column short: ZK_EINVAL, no out-of-bounds read
+    assert e.value.code == -1
+    for lb in (0, 7, 31, 32, 40):                              # lookup_bits must be in [1, k)
+        bad = zk.circuit.CircuitParams(degree=7, num_advice=1, num_lookup_advice=1, num_fixed=1, lookup_bits=lb)
+        with pytest.raises(zk.ZkError) as e:
+            eng.keygen(bad, fixed, asg.copies)
+        assert e.value.code == -1
+    with pytest.raises(ValueError):
+        eng.srs_setup(7, b"short")
+    with pytest.raises(zk.ZkError):
+        eng.set_option(99, 1)
+    with pytest.raises(zk.ZkError):
+        eng.set_option(E.ZK_OPT_MSM_WINDOW, 40)
     eng.close()

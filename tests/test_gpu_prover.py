@@ -78,16 +78,18 @@ def test_proofs_byte_identical_to_oracle(engine, name):
     engine.pk_free(pk)
 
 
-def test_batch_inversion_fallback_same_bytes(engine, monkeypatch):
+def test_batch_inversion_fallback_same_bytes(engine):
     """The grand products normally use one inversion per product (prefix x suffix scans); a zero
     denominator sends them down the batch-inversion path.  Both must give the same proof."""
     A, L, F, k, lb = SHAPES["k17like"]
     _, asg, pk, polys = setup(engine, A, L, F, k, lb)
     seed = b"\x21" * 32
     a = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
-    monkeypatch.setenv("ZKMI355_BATCH_INVERT", "1")
-    b = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
-    monkeypatch.delenv("ZKMI355_BATCH_INVERT")
+    engine.set_option(E.ZK_OPT_GP_BATCH_INVERT, 1)
+    try:
+        b = engine.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
+    finally:
+        engine.set_option(E.ZK_OPT_GP_BATCH_INVERT, 0)
     assert a == b
     for h in polys:
         h.free()
@@ -208,33 +210,100 @@ def test_one_key_many_witnesses(engine):
     engine.pk_free(pk)
 
 
-def test_reference_api_mirror(engine, tmp_path):
-    """download_keys / generate_proof / generate_proof_evm (reference ecdsa_p256.rs:256-427) at the
-    server's default degree 17 (proving-server/src/main.rs:17): sizes as published, accepted by the
-    pinned verifier, same request -> same witness, error behaviour on bad input."""
+def es256_request(seed=1):
+    """A valid ES256 request in the server's encoding (five 32-byte little-endian fields)."""
+    import random
     from webauthn_halo2_amd import ecdsa_p256 as api
+    rng = random.Random(seed)
+    d, kk, z = (rng.randrange(1, api._N) for _ in range(3))
+    q = api._p256_mul(d, api._G)
+    r = api._p256_mul(kk, api._G)[0] % api._N
+    s = pow(kk, -1, api._N) * (z + r * d) % api._N
+    le = lambda v: v.to_bytes(32, "little")
+    return [le(q[0]), le(q[1]), le(r), le(s), le(z)]  # pubkey_x, pubkey_y, r, s, msg_hash
+
+
+def test_reference_api_mirror(engine, tmp_path):
+    """download_keys + the request-shaped provers (reference ecdsa_p256.rs:256-427) at the server's default
+    degree 17 (proving-server/src/main.rs:17): sizes as published, accepted by the pinned verifier, same
+    request -> same witness, error behaviour on bad input; an INVALID signature is refused (the
+    synthetic stand-in must never turn arbitrary bytes into a verifying proof); the JSON-in / hex-out
+    contract of the server (main.rs:39-79) on top."""
+    import json
+    from webauthn_halo2_amd import ecdsa_p256 as api, proving_server as srv
 
     api._STATE.clear()
     pkp, vkp = str(tmp_path / "proving_key.pk"), str(tmp_path / "verifying_key.vk")
     api.download_keys(17, pkp, vkp)
     eng = api._STATE[0]["eng"]
-    req = [bytes([i]) * 32 for i in range(5)]
+    req = es256_request()
+    assert not hasattr(api, "generate_proof") and not hasattr(api, "generate_proof_evm")
     with pytest.raises(FileNotFoundError):
-        api.generate_proof(*req, str(tmp_path / "missing.pk"), 17)
+        api.generate_proof_synthetic(*req, str(tmp_path / "missing.pk"), 17)
     with pytest.raises(ValueError):
-        api.generate_proof(b"short", *req[1:], pkp, 17)
-    pf = api.generate_proof(*req, pkp, 17, rng_seed=bytes(32))
-    pe = api.generate_proof_evm(*req, pkp, 17, rng_seed=bytes(32))
+        api.generate_proof_synthetic(b"short", *req[1:], pkp, 17)
+    with pytest.raises(ValueError):
+        api.generate_proof_synthetic(*[bytes([i]) * 32 for i in range(5)], pkp, 17)   # arbitrary bytes: not a signature
+    bad = list(req)
+    bad[3] = (int.from_bytes(req[3], "little") ^ 2).to_bytes(32, "little")            # one bit of s flipped
+    with pytest.raises(ValueError):
+        api.generate_proof_evm_synthetic(*bad, pkp, 17)
+    pf = api.generate_proof_synthetic(*req, pkp, 17, rng_seed=bytes(32))
+    pe = api.generate_proof_evm_synthetic(*req, pkp, 17, rng_seed=bytes(32))
     assert (len(pf), len(pe)) == (1920, 2720)
-    assert pe == api.generate_proof_evm(*req, pkp, 17, rng_seed=bytes(32))
-    assert pe != api.generate_proof_evm(*req, pkp, 17)  # OsRng-style fresh randomness
+    assert pe == api.generate_proof_evm_synthetic(*req, pkp, 17, rng_seed=bytes(32))
+    assert pe != api.generate_proof_evm_synthetic(*req, pkp, 17)  # OsRng-style fresh randomness
     sh = plonk.Shape(17, 4, 1, 1, 16)
     p, pk = api._STATE[0]["keys"][pkp]
     vk = product_vk(eng, pk, sh)
     assert plonk.verify(vk, pf, "blake2b") and plonk.verify(vk, pe, "evm")
     assert os.path.getsize(vkp) == 12 + (6 + 6) * 64 + 32
+    # the engine's real input: advice columns handed over by the host
+    asg = zk.circuit.synthesize(p, api._witness_seed(*req))
+    assert api.create_proof_from_advice([asg.to_limbs(c) for c in asg.advice], pkp, 17, E.ZK_TRANSCRIPT_EVM, rng_seed=bytes(32)) == pe
+    # JSON in, hex out
+    body = {"pubkey_x": list(req[0]), "pubkey_y": list(req[1]), "r": list(req[2]), "s": list(req[3]), "msghash": list(req[4]),
+            "proving_key_path": pkp}
+    assert srv.prove_evm(json.dumps(body), rng_seed=bytes(32)) == pe.hex()
+    assert bytes.fromhex(srv.prove(body, rng_seed=bytes(32))) == pf
+    outs = srv.prove_batch([body, dict(body, r=[0] * 32), body], evm=True, devices=(0,))
+    assert isinstance(outs[1], ValueError) and len(outs[0]) == len(outs[2]) == 2 * 2720
+    assert plonk.verify(vk, bytes.fromhex(outs[2]), "evm")
+    for brk in (dict(body, r=list(req[2])[:31]), dict(body, s=[256] + list(req[3])[1:]), {k: v for k, v in body.items() if k != "msghash"}):
+        with pytest.raises(ValueError):
+            srv.prove_evm(brk)
     eng.close()
     api._STATE.clear()
+
+
+def test_batch_of_jobs_equals_lone_proofs():
+    """BASELINE config 4 in small: a batch of 10 independent jobs (witness seeds 0x5eed0019 + i) drained by two
+    pipelines (own zk_ctx + host thread each, one shared device here) gives, job by job, the bytes a lone
+    pipeline produces for that job — and those are the oracle's bytes."""
+    from webauthn_halo2_amd import batch
+    p = zk.circuit.CircuitParams(degree=9, num_advice=2, num_lookup_advice=1, num_fixed=1, lookup_bits=7)
+    jobs = list(range(10))
+    wit = batch.synthesize_jobs(p, jobs, processes=2)
+    fixed, copies = batch.structure(p)
+    pipes = [batch.Pipeline(0, p, fixed, copies) for _ in range(2)]
+    for q, pl in enumerate(pipes):
+        for j in jobs[q::2]:
+            pl.load(j, wit[j])
+    got = batch.run(pipes, jobs, E.ZK_TRANSCRIPT_EVM)
+    assert sorted(got) == jobs and len(set(got.values())) == len(jobs)
+    lone = batch.Pipeline(0, p, fixed, copies)
+    for j in jobs:
+        lone.load(j, wit[j])
+        assert lone.prove(j, E.ZK_TRANSCRIPT_EVM) == got[j]
+    # two of them against the oracle prover (same witness generator, same RNG stream)
+    sh = plonk.Shape(9, 2, 1, 1, 7)
+    asg0 = zk.circuit.synthesize(p, 0)
+    opk = prover.keygen(prover.Circuit(sh, asg0.fixed, asg0.copies, asg0.advice))
+    for j in (0, 7):
+        asg = zk.circuit.synthesize(p, batch.job_seed(j))
+        assert got[j] == prover.create_proof(opk, asg.advice, ChaCha20Rng(batch.job_rng_seed(j)), "evm")
+    for pl in pipes + [lone]:
+        pl.close()
 
 
 def test_concurrent_pipelines_are_deterministic():

@@ -34,6 +34,26 @@ def test_bench_two_ranks_gloo():
     assert abs(j["value"] - 2 * 5 / (j["ms_per_step"] * 5 / 1e3)) < 1e-6
 
 
+def test_bench_launches_its_own_workers():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the script itself starts one worker per
+    device (torch.distributed.run on 127.0.0.1) and relays rank 0's single JSON line — what the driver's 8-GPU run
+    relies on.  Fake workload (no GPU here): rank r sleeps 10 (r + 1) ms per job."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ZKMI355_BENCH_WORKER")}
+    env["ZKMI355_BENCH_FAKE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["jobs_total"] == 8
+    assert j["ms_per_step"] >= 19.0  # the slower rank sets the clock
+    # --gpus 1 stays in-process
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
 def test_job_seeds_are_disjoint_across_ranks():
     # BASELINE config 4: job i uses witness seed 0x5eed0019 + i; rank r of N takes i = r, r + N, ...
     import webauthn_halo2_amd as zk

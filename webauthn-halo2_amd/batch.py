@@ -1,7 +1,23 @@
-"""Batch driver for independent proofs (BASELINE.json configs[3]): jobs are assigned round-robin,
-one proof in flight per GPU, no collective.  Mirrors the request shape of the reference's
-/prove endpoints (proving-server/src/main.rs:39-79): a job is one (r, s, pubkey, msghash) tuple; here
-it selects the synthetic witness seed (0x5eed0019 + i)."""
+"""Batch driver for independent proofs (BASELINE.json configs[3]; SURVEY.md §8d "config 4", §8e).
+
+The reference's concurrency model is one Rocket worker thread per request, each running its own
+`create_proof` (proving-server/src/main.rs:457-472).  Here that is: one `Pipeline` (= one `zk_ctx`: HIP
+device + streams + resident SRS / proving key + host thread) per in-flight proof, one or more pipelines per
+GPU, jobs dealt round-robin; a job is one request — here one synthetic witness of seed 0x5eed0019 + i
+ — and its result is the proof bytes.  Replicas only: no data-path collective, nothing is
+exchanged between pipelines (§8e).
+
+    assign(jobs, rank, world)            round-robin shard of a job list
+    synthesize_jobs(params, jobs)        host witness generation for a list of jobs (process pool)
+    Pipeline(device, params)             resident SRS + key on one device; .load(job, cols) / .prove(job)
+    run(pipelines, jobs, transcript)     drains `jobs` over the pipelines (one host thread each) -> {job: proof}
+"""
+import threading
+
+import numpy as np
+
+from . import circuit
+from .engine import ZK_TRANSCRIPT_BLAKE2B, Engine
 
 BASE_SEED = 0x5EED0019
 
@@ -10,18 +26,109 @@ def job_seed(i: int) -> int:
     return BASE_SEED + i
 
 
+def job_rng_seed(i: int) -> bytes:
+    """create_proof's RNG stream for job i (the reference draws from OsRng, ecdsa_p256.rs:412; a fixed
+    per-job seed makes a batch reproducible and comparable with lone proofs)."""
+    return (0x9E3779B97F4A7C15 * (i + 1) % (1 << 256)).to_bytes(32, "little")
+
+
 def assign(jobs, rank: int, world: int):
     """Round-robin shard of the job list for `rank` of `world` (weak scaling: no exchange)."""
     return list(jobs)[rank::world]
 
 
-def run(engine, pk, params, jobs, transcript, make_witness, upload):
-    """Prove every job in `jobs` on `engine`; returns {job: proof bytes}."""
-    out = {}
-    for i in jobs:
-        asg = make_witness(params, job_seed(i))
-        polys = upload(engine, asg)
-        out[i] = engine.prove(pk, polys, i.to_bytes(32, "little"), transcript)
-        for p in polys:
+def _synth_one(args):
+    params, i, worst = args
+    asg = circuit.synthesize(params, job_seed(i), worst_case=worst)
+    return i, [asg.to_limbs(col) for col in asg.advice]
+
+
+def synthesize_jobs(params, jobs, processes=None, worst_case=False):
+    """Advice columns (canonical limbs) of every job: {job: [(n, 4) uint64 per advice column]}.
+    Witness generation is host work (in the reference: ECDSACircuit::synthesize, ecdsa_p256.rs:117-206);
+    jobs are independent, so a process pool spreads them over the host cores."""
+    jobs = list(jobs)
+    if not jobs:
+        return {}
+    if processes is None:
+        import os
+        processes = min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 32)
+    args = [(params, i, worst_case) for i in jobs]
+    if processes <= 1 or len(jobs) == 1:
+        return dict(_synth_one(a) for a in args)
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(processes) as pool:
+        return dict(pool.imap_unordered(_synth_one, args, chunksize=1))
+
+
+def structure(params):
+    """The witness-independent half of synthesis: fixed columns + copy constraints (one proving key for all jobs)."""
+    asg = circuit.synthesize(params, 0)
+    return np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies
+
+
+class Pipeline:
+    """One proof in flight: a zk_ctx on `device` with the SRS of params.degree and the proving key resident."""
+
+    def __init__(self, device, params, fixed=None, copies=None, engine_factory=Engine):
+        self.params = params
+        self.eng = engine_factory(device)
+        self.eng.srs_setup(params.degree)
+        if fixed is None:
+            fixed, copies = structure(params)
+        self.pk = self.eng.keygen(params, fixed, copies)
+        self.resident = {}  # job -> [Poly]
+
+    def load(self, job, columns):
+        """Ship a job's advice columns to the device (the per-request H2D of a real host)."""
+        n = 1 << self.params.degree
+        polys = []
+        for col in columns:
+            h = self.eng.poly(n)
+            self.eng.upload_canonical(h, col)
+            polys.append(h)
+        self.resident[job] = polys
+
+    def prove(self, job, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False):
+        proof = self.eng.prove(self.pk, self.resident[job], job_rng_seed(job), transcript)
+        if not keep:
+            self.unload(job)
+        return proof
+
+    def unload(self, job):
+        for p in self.resident.pop(job, []):
             p.free()
+
+    def close(self):
+        for job in list(self.resident):
+            self.unload(job)
+        self.eng.close()
+
+
+def run(pipelines, jobs, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False, on_done=None):
+    """Drain `jobs` (already loaded: pipeline q holds jobs[q::len(pipelines)]) — one host thread per pipeline,
+    as the reference has one worker thread per request.  Returns {job: proof bytes}."""
+    jobs = list(jobs)
+    out = {}
+    errs = []
+
+    def work(q):
+        try:
+            for j in jobs[q::len(pipelines)]:
+                out[j] = pipelines[q].prove(j, transcript, keep)
+                if on_done:
+                    on_done(j)
+        except Exception as e:  # surfaced to the caller below
+            errs.append(e)
+
+    if len(pipelines) == 1:
+        work(0)
+    else:
+        ths = [threading.Thread(target=work, args=(q,)) for q in range(len(pipelines))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    if errs:
+        raise errs[0]
     return out

@@ -1,6 +1,7 @@
 // ctx.h — the engine context shared by engine.hip (C-ABI) and prover.hip.
 #pragma once
 #include <map>
+#include <new>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -31,11 +32,9 @@ struct zk_ctx {
     G1Affine* g_table = nullptr;           // window multiples of g / g_lagrange (fixed-base MSM)
     G1Affine* g_lagrange_table = nullptr;
     uint32_t table_c = 0;
-    // The host arrays zk_srs_load was given (the Rust host's params.g / params.g_lagrange): when the fine-grained seam
-    // is called with the same array again it uses the resident copy.  256 sampled points guard against the array
-    // having been rewritten in the meantime.
-    const void* srs_host[2] = {nullptr, nullptr};
-    std::vector<G1Affine> srs_sample[2];
+    uint64_t srs_gen = 0;  // bumped by every zk_srs_setup / zk_srs_load / zk_srs_read: keys remember the SRS they were made under
+    // tuning options (zk_ctx_set_option); 0 = built-in choice
+    uint32_t opt_msm_window = 0, opt_msm_batch = 0, opt_ntt_max_r = 0, opt_gp_batch_invert = 0;
     // MSM lanes: each in-flight MSM owns a workspace, a tail stream and a pinned result buffer
     static constexpr int MSM_LANES = 3;
     struct MsmLane {
@@ -72,6 +71,21 @@ struct zk_ctx {
     uint64_t msm_launches = 0;
     float last_plain_ms[ZK_T_COUNT] = {0};
 };
+
+// Every `extern "C"` entry point is defined through ZK_API: the body runs inside a try block, so that no C++
+// exception (std::bad_alloc from the host-side containers, anything else) crosses the C boundary.
+#define ZK_API(name, params, args)                          \
+    static int name##_impl params;                          \
+    extern "C" int name params {                            \
+        try {                                               \
+            return name##_impl args;                        \
+        } catch (const std::bad_alloc&) {                   \
+            return ZK_ENOMEM;                               \
+        } catch (...) {                                     \
+            return ZK_EINTERNAL;                            \
+        }                                                   \
+    }                                                       \
+    static int name##_impl params
 
 #define HIPCHK(ctx, x)                 \
     do {                               \

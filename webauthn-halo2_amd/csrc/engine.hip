@@ -71,9 +71,9 @@ int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
 // columns per fixed-base launch.  Batching makes the accumulate launch bigger (fuller waves: -15 % per column
 // already at two columns of 2^19) and replaces several reduction tails by one longer one; measured best
 // (whole proofs): 2 at 2^19, growing as the columns get shorter and launch overheads dominate
-static uint32_t batch_for(size_t n) {
+static uint32_t batch_for(const zk_ctx* c, size_t n) {
     size_t b = ((size_t)1 << 20) / (n ? n : 1);
-    if (const char* e = getenv("ZKMI355_MSM_BATCH")) b = (size_t)atoi(e);  // tuning override
+    if (c->opt_msm_batch) b = c->opt_msm_batch;  // zk_ctx_set_option(ZK_OPT_MSM_BATCH)
     if (b < 1) b = 1;
     if (b > MSM_MAX_BATCH) b = MSM_MAX_BATCH;
     return (uint32_t)b;
@@ -81,7 +81,7 @@ static uint32_t batch_for(size_t n) {
 
 uint32_t ctx_msm_max_batch(const zk_ctx* c) {
     if (c->srs_k < 0 || !c->table_c) return 1;
-    return batch_for((size_t)1 << c->srs_k);
+    return batch_for(c, (size_t)1 << c->srs_k);
 }
 
 // device staging buffer `which` of at least `bytes` (kept for the next call: a Rust host patched at best_multiexp /
@@ -113,7 +113,7 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, MsmWorkspace** out) {
     }
     if (!L.ws) {
         hipError_t e;
-        L.ws = msm_workspace_create(want, 0, &e, batch_for(want));
+        L.ws = msm_workspace_create(want, msm_auto_window(want, c->opt_msm_window), &e, batch_for(c, want));
         if (!L.ws) {
             c->last_hip = (int)e;
             return e == hipErrorInvalidValue ? ZK_EINVAL : ZK_ENOMEM;
@@ -221,11 +221,12 @@ const char* zk_strerror(int code) {
         case ZK_ENODEV: return "no usable gfx950 device";
         case ZK_ESTATE: return "missing prerequisite (SRS / key not loaded)";
         case ZK_EWITNESS: return "witness does not satisfy the circuit (lookup input outside the table)";
+        case ZK_EINTERNAL: return "internal error (C++ exception stopped at the ABI boundary)";
         default: return "unknown error";
     }
 }
 
-int zk_ctx_create(int device_id, zk_ctx** out) {
+ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
     if (!out) return ZK_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ENODEV;
@@ -299,7 +300,7 @@ void zk_ctx_destroy(zk_ctx* c) {
 
 int zk_last_hip_error(const zk_ctx* c) { return c ? c->last_hip : 0; }
 
-int zk_sync(zk_ctx* c) {
+ZK_API(zk_sync, (zk_ctx* c), (c)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
@@ -308,7 +309,7 @@ int zk_sync(zk_ctx* c) {
     return ZK_OK;
 }
 
-int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
+ZK_API(zk_last_kernel_ms, (zk_ctx* c, int which, float* out_ms), (c, which, out_ms)) {
     if (!c || !out_ms || which < 0 || which >= ZK_T_COUNT) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (which == ZK_T_MSM || which == ZK_T_MSM_ACCUM) {
@@ -326,7 +327,7 @@ int zk_last_kernel_ms(zk_ctx* c, int which, float* out_ms) {
     return ZK_OK;
 }
 
-int zk_timer_reset(zk_ctx* c) {
+ZK_API(zk_timer_reset, (zk_ctx* c), (c)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     for (int i = 0; i < ZK_T_COUNT; i++) {
@@ -336,7 +337,7 @@ int zk_timer_reset(zk_ctx* c) {
     return ZK_OK;
 }
 
-int zk_timer_stats(zk_ctx* c, int which, double* total_ms, uint64_t* count) {
+ZK_API(zk_timer_stats, (zk_ctx* c, int which, double* total_ms, uint64_t* count), (c, which, total_ms, count)) {
     if (!c || which < 0 || which >= ZK_T_COUNT || !total_ms || !count) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     *total_ms = c->acc_ms[which];
@@ -344,11 +345,32 @@ int zk_timer_stats(zk_ctx* c, int which, double* total_ms, uint64_t* count) {
     return ZK_OK;
 }
 
+ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, value)) {
+    if (!c || value < 0) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    switch (option) {
+        case ZK_OPT_MSM_WINDOW:
+            if (value && (value < 9 || value > 15)) return ZK_EINVAL;
+            c->opt_msm_window = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_MSM_BATCH:
+            if (value > MSM_MAX_BATCH) return ZK_EINVAL;
+            c->opt_msm_batch = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_NTT_MAX_RADIX_LOG2:
+            if (value && (value < 1 || value > 9)) return ZK_EINVAL;
+            c->opt_ntt_max_r = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_GP_BATCH_INVERT:
+            c->opt_gp_batch_invert = value ? 1 : 0;
+            return ZK_OK;
+        default: return ZK_EINVAL;
+    }
+}
+
 // ---- fine-grained seam -------------------------------------------------------
 
-static bool seam_is_resident_basis(const zk_ctx* c, int b, const uint64_t* bases, size_t n);
-
-int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out[12]) {
+ZK_API(zk_msm_bn254, (zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out[12]), (c, scalars, bases, n, out)) {
     if (!c || !out || (n && (!scalars || !bases))) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
@@ -364,11 +386,9 @@ int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size
     Fr* d_s = nullptr;
     G1Affine* d_b = nullptr;
     if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_s))) return rc;
-    // the host's own copy of the resident SRS: no upload of the bases, window-table MSM
-    if (seam_is_resident_basis(c, 1, bases, n)) d_b = c->g_lagrange;
-    else if (seam_is_resident_basis(c, 0, bases, n)) d_b = c->g;
+    // arbitrary bases: both operands are uploaded on every call (the resident-SRS form is zk_msm_srs)
     if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
-    if (!d_b && rc == ZK_OK) {
+    if (rc == ZK_OK) {
         if ((rc = seam_buffer(c, 1, n * sizeof(G1Affine), (void**)&d_b))) return rc;
         if (hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     }
@@ -378,7 +398,31 @@ int zk_msm_bn254(zk_ctx* c, const uint64_t* scalars, const uint64_t* bases, size
     return rc;
 }
 
-int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+ZK_API(zk_msm_srs, (zk_ctx* c, int basis, const uint64_t* scalars, size_t n, uint64_t out[12]), (c, basis, scalars, n, out)) {
+    if (!c || !out || (n && !scalars) || (basis != ZK_BASIS_MONOMIAL && basis != ZK_BASIS_LAGRANGE)) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->srs_k < 0) return ZK_ESTATE;
+    if (n > ((size_t)1 << c->srs_k)) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    G1Jac res;
+    if (n == 0) {
+        res.x = Fq::one();
+        res.y = Fq::one();
+        res.z = Fq::zero();
+        memcpy(out, &res, 96);
+        return ZK_OK;
+    }
+    Fr* d_s = nullptr;
+    if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_s))) return rc;
+    if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
+    if (rc == ZK_OK) rc = ctx_msm_device(c, d_s, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, n, &res);
+    hipStreamSynchronize(c->stream);
+    if (rc == ZK_OK) memcpy(out, &res, 96);
+    return rc;
+}
+
+ZK_API(zk_ntt_bn254_fr, (zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t log_n), (c, a, omega, log_n)) {
     if (!c || !a || !omega || log_n > 26) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
@@ -416,6 +460,7 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
     job.log_n = log_n;
     job.inverse = inverse;
     job.n_in = job.n_out = (uint32_t)n;
+    job.max_log_r = c->opt_ntt_max_r;
     if (hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     if (rc == ZK_OK) {
         hipEventRecord(c->ev[ZK_T_NTT][0], c->stream);
@@ -442,13 +487,11 @@ int zk_ntt_bn254_fr(zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32_t lo
 }
 
 // ---- SRS ---------------------------------------------------------------------
-static constexpr uint32_t SRS_SAMPLES = 256;
-
 // window-multiple tables of both bases for the fixed-base MSM (k >= 10; smaller SRS use the generic path)
 static int srs_build_tables(zk_ctx* c, uint32_t k) {
     if (k < 10) return ZK_OK;
     const uint32_t n = 1u << k;
-    const uint32_t cw = msm_auto_window(n);
+    const uint32_t cw = msm_auto_window(n, c->opt_msm_window);
     const size_t cnt = (size_t)msm_num_windows(cw) * n;
     if (hipMalloc(&c->g_table, cnt * sizeof(G1Affine)) != hipSuccess ||
         hipMalloc(&c->g_lagrange_table, cnt * sizeof(G1Affine)) != hipSuccess)
@@ -461,37 +504,12 @@ static int srs_build_tables(zk_ctx* c, uint32_t k) {
         return ZK_EHIP;
     }
     c->table_c = cw;
-    // fingerprints of the two bases (SRS_SAMPLES evenly spaced points each) for zk_msm_bn254
-    for (int b = 0; b < 2; b++) {
-        c->srs_sample[b].resize(SRS_SAMPLES);
-        const G1Affine* src = b ? c->g_lagrange : c->g;
-        if (hipMemcpy2D(c->srs_sample[b].data(), sizeof(G1Affine), src, (size_t)(n / SRS_SAMPLES) * sizeof(G1Affine), sizeof(G1Affine),
-                        SRS_SAMPLES, hipMemcpyDeviceToHost) != hipSuccess) {
-            c->srs_sample[b].clear();
-            return ZK_EHIP;
-        }
-    }
     return ZK_OK;
-}
-
-// Is the host array `bases` (n points) the one zk_srs_load was given as basis b?  A Rust host patched at
-// best_multiexp passes &params.g / &params.g_lagrange on every call: the same array it loaded the SRS from.  Then the
-// upload of the bases is skipped and the window-table MSM runs on the resident copy.  The sampled points are a guard
-// against the array having been rewritten since (the contract of zk_srs_load: the arrays are the SRS, immutable).
-static bool seam_is_resident_basis(const zk_ctx* c, int b, const uint64_t* bases, size_t n) {
-    if (c->srs_k < 0 || !c->table_c || n != ((size_t)1 << c->srs_k) || c->srs_sample[b].size() != SRS_SAMPLES) return false;
-    if (c->srs_host[b] != (const void*)bases) return false;
-    const size_t step = n / SRS_SAMPLES;
-    for (uint32_t j = 0; j < SRS_SAMPLES; j++)
-        if (memcmp(bases + (size_t)j * step * 8, &c->srs_sample[b][j], sizeof(G1Affine)) != 0) return false;
-    return true;
 }
 
 static int srs_alloc(zk_ctx* c, uint32_t k) {
     if (k < 1 || k > 24) return ZK_EINVAL;
-    c->srs_sample[0].clear();
-    c->srs_sample[1].clear();
-    c->srs_host[0] = c->srs_host[1] = nullptr;
+    c->srs_gen++;  // proving keys made under the previous SRS are refused from now on (ZK_ESTATE)
     const size_t n = (size_t)1 << k;
     if (c->g) hipFree(c->g);
     if (c->g_lagrange) hipFree(c->g_lagrange);
@@ -505,7 +523,7 @@ static int srs_alloc(zk_ctx* c, uint32_t k) {
     return ZK_OK;
 }
 
-int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
+ZK_API(zk_srs_setup, (zk_ctx* c, uint32_t k, const uint8_t seed[32]), (c, k, seed)) {
     if (!c || !seed) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
@@ -585,7 +603,7 @@ int zk_srs_setup(zk_ctx* c, uint32_t k, const uint8_t seed[32]) {
     return rc;
 }
 
-int zk_srs_load(zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl) {
+ZK_API(zk_srs_load, (zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl), (c, k, g, gl)) {
     if (!c || !g || !gl) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
@@ -596,12 +614,10 @@ int zk_srs_load(zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* gl) {
     HIPCHK(c, hipMemcpy(c->g_lagrange, gl, bytes, hipMemcpyHostToDevice));
     if ((rc = srs_build_tables(c, k)) != ZK_OK) return rc;
     c->srs_k = (int)k;
-    c->srs_host[0] = g;
-    c->srs_host[1] = gl;
     return ZK_OK;
 }
 
-int zk_srs_export(zk_ctx* c, int basis, uint64_t* out, size_t first, size_t count) {
+ZK_API(zk_srs_export, (zk_ctx* c, int basis, uint64_t* out, size_t first, size_t count), (c, basis, out, first, count)) {
     if (!c || !out) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->srs_k < 0) return ZK_ESTATE;
@@ -616,7 +632,7 @@ int zk_srs_export(zk_ctx* c, int basis, uint64_t* out, size_t first, size_t coun
 
 int zk_srs_k(const zk_ctx* c) { return c ? c->srs_k : -1; }
 
-int zk_srs_msm_plan(const zk_ctx* c, uint32_t* window_bits, uint32_t* windows) {
+ZK_API(zk_srs_msm_plan, (const zk_ctx* c, uint32_t* window_bits, uint32_t* windows), (c, window_bits, windows)) {
     if (!c || !window_bits || !windows) return ZK_EINVAL;
     if (c->srs_k < 0) return ZK_ESTATE;
     *window_bits = c->table_c;  // 0: no window-multiple tables (k < 10), zk_commit takes the generic path
@@ -631,7 +647,7 @@ static PolyRec* find_poly(zk_ctx* c, zk_poly h) {
     return it == c->polys.end() ? nullptr : &it->second;
 }
 
-int zk_poly_alloc(zk_ctx* c, size_t n, zk_poly* out) {
+ZK_API(zk_poly_alloc, (zk_ctx* c, size_t n, zk_poly* out), (c, n, out)) {
     if (!c || !out || n == 0) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
@@ -644,7 +660,7 @@ int zk_poly_alloc(zk_ctx* c, size_t n, zk_poly* out) {
     return ZK_OK;
 }
 
-int zk_poly_free(zk_ctx* c, zk_poly h) {
+ZK_API(zk_poly_free, (zk_ctx* c, zk_poly h), (c, h)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
@@ -656,7 +672,7 @@ int zk_poly_free(zk_ctx* c, zk_poly h) {
     return ZK_OK;
 }
 
-int zk_poly_len(zk_ctx* c, zk_poly h, size_t* out) {
+ZK_API(zk_poly_len, (zk_ctx* c, zk_poly h, size_t* out), (c, h, out)) {
     if (!c || !out) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
@@ -665,7 +681,7 @@ int zk_poly_len(zk_ctx* c, zk_poly h, size_t* out) {
     return ZK_OK;
 }
 
-int zk_poly_upload(zk_ctx* c, zk_poly h, const uint64_t* host, size_t n) {
+ZK_API(zk_poly_upload, (zk_ctx* c, zk_poly h, const uint64_t* host, size_t n), (c, h, host, n)) {
     if (!c || !host) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
@@ -678,7 +694,7 @@ int zk_poly_upload(zk_ctx* c, zk_poly h, const uint64_t* host, size_t n) {
     return ZK_OK;
 }
 
-int zk_poly_download(zk_ctx* c, zk_poly h, uint64_t* host, size_t n) {
+ZK_API(zk_poly_download, (zk_ctx* c, zk_poly h, uint64_t* host, size_t n), (c, h, host, n)) {
     if (!c || !host) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
@@ -690,7 +706,7 @@ int zk_poly_download(zk_ctx* c, zk_poly h, uint64_t* host, size_t n) {
     return ZK_OK;
 }
 
-int zk_poly_copy(zk_ctx* c, zk_poly dst, zk_poly src) {
+ZK_API(zk_poly_copy, (zk_ctx* c, zk_poly dst, zk_poly src), (c, dst, src)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec *d = find_poly(c, dst), *s = find_poly(c, src);
@@ -702,7 +718,7 @@ int zk_poly_copy(zk_ctx* c, zk_poly dst, zk_poly src) {
     return ZK_OK;
 }
 
-int zk_commit(zk_ctx* c, zk_poly h, int basis, uint64_t out[8]) {
+ZK_API(zk_commit, (zk_ctx* c, zk_poly h, int basis, uint64_t out[8]), (c, h, basis, out)) {
     if (!c || !out || (basis != ZK_BASIS_MONOMIAL && basis != ZK_BASIS_LAGRANGE)) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->srs_k < 0) return ZK_ESTATE;
@@ -719,7 +735,7 @@ int zk_commit(zk_ctx* c, zk_poly h, int basis, uint64_t out[8]) {
     return ZK_OK;
 }
 
-int zk_commit_batch(zk_ctx* c, const zk_poly* hs, size_t count, int basis, uint64_t* out) {
+ZK_API(zk_commit_batch, (zk_ctx* c, const zk_poly* hs, size_t count, int basis, uint64_t* out), (c, hs, count, basis, out)) {
     if (!c || !out || !hs || count == 0 || (basis != ZK_BASIS_MONOMIAL && basis != ZK_BASIS_LAGRANGE)) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->srs_k < 0) return ZK_ESTATE;
@@ -784,6 +800,7 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
     job.inverse = inverse ? 1 : 0;
     job.n_in = (uint32_t)(src_n < N ? src_n : N);
     job.n_out = (uint32_t)n_out;
+    job.max_log_r = c->opt_ntt_max_r;
     if (!inverse && coset) {  // coeff_to_extended: a_i *= zeta^(i mod 3)
         job.has_pre = 1;
         job.pre[0] = Fr::one();
@@ -820,7 +837,7 @@ static uint32_t log2_exact(size_t n) {
     return ((size_t)1 << l) == n ? l : 0xffffffffu;
 }
 
-int zk_lagrange_to_coeff(zk_ctx* c, zk_poly h) {
+ZK_API(zk_lagrange_to_coeff, (zk_ctx* c, zk_poly h), (c, h)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
@@ -832,7 +849,7 @@ int zk_lagrange_to_coeff(zk_ctx* c, zk_poly h) {
     return ntt_resident(c, r, r, lg, true, false, r->n);
 }
 
-int zk_coeff_to_lagrange(zk_ctx* c, zk_poly h) {
+ZK_API(zk_coeff_to_lagrange, (zk_ctx* c, zk_poly h), (c, h)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);
@@ -844,7 +861,7 @@ int zk_coeff_to_lagrange(zk_ctx* c, zk_poly h) {
     return ntt_resident(c, r, r, lg, false, false, r->n);
 }
 
-int zk_coeff_to_extended(zk_ctx* c, zk_poly src, zk_poly dst) {
+ZK_API(zk_coeff_to_extended, (zk_ctx* c, zk_poly src, zk_poly dst), (c, src, dst)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec *s = find_poly(c, src), *d = find_poly(c, dst);
@@ -856,7 +873,7 @@ int zk_coeff_to_extended(zk_ctx* c, zk_poly src, zk_poly dst) {
     return ntt_resident(c, s, d, lg, false, true, d->n);
 }
 
-int zk_extended_to_coeff(zk_ctx* c, zk_poly ext, size_t n_out) {
+ZK_API(zk_extended_to_coeff, (zk_ctx* c, zk_poly ext, size_t n_out), (c, ext, n_out)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, ext);
@@ -868,7 +885,7 @@ int zk_extended_to_coeff(zk_ctx* c, zk_poly ext, size_t n_out) {
     return ntt_resident(c, r, r, lg, true, true, n_out);
 }
 
-int zk_eval(zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]) {
+ZK_API(zk_eval, (zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]), (c, h, x, out)) {
     if (!c || !x || !out) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     PolyRec* r = find_poly(c, h);

@@ -75,13 +75,13 @@ struct MsmWorkspace {
     G1X* bit_sum;               // [nwin * c]
 };
 
-uint32_t msm_auto_window(size_t n) {
+uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     // measured on MI355X with whole proofs (tools/k17_timing.py, bench.py): 13 at 2^19, 12 at 2^16..2^18
     int c = lg >= 19 ? (int)lg - 6 : (lg >= 16 ? 12 : (int)lg - 5);
     if (c > 14) c = lg >= 21 ? 15 : 14;  // 15-bit windows (two LDS sweeps per sort, 4x the bucket tail) pay from 2^21 up
-    if (const char* e = getenv("ZKMI355_MSM_WINDOW")) c = atoi(e);  // tuning override
+    if (override_c) c = (int)override_c;  // zk_ctx_set_option(ZK_OPT_MSM_WINDOW)
     if (c < 9) c = 9;
     if (c > 15) c = 15;  // digits are int16
     return (uint32_t)c;

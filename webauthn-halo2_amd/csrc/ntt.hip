@@ -180,8 +180,7 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         dsts[b] = job.batch ? job.dsts[b] : job.dst;
     }
     uint32_t bits[8];
-    static const uint32_t env_r = getenv("ZKMI355_NTT_MAXR") ? (uint32_t)atoi(getenv("ZKMI355_NTT_MAXR")) : 0;  // tuning override
-    const int np = ntt_plan(log_n, job.max_log_r ? job.max_log_r : (env_r ? env_r : 7), bits);
+    const int np = ntt_plan(log_n, job.max_log_r ? job.max_log_r : 7, bits);
     if (np == 0) {  // N == 1
         for (uint32_t b = 0; b < batch; b++)
             if (dsts[b] != srcs[b]) {

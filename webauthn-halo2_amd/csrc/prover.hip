@@ -46,6 +46,7 @@ struct Layout {
         k = p.k; A = p.num_advice; L = p.num_lookup_advice; F = p.num_fixed; lookup_bits = p.lookup_bits;
         idle = p.num_idle_gate_columns;
         if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1 || idle >= A) return false;
+        if (lookup_bits < 1 || lookup_bits >= k) return false;  // the range table 0 .. 2^lookup_bits - 1 must fit in the usable rows
         n = 1u << k;
         single = A == 1;
         n_gate = A;
@@ -89,6 +90,7 @@ static constexpr uint32_t ROWS_CAP = 512, ROWS_BLOCKS = 16;  // staged row write
 
 struct zk_pk_rec {
     Layout lay;
+    uint64_t srs_gen = 0;  // the context's SRS generation the key's commitments belong to
     std::vector<Fr*> dev;  // every device allocation (freed together)
     std::vector<Fr*> fixed_val, fixed_poly, fixed_coset, sigma_val, sigma_poly, sigma_coset;
     Fr *l0_coset = nullptr, *l_last_coset = nullptr, *l_active_coset = nullptr;
@@ -237,14 +239,14 @@ void pk_destroy_all(zk_ctx* c) {
 
 // =================================================================== keygen ==
 
-extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint64_t* fixed_canonical,
-                         const uint32_t* copies, size_t n_copies, zk_pk* out) {
+ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* fixed_canonical, size_t n_fixed_columns, const uint32_t* copies, size_t n_copies, zk_pk* out), (c, params, fixed_canonical, n_fixed_columns, copies, n_copies, out)) {
     if (!c || !params || !fixed_canonical || !out || (n_copies && !copies)) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
     if (rc) return rc;
     Layout lay;
     if (!lay.init(*params)) return ZK_EINVAL;
+    if (n_fixed_columns != lay.n_fix) return ZK_EINVAL;  // fixed_canonical holds n_fixed_columns x n x 4 limbs
     if (c->srs_k != (int)lay.k) return ZK_ESTATE;
     const uint32_t n = lay.n, N = 4 * n, T = 1u << lay.lookup_bits;
     // the lookup path is specialised to halo2-lib's range table: 0..T-1 then zeros
@@ -263,6 +265,7 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     zk_pk_rec* pk = new (std::nothrow) zk_pk_rec();
     if (!pk) return ZK_ENOMEM;
     pk->lay = lay;
+    pk->srs_gen = c->srs_gen;
     pk->max_evals = (uint32_t)(lay.advice_queries.size() + lay.n_fix + lay.perm_cols.size() + 3 * lay.n_chunks +
                                5 * lay.n_lookups + 16);
     Dev d{c, pk};
@@ -476,7 +479,7 @@ extern "C" int zk_keygen(zk_ctx* c, const zk_circuit_params* params, const uint6
     return ZK_OK;
 }
 
-extern "C" int zk_pk_free(zk_ctx* c, zk_pk h) {
+ZK_API(zk_pk_free, (zk_ctx* c, zk_pk h), (c, h)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     auto it = c->pks.find(h);
@@ -488,13 +491,13 @@ extern "C" int zk_pk_free(zk_ctx* c, zk_pk h) {
     return ZK_OK;
 }
 
-extern "C" int zk_vk_export(zk_ctx* c, zk_pk h, uint64_t* fixed_commitments, uint64_t* perm_commitments,
-                            uint64_t transcript_repr[4], uint32_t counts[2]) {
+ZK_API(zk_vk_export, (zk_ctx* c, zk_pk h, uint64_t* fixed_commitments, uint64_t* perm_commitments, uint64_t transcript_repr[4], uint32_t counts[2]), (c, h, fixed_commitments, perm_commitments, transcript_repr, counts)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     auto it = c->pks.find(h);
     if (it == c->pks.end()) return ZK_EINVAL;
     zk_pk_rec* pk = it->second;
+    if (pk->srs_gen != c->srs_gen) return ZK_ESTATE;  // the SRS was replaced after this key was made
     if (counts) {
         counts[0] = (uint32_t)pk->fixed_commit.size();
         counts[1] = (uint32_t)pk->perm_commit.size();
@@ -502,6 +505,25 @@ extern "C" int zk_vk_export(zk_ctx* c, zk_pk h, uint64_t* fixed_commitments, uin
     if (fixed_commitments) memcpy(fixed_commitments, pk->fixed_commit.data(), pk->fixed_commit.size() * sizeof(G1Affine));
     if (perm_commitments) memcpy(perm_commitments, pk->perm_commit.data(), pk->perm_commit.size() * sizeof(G1Affine));
     if (transcript_repr) memcpy(transcript_repr, &pk->transcript_repr, 32);
+    return ZK_OK;
+}
+
+ZK_API(zk_pk_set_transcript_repr, (zk_ctx* c, zk_pk h, const uint64_t transcript_repr[4]), (c, h, transcript_repr)) {
+    if (!c || !transcript_repr) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    Fr v;
+    memcpy(&v, transcript_repr, 32);
+    // a Montgomery image is < r
+    for (int i = 7; i >= 0; i--) {
+        if (v.v[i] != FrParams::P[i]) {
+            if (v.v[i] > FrParams::P[i]) return ZK_EINVAL;
+            break;
+        }
+        if (i == 0) return ZK_EINVAL;
+    }
+    it->second->transcript_repr = v;
     return ZK_OK;
 }
 
@@ -983,8 +1005,7 @@ struct Prover {
             Fr* qinv_dev = pk->gp_scal + nprod;
             Fr* k_dev = pk->gp_scal + 2 * (size_t)nprod;
             Fr* init_dev = pk->gp_scal + 3 * (size_t)nprod;
-            const char* force = getenv("ZKMI355_BATCH_INVERT");
-            bool fast = !(force && force[0] == '1');
+            bool fast = !c->opt_gp_batch_invert;  // zk_ctx_set_option(ZK_OPT_GP_BATCH_INVERT)
             if (fast) {
                 if (hipMemcpyAsync(pk->d_gp_items, items.data(), nprod * sizeof(GpItem), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
                 launch_gp_batch_scan(pk->d_gp_items, nprod, n, q_dev, st);
@@ -1330,7 +1351,7 @@ struct Prover {
 
 }  // namespace
 
-extern "C" int zk_proof_size(zk_ctx* c, zk_pk pkh, int transcript, int scheme, size_t* out) {
+ZK_API(zk_proof_size, (zk_ctx* c, zk_pk pkh, int transcript, int scheme, size_t* out), (c, pkh, transcript, scheme, out)) {
     if (!c || !out) return ZK_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     auto it = c->pks.find(pkh);
@@ -1349,14 +1370,14 @@ extern "C" int zk_proof_size(zk_ctx* c, zk_pk pkh, int transcript, int scheme, s
     return ZK_OK;
 }
 
-extern "C" int zk_prove(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, const uint8_t rng_seed[32],
-                        int transcript, int scheme, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, const uint8_t rng_seed[32], int transcript, int scheme, uint8_t* proof_out, size_t proof_cap, size_t* proof_len), (c, h, advice, n_advice, rng_seed, transcript, scheme, proof_out, proof_cap, proof_len)) {
     if (!c || !advice || !rng_seed || !proof_len) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     auto it = c->pks.find(h);
     if (it == c->pks.end()) return ZK_EINVAL;
     zk_pk_rec* pk = it->second;
     const Layout& lay = pk->lay;
+    if (pk->srs_gen != c->srs_gen) return ZK_ESTATE;  // the SRS was replaced after this key was made: its vk is stale
     if (n_advice != lay.n_adv || c->srs_k != (int)lay.k) return ZK_EINVAL;
     if (transcript != ZK_TRANSCRIPT_BLAKE2B && transcript != ZK_TRANSCRIPT_EVM) return ZK_EINVAL;
     if (scheme == ZK_SCHEME_DEFAULT) scheme = transcript == ZK_TRANSCRIPT_EVM ? ZK_SCHEME_GWC : ZK_SCHEME_SHPLONK;
@@ -1384,7 +1405,7 @@ extern "C" int zk_prove(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advi
     return ZK_OK;
 }
 
-extern "C" int zk_poly_upload_canonical(zk_ctx* c, zk_poly h, const uint64_t* host_canonical, size_t n) {
+ZK_API(zk_poly_upload_canonical, (zk_ctx* c, zk_poly h, const uint64_t* host_canonical, size_t n), (c, h, host_canonical, n)) {
     int rc = zk_poly_upload(c, h, host_canonical, n);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);

@@ -1,18 +1,27 @@
-"""Host-side mirror of the reference's proving API (halo2-circuits/src/ecc/ecdsa_p256.rs):
-same function names, argument meaning and error behaviour, on top of the resident engine.
+"""Host-side mirror of the reference's proving API (halo2-circuits/src/ecc/ecdsa_p256.rs) on top of
+the resident engine.
 
-    download_keys(degree, proving_key_path, verifying_key_path)      ecdsa_p256.rs:256-272
-    generate_proof(pubkey_x, pubkey_y, r, s, msg_hash, pk_path, k)   ecdsa_p256.rs:379-427  (Blake2b + SHPLONK)
-    generate_proof_evm(...)                                          ecdsa_p256.rs:329-377  (EvmTranscript + GWC)
+    download_keys(degree, proving_key_path, verifying_key_path)        ecdsa_p256.rs:256-272
+    create_proof_from_advice(advice_columns, ..., transcript)          the engine's real input: the advice
+                                                                       columns `ECDSACircuit::synthesize`
+                                                                       (ecdsa_p256.rs:117-206) leaves behind
+    generate_proof_synthetic / generate_proof_evm_synthetic            request-shaped stand-ins for
+                                                                       generate_proof (:379-427) / _evm (:329-377)
 
-Differences that the scope of this repository imposes:
-  * the reference re-reads the SRS and the proving key from disk on EVERY request
+What the scope of this repository imposes, stated where a caller will read it:
+
+  * The reference re-reads the SRS and the proving key from disk on EVERY request
     (ecdsa_p256.rs:338-343); here `gen_srs` and the key stay resident on the device
-     — the path arguments select a cached, resident key;
-  * the secp256r1 witness generation (`ECDSACircuit::synthesize`, ecdsa_p256.rs:117-206) needs
-    the Rust halo2-ecc chips and stays on the host side of the real integration; here the five
-    32-byte little-endian request fields seed the synthetic witness of the same column shape
-    (circuit.synthesize), so that equal requests give equal witnesses;
+     — the path arguments select a cached, resident key.
+  * The secp256r1 witness generation (`ECDSACircuit::synthesize`) needs the Rust halo2-ecc chips and stays
+    on the host side of the real integration.  The product entry point is therefore
+    `create_proof_from_advice`: it takes advice columns and proves them.
+  * The request-shaped functions carry `_synthetic` in their name because the circuit they prove is the
+    SAME-SHAPE SYNTHETIC circuit of `circuit.synthesize`, not the secp256r1 verification circuit: a proof
+    from them says nothing about the signature inside the SNARK.  They do check the ES256 signature on the
+    host first (plain secp256r1 ECDSA verification of (r, s) over msg_hash under the public key) and refuse
+    an invalid request, so that, unlike a bare seed-hash, an invalid signature or arbitrary bytes never
+    yields a verifying proof.  The reference's `generate_proof*` names are deliberately NOT exported.
   * `verify` / `verify_evm` (ecdsa_p256.rs:429-469) are ms-scale host work outside the hot path and
     are not reimplemented in the product; tests verify proofs with the oracle's verifier.
 """
@@ -74,28 +83,32 @@ def download_keys(degree: int, proving_key_path=None, verifying_key_path=None, d
     return pk
 
 
-def _witness_seed(pubkey_x, pubkey_y, r, s, msg_hash) -> int:
-    for name, v in (("pubkey_x", pubkey_x), ("pubkey_y", pubkey_y), ("r", r), ("s", s), ("msg_hash", msg_hash)):
-        if len(v) != 32:
-            raise ValueError(f"{name} must be 32 little-endian bytes")  # the reference takes &[u8; 32]
-    return int.from_bytes(hashlib.sha256(bytes(pubkey_x) + bytes(pubkey_y) + bytes(r) + bytes(s) + bytes(msg_hash)).digest()[:8], "little")
-
-
-def _prove(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, transcript, device, rng_seed):
+def _resident_key(proving_key_path, degree, device):
     eng = gen_srs(degree, device)
     keys = _STATE[device]["keys"]
     key = proving_key_path or "<default>"
     if key not in keys:
         # the reference panics with "Unable to open proving key file" (ecdsa_p256.rs:340)
         raise FileNotFoundError(f"Unable to open proving key file: {proving_key_path} (call download_keys first)")
-    p, pk = keys[key]
-    asg = circuit.synthesize(p, _witness_seed(pubkey_x, pubkey_y, r, s, msg_hash))
+    return (eng,) + keys[key]
+
+
+def create_proof_from_advice(advice_columns, proving_key_path, degree, transcript=ZK_TRANSCRIPT_BLAKE2B, device=0,
+                             rng_seed=None) -> bytes:
+    """create_proof over host-synthesized advice columns — what an unchanged Rust host hands the engine
+    after `ECDSACircuit::synthesize`.  `advice_columns`: sequence of (n, 4) uint64 arrays of canonical
+    little-endian limbs, one per advice column of the key's shape."""
+    eng, p, pk = _resident_key(proving_key_path, degree, device)
+    n = 1 << degree
     polys = []
     try:
-        for col in asg.advice:
-            h = eng.poly(1 << degree)
-            eng.upload_canonical(h, asg.to_limbs(col))
+        for col in advice_columns:
+            col = np.ascontiguousarray(col, dtype=np.uint64)
+            if col.shape != (n, 4):
+                raise ValueError("an advice column must be an (n, 4) array of canonical limbs")
+            h = eng.poly(n)
             polys.append(h)
+            eng.upload_canonical(h, col)
         seed = rng_seed if rng_seed is not None else os.urandom(32)  # the reference draws from OsRng (ecdsa_p256.rs:362)
         return eng.prove(pk, polys, seed, transcript)
     finally:
@@ -103,14 +116,80 @@ def _prove(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, transcr
             h.free()
 
 
-def generate_proof(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, device=0, rng_seed=None) -> bytes:
-    """Blake2b transcript + SHPLONK (the /prove endpoint, proving-server/src/main.rs:65-79)."""
-    return _prove(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, ZK_TRANSCRIPT_BLAKE2B, device, rng_seed)
+# ---- ES256 (secp256r1 ECDSA) request validation, host side -------------------------------------------
+_P = 0xFFFFFFFF00000001000000000000000000000000FFFFFFFFFFFFFFFFFFFFFFFF
+_N = 0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551
+_B = 0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B
+_G = (0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
+      0x4FE342E2FE1A7F9B8EE7EB4A7C0F9E162BCE33576B315ECECBB6406837BF51F5)
 
 
-def generate_proof_evm(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, device=0, rng_seed=None) -> bytes:
-    """Keccak EvmTranscript + GWC (the /prove_evm endpoint, proving-server/src/main.rs:49-63)."""
-    return _prove(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, ZK_TRANSCRIPT_EVM, device, rng_seed)
+def _p256_add(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    if a[0] == b[0]:
+        if (a[1] + b[1]) % _P == 0:
+            return None
+        lam = 3 * (a[0] * a[0] - 1) * pow(2 * a[1], -1, _P) % _P  # a = -3
+    else:
+        lam = (b[1] - a[1]) * pow(b[0] - a[0], -1, _P) % _P
+    x = (lam * lam - a[0] - b[0]) % _P
+    return x, (lam * (a[0] - x) - a[1]) % _P
+
+
+def _p256_mul(k, pt):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _p256_add(acc, pt)
+        pt = _p256_add(pt, pt)
+        k >>= 1
+    return acc
+
+
+def es256_verify(pubkey_x: bytes, pubkey_y: bytes, r: bytes, s: bytes, msg_hash: bytes) -> bool:
+    """Plain secp256r1 ECDSA verification of the request, all five fields 32 little-endian bytes as the web
+    client posts them (web-demo/src/pages/index.tsx:285-293; `Fp::from_bytes` / `Fq::from_bytes` at
+    ecdsa_p256.rs:345-352 reject non-canonical encodings — so does this)."""
+    x, y = int.from_bytes(pubkey_x, "little"), int.from_bytes(pubkey_y, "little")
+    ri, si, z = int.from_bytes(r, "little"), int.from_bytes(s, "little"), int.from_bytes(msg_hash, "little")
+    if x >= _P or y >= _P or z >= _N or not (0 < ri < _N) or not (0 < si < _N):
+        return False
+    if (y * y - (x * x * x - 3 * x + _B)) % _P:
+        return False  # Secp256r1Affine::from_xy is None off the curve
+    w = pow(si, -1, _N)
+    pt = _p256_add(_p256_mul(z * w % _N, _G), _p256_mul(ri * w % _N, (x, y)))
+    return pt is not None and pt[0] % _N == ri
+
+
+def _witness_seed(pubkey_x, pubkey_y, r, s, msg_hash) -> int:
+    return int.from_bytes(hashlib.sha256(bytes(pubkey_x) + bytes(pubkey_y) + bytes(r) + bytes(s) + bytes(msg_hash)).digest()[:8], "little")
+
+
+def _prove_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, transcript, device, rng_seed):
+    for name, v in (("pubkey_x", pubkey_x), ("pubkey_y", pubkey_y), ("r", r), ("s", s), ("msg_hash", msg_hash)):
+        if len(v) != 32:
+            raise ValueError(f"{name} must be 32 little-endian bytes")  # the reference takes &[u8; 32]
+    if not es256_verify(pubkey_x, pubkey_y, r, s, msg_hash):
+        # the real circuit would be unsatisfiable; never let such a request come back with a verifying proof
+        raise ValueError("invalid ES256 signature (or non-canonical field encoding): request refused")
+    _, p, _ = _resident_key(proving_key_path, degree, device)
+    asg = circuit.synthesize(p, _witness_seed(pubkey_x, pubkey_y, r, s, msg_hash))
+    return create_proof_from_advice([asg.to_limbs(col) for col in asg.advice], proving_key_path, degree, transcript, device, rng_seed)
+
+
+def generate_proof_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, device=0, rng_seed=None) -> bytes:
+    """Request shape of `generate_proof` (Blake2b + SHPLONK, the /prove endpoint, proving-server/src/main.rs:65-79)
+    over the SYNTHETIC same-shape circuit — see the module docstring."""
+    return _prove_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, ZK_TRANSCRIPT_BLAKE2B, device, rng_seed)
+
+
+def generate_proof_evm_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, device=0, rng_seed=None) -> bytes:
+    """Request shape of `generate_proof_evm` (Keccak EvmTranscript + GWC, the /prove_evm endpoint,
+    proving-server/src/main.rs:49-63) over the SYNTHETIC same-shape circuit — see the module docstring."""
+    return _prove_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, ZK_TRANSCRIPT_EVM, device, rng_seed)
 
 
 def verify(*_a, **_k):
@@ -119,29 +198,3 @@ def verify(*_a, **_k):
 
 
 verify_evm = verify
-
-
-def prover_smoke(eng: Engine) -> None:
-    """One tiny full proof on `eng` checked by the oracle (called from __graft_entry__.smoke)."""
-    import sys
-
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-    from zkoracle import cops, plonk, prover  # checker only
-    from zkoracle.hashes import ChaCha20Rng
-
-    p = circuit.CircuitParams(degree=7, num_advice=1, num_lookup_advice=1, num_fixed=1, lookup_bits=6)
-    asg = circuit.synthesize(p, 0x5EED0019)
-    eng.srs_setup(7)
-    pk = eng.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)
-    h = eng.poly(128)
-    eng.upload_canonical(h, asg.to_limbs(asg.advice[0]))
-    seed = b"\x05" * 32
-    got = eng.prove(pk, [h], seed, ZK_TRANSCRIPT_EVM)
-    sh = plonk.Shape(7, 1, 1, 1, 6)
-    opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
-    assert got == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), "evm"), "device proof != oracle proof"
-    fc, pc, tr = eng.vk_export(pk)
-    vk = plonk.VerifyingKey(sh, cops.affine_arr_to_ints(fc), cops.affine_arr_to_ints(pc), cops.fr_ints(tr.reshape(1, 4))[0])
-    assert plonk.verify(vk, got, "evm")
-    h.free()
-    eng.pk_free(pk)

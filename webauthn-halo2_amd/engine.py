@@ -19,6 +19,7 @@ ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS =
 
 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
+ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT = 1, 2, 3, 4
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
 
@@ -60,7 +61,9 @@ def load_library():
         "zk_strerror": ([ctypes.c_int], ctypes.c_char_p),
         "zk_last_hip_error": ([vp], ctypes.c_int),
         "zk_sync": ([vp], ctypes.c_int),
+        "zk_ctx_set_option": ([vp, ctypes.c_int, ctypes.c_int64], ctypes.c_int),
         "zk_msm_bn254": ([vp, u64p, u64p, sz, u64p], ctypes.c_int),
+        "zk_msm_srs": ([vp, ctypes.c_int, u64p, sz, u64p], ctypes.c_int),
         "zk_ntt_bn254_fr": ([vp, u64p, u64p, u32], ctypes.c_int),
         "zk_srs_setup": ([vp, u32, ctypes.c_char_p], ctypes.c_int),
         "zk_srs_load": ([vp, u32, u64p, u64p], ctypes.c_int),
@@ -83,8 +86,9 @@ def load_library():
         "zk_last_kernel_ms": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
         "zk_timer_reset": ([vp], ctypes.c_int),
         "zk_timer_stats": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
-        "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, ctypes.POINTER(ctypes.c_uint32), sz,
+        "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, sz, ctypes.POINTER(ctypes.c_uint32), sz,
                        ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_pk_set_transcript_repr": ([vp, ctypes.c_uint64, u64p], ctypes.c_int),
         "zk_pk_free": ([vp, ctypes.c_uint64], ctypes.c_int),
         "zk_vk_export": ([vp, ctypes.c_uint64, u64p, u64p, u64p, ctypes.POINTER(ctypes.c_uint32)], ctypes.c_int),
         "zk_proof_size": ([vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz)], ctypes.c_int),
@@ -149,7 +153,17 @@ class Engine:
         if rc != 0:
             raise ZkError(rc, what + ": " + self.L.zk_strerror(rc).decode(), self.L.zk_last_hip_error(self.ctx))
 
+    def set_option(self, option, value):
+        self._chk(self.L.zk_ctx_set_option(self.ctx, option, value), "zk_ctx_set_option")
+
     # ---- fine-grained seam ----------------------------------------------------
+    def msm_srs(self, scalars_mont, basis):
+        """ParamsKZG::commit / commit_lagrange as a Rust host calls it: host scalars, resident basis."""
+        s = _arr(scalars_mont, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.zk_msm_srs(self.ctx, basis, _p(s), s.shape[0], _p(out)), "zk_msm_srs")
+        return out
+
     def msm(self, scalars_mont, bases_mont):
         s = _arr(scalars_mont, 4)
         b = _arr(bases_mont, 8)
@@ -169,6 +183,8 @@ class Engine:
 
     # ---- SRS ----------------------------------------------------------------------
     def srs_setup(self, k, seed=bytes(32)):
+        if len(seed) != 32:
+            raise ValueError("SRS seed must be 32 bytes")
         self._chk(self.L.zk_srs_setup(self.ctx, k, seed), "zk_srs_setup")
 
     def srs_load(self, k, g, g_lagrange):
@@ -249,11 +265,17 @@ class Engine:
         cp = CircuitParamsC(params.degree, params.num_advice, params.num_lookup_advice, params.num_fixed, params.lookup_bits,
                             getattr(params, "idle_gate_columns", 0))
         fx = np.ascontiguousarray(fixed_canonical, dtype=np.uint64)
+        if fx.ndim != 3 or fx.shape[1:] != (1 << params.degree, 4):
+            raise ValueError("fixed_canonical must have shape (n_fixed_columns, 2^degree, 4)")
         cps = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], dtype=np.uint32).reshape(-1, 4))
         h = ctypes.c_uint64()
-        self._chk(self.L.zk_keygen(self.ctx, ctypes.byref(cp), _p(fx), cps.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
-                                   cps.shape[0], ctypes.byref(h)), "zk_keygen")
+        self._chk(self.L.zk_keygen(self.ctx, ctypes.byref(cp), _p(fx), fx.shape[0],
+                                   cps.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cps.shape[0], ctypes.byref(h)), "zk_keygen")
         return h.value
+
+    def pk_set_transcript_repr(self, pk, repr_mont):
+        t = np.ascontiguousarray(repr_mont, dtype=np.uint64).reshape(4)
+        self._chk(self.L.zk_pk_set_transcript_repr(self.ctx, pk, _p(t)), "zk_pk_set_transcript_repr")
 
     def pk_free(self, pk):
         self._chk(self.L.zk_pk_free(self.ctx, pk), "zk_pk_free")
@@ -268,6 +290,8 @@ class Engine:
         return fc, pc, tr
 
     def prove(self, pk, advice_polys, seed=bytes(32), transcript=ZK_TRANSCRIPT_BLAKE2B, scheme=ZK_SCHEME_DEFAULT):
+        if len(seed) != 32:
+            raise ValueError("rng seed must be 32 bytes")
         hs = (ctypes.c_uint64 * len(advice_polys))(*[p.h for p in advice_polys])
         ln = ctypes.c_size_t()
         self._chk(self.L.zk_proof_size(self.ctx, pk, transcript, scheme, ctypes.byref(ln)), "zk_proof_size")
