@@ -462,3 +462,282 @@ void orc_fr_powers(const uint64_t *base_mont, const uint64_t *first_mont, uint64
     fe b; memcpy(&b, base_mont, 32);
     for (size_t i = 0; i < n; i++) { memcpy(out + 4 * i, &cur, 32); fe_mul(&cur, &cur, &b, &FR); }
 }
+
+/* ===================================================== prover vector ops ==
+ * Element-wise / scan operators of halo2_proofs' create_proof between its MSM and FFT calls
+ * (plonk/prover.rs, plonk/permutation/prover.rs, plonk/lookup/prover.rs, plonk/evaluation.rs,
+ * arithmetic.rs `eval_polynomial` / `kate_division`; reached from the reference at
+ * halo2-circuits/src/ecc/ecdsa_p256.rs:366-373, 416-423), restated for the oracle's full-size
+ * CPU prover (oracle/zkoracle/fastprover.py), which is (a) the generator of the BASELINE-size golden
+ * proofs under tests/golden/ and (b) bench.py's whole-proof cpu_baseline.  halo2 parallelises these
+ * loops with rayon over rows; here: pthreads over rows.  All vectors are Fr, Montgomery form. */
+
+typedef struct { fe *out; const fe *a, *b; fe ca, cb, k; int has_b; } lin_ctx;
+static void lin_job(void *p, size_t tid, size_t lo, size_t hi) {
+    (void)tid;
+    lin_ctx *c = p;
+    for (size_t i = lo; i < hi; i++) {
+        fe t; fe_mul(&t, &c->a[i], &c->ca, &FR);
+        if (c->has_b) { fe u; fe_mul(&u, &c->b[i], &c->cb, &FR); fe_add(&t, &t, &u, &FR); }
+        fe_add(&c->out[i], &t, &c->k, &FR);
+    }
+}
+/* out[i] = ca a[i] + cb b[i] + k  (b may be NULL) */
+void orc_vec_lin(uint64_t *out, const uint64_t *a, const uint64_t *ca, const uint64_t *b, const uint64_t *cb, const uint64_t *k,
+                 size_t n, int nthreads) {
+    lin_ctx c = {(fe *)out, (const fe *)a, (const fe *)b, *(const fe *)ca, b ? *(const fe *)cb : FR.one, *(const fe *)k, b != NULL};
+    parallel_for(n, nthreads, lin_job, &c);
+}
+
+typedef struct { fe *out; const fe *a, *b; } mul_ctx;
+static void mul_job(void *p, size_t tid, size_t lo, size_t hi) {
+    (void)tid;
+    mul_ctx *c = p;
+    for (size_t i = lo; i < hi; i++) fe_mul(&c->out[i], &c->a[i], &c->b[i], &FR);
+}
+void orc_vec_mul(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t n, int nthreads) {
+    mul_ctx c = {(fe *)out, (const fe *)a, (const fe *)b};
+    parallel_for(n, nthreads, mul_job, &c);
+}
+
+typedef struct { fe *a; fe s[3]; } p3_ctx;
+static void p3_job(void *p, size_t tid, size_t lo, size_t hi) {
+    (void)tid;
+    p3_ctx *c = p;
+    for (size_t i = lo; i < hi; i++) fe_mul(&c->a[i], &c->a[i], &c->s[i % 3], &FR);
+}
+/* a[i] *= s[i mod 3]: EvaluationDomain::distribute_powers_zeta (coset scaling by the cube root of unity), times a constant */
+void orc_vec_scale_period3(uint64_t *a, const uint64_t *s3, size_t n, int nthreads) {
+    p3_ctx c; c.a = (fe *)a; memcpy(c.s, s3, 96);
+    parallel_for(n, nthreads, p3_job, &c);
+}
+
+/* halo2 `batch_invert` semantics over a whole vector: out[i] = a[i]^-1, 0 -> 0 (Montgomery's trick per thread chunk) */
+typedef struct { fe *out; const fe *a; } binv_ctx;
+static void binv_job(void *p, size_t tid, size_t lo, size_t hi) {
+    (void)tid;
+    binv_ctx *c = p;
+    size_t cnt = hi - lo;
+    fe *pref = malloc(sizeof(fe) * (cnt + 1));
+    pref[0] = FR.one;
+    for (size_t i = 0; i < cnt; i++) {
+        if (fe_is_zero(&c->a[lo + i])) pref[i + 1] = pref[i];
+        else fe_mul(&pref[i + 1], &pref[i], &c->a[lo + i], &FR);
+    }
+    fe inv; fe_inv(&inv, &pref[cnt], &FR);
+    for (size_t i = cnt; i-- > 0;) {
+        if (fe_is_zero(&c->a[lo + i])) { memset(&c->out[lo + i], 0, sizeof(fe)); continue; }
+        fe ai = c->a[lo + i];  /* out may alias a */
+        fe_mul(&c->out[lo + i], &inv, &pref[i], &FR);
+        fe_mul(&inv, &inv, &ai, &FR);
+    }
+    free(pref);
+}
+void orc_vec_batch_inv(uint64_t *out, const uint64_t *a, size_t n, int nthreads) {
+    binv_ctx c = {(fe *)out, (const fe *)a};
+    parallel_for(n, nthreads, binv_job, &c);
+}
+
+/* z[0] = init, z[i + 1] = z[i] * f[i] for i + 1 < n  (the grand-product running product; serial, as in halo2) */
+void orc_running_product(uint64_t *z, const uint64_t *f, const uint64_t *init, size_t n) {
+    fe *zz = (fe *)z; const fe *ff = (const fe *)f;
+    memcpy(&zz[0], init, 32);
+    for (size_t i = 0; i + 1 < n; i++) fe_mul(&zz[i + 1], &zz[i], &ff[i], &FR);
+}
+
+/* sum_i a[i] b[i] */
+typedef struct { const fe *a, *b; fe *part; } dot_ctx;
+static void dot_job(void *p, size_t tid, size_t lo, size_t hi) {
+    dot_ctx *c = p;
+    fe acc; memset(&acc, 0, sizeof(acc));
+    for (size_t i = lo; i < hi; i++) { fe t; fe_mul(&t, &c->a[i], &c->b[i], &FR); fe_add(&acc, &acc, &t, &FR); }
+    c->part[tid] = acc;
+}
+void orc_vec_dot(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    fe *part = calloc((size_t)nthreads, sizeof(fe));
+    dot_ctx c = {(const fe *)a, (const fe *)b, part};
+    parallel_for(n, nthreads, dot_job, &c);
+    fe acc; memset(&acc, 0, sizeof(acc));
+    for (int t = 0; t < nthreads; t++) fe_add(&acc, &acc, &part[t], &FR);
+    memcpy(out, &acc, 32);
+    free(part);
+}
+
+/* arithmetic.rs eval_polynomial: Horner per thread chunk, chunks combined with x^chunk */
+typedef struct { const fe *c; fe x; fe *part; size_t *len; } ev_ctx;
+static void ev_job(void *p, size_t tid, size_t lo, size_t hi) {
+    ev_ctx *c = p;
+    fe acc; memset(&acc, 0, sizeof(acc));
+    for (size_t i = hi; i-- > lo;) { fe_mul(&acc, &acc, &c->x, &FR); fe_add(&acc, &acc, &c->c[i], &FR); }
+    c->part[tid] = acc;
+    c->len[tid] = hi - lo;
+}
+void orc_eval_poly(const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    fe *part = calloc((size_t)nthreads, sizeof(fe));
+    size_t *len = calloc((size_t)nthreads, sizeof(size_t));
+    ev_ctx c; c.c = (const fe *)coeffs; memcpy(&c.x, x, 32); c.part = part; c.len = len;
+    parallel_for(n, nthreads, ev_job, &c);
+    /* value = sum_t part[t] * x^(offset_t): combine from the top chunk down */
+    fe acc; memset(&acc, 0, sizeof(acc));
+    for (int t = nthreads - 1; t >= 0; t--) {
+        if (!len[t]) continue;
+        /* acc = acc * x^len[t] + part[t] */
+        fe pw = FR.one, b = c.x;
+        for (size_t e = len[t]; e; e >>= 1) { if (e & 1) fe_mul(&pw, &pw, &b, &FR); fe_mul(&b, &b, &b, &FR); }
+        fe_mul(&acc, &acc, &pw, &FR);
+        fe_add(&acc, &acc, &part[t], &FR);
+    }
+    memcpy(out, &acc, 32);
+    free(part); free(len);
+}
+
+/* arithmetic.rs kate_division: (p(X) - p(z)) / (X - z); n coefficients in, n - 1 out (q[n - 1] is set to 0) */
+void orc_kate_division(const uint64_t *p, size_t n, const uint64_t *z, uint64_t *q) {
+    const fe *pp = (const fe *)p; fe *qq = (fe *)q;
+    fe zz; memcpy(&zz, z, 32);
+    fe carry; memset(&carry, 0, sizeof(carry));
+    memset(&qq[n - 1], 0, sizeof(fe));
+    for (size_t i = n - 1; i >= 1; i--) {
+        fe t; fe_mul(&t, &carry, &zz, &FR);
+        fe_add(&carry, &pp[i], &t, &FR);
+        qq[i - 1] = carry;
+    }
+}
+
+/* plonk/evaluation.rs Evaluator::evaluate_h for the halo2-lib column shape + divide_by_vanishing_poly, one row of
+ * the extended coset per iteration.  Expressions and y-Horner order as the reference's generated verifier checks
+ * them (proving-server/P256Verifier.yul:406-552).  Pointers are extended-coset vectors of 2^log_ext rows. */
+typedef struct {
+    uint32_t log_ext, n_gate, n_chunks, chunk_len, n_perm, n_lookups, single, fx_table, fx_qlookup;
+    int32_t last_rot;
+    const fe *const *adv; const fe *const *fix; const int32_t *fx_sel;
+    const fe *const *sigma; const fe *const *perm_val; const fe *const *z;
+    const fe *const *lk_z; const fe *const *lk_a; const fe *const *lk_s; const fe *const *lk_in;
+    const fe *l0, *l_last, *l_blind, *xs;
+    fe beta, gamma, y;
+    const fe *delta_pow;  /* delta^p */
+    fe t_inv[4];
+    fe *out;
+} quot_ctx;
+
+static void quot_job(void *p, size_t tid, size_t lo, size_t hi) {
+    (void)tid;
+    const quot_ctx *a = p;
+    const size_t N = (size_t)1 << a->log_ext, mask = N - 1;
+    for (size_t i = lo; i < hi; i++) {
+#define ROT(r) ((i + (size_t)((int64_t)(r) * 4)) & mask)
+        fe acc; memset(&acc, 0, sizeof(acc));
+#define PUSH(e) do { fe_mul(&acc, &acc, &a->y, &FR); fe_add(&acc, &acc, (e), &FR); } while (0)
+        fe t, u, v;
+        for (uint32_t j = 0; j < a->n_gate; j++) {
+            if (a->fx_sel[j] < 0) { memset(&t, 0, sizeof(t)); PUSH(&t); continue; }
+            const fe *c = a->adv[j];
+            fe_mul(&t, &c[ROT(1)], &c[ROT(2)], &FR);
+            fe_add(&t, &t, &c[i], &FR);
+            fe_sub(&t, &t, &c[ROT(3)], &FR);
+            fe_mul(&t, &t, &a->fix[a->fx_sel[j]][i], &FR);
+            PUSH(&t);
+        }
+        const fe *l0 = &a->l0[i], *ll = &a->l_last[i];
+        fe active; fe_sub(&active, &FR.one, ll, &FR); fe_sub(&active, &active, &a->l_blind[i], &FR);
+        /* permutation */
+        fe_sub(&t, &FR.one, &a->z[0][i], &FR); fe_mul(&t, &t, l0, &FR); PUSH(&t);
+        { const fe *zl = &a->z[a->n_chunks - 1][i]; fe_mul(&t, zl, zl, &FR); fe_sub(&t, &t, zl, &FR); fe_mul(&t, &t, ll, &FR); PUSH(&t); }
+        for (uint32_t c = 1; c < a->n_chunks; c++) {
+            fe_sub(&t, &a->z[c][i], &a->z[c - 1][ROT(a->last_rot)], &FR); fe_mul(&t, &t, l0, &FR); PUSH(&t);
+        }
+        fe bx; fe_mul(&bx, &a->beta, &a->xs[i], &FR);
+        for (uint32_t c = 0; c < a->n_chunks; c++) {
+            fe left = a->z[c][ROT(1)], right = a->z[c][i];
+            uint32_t lo_p = c * a->chunk_len, hi_p = lo_p + a->chunk_len; if (hi_p > a->n_perm) hi_p = a->n_perm;
+            for (uint32_t q = lo_p; q < hi_p; q++) {
+                fe vg; fe_add(&vg, &a->perm_val[q][i], &a->gamma, &FR);
+                fe_mul(&u, &a->beta, &a->sigma[q][i], &FR); fe_add(&u, &u, &vg, &FR); fe_mul(&left, &left, &u, &FR);
+                fe_mul(&v, &bx, &a->delta_pow[q], &FR); fe_add(&v, &v, &vg, &FR); fe_mul(&right, &right, &v, &FR);
+            }
+            fe_sub(&t, &left, &right, &FR); fe_mul(&t, &t, &active, &FR); PUSH(&t);
+        }
+        /* lookups */
+        for (uint32_t l = 0; l < a->n_lookups; l++) {
+            const fe *zc = &a->lk_z[l][i], *zn = &a->lk_z[l][ROT(1)];
+            const fe *ap = &a->lk_a[l][i], *apm = &a->lk_a[l][ROT(-1)], *sp = &a->lk_s[l][i];
+            fe inp;
+            if (a->single) fe_mul(&inp, &a->fix[a->fx_qlookup][i], &a->adv[0][i], &FR); else inp = a->lk_in[l][i];
+            const fe *tab = &a->fix[a->fx_table][i];
+            fe_sub(&t, &FR.one, zc, &FR); fe_mul(&t, &t, l0, &FR); PUSH(&t);
+            fe_mul(&t, zc, zc, &FR); fe_sub(&t, &t, zc, &FR); fe_mul(&t, &t, ll, &FR); PUSH(&t);
+            fe left, right;
+            fe_add(&u, ap, &a->beta, &FR); fe_mul(&left, zn, &u, &FR); fe_add(&u, sp, &a->gamma, &FR); fe_mul(&left, &left, &u, &FR);
+            fe_add(&u, &inp, &a->beta, &FR); fe_mul(&right, zc, &u, &FR); fe_add(&u, tab, &a->gamma, &FR); fe_mul(&right, &right, &u, &FR);
+            fe_sub(&t, &left, &right, &FR); fe_mul(&t, &t, &active, &FR); PUSH(&t);
+            fe d; fe_sub(&d, ap, sp, &FR);
+            fe_mul(&t, &d, l0, &FR); PUSH(&t);
+            fe_sub(&u, ap, apm, &FR); fe_mul(&t, &d, &u, &FR); fe_mul(&t, &t, &active, &FR); PUSH(&t);
+        }
+        fe_mul(&a->out[i], &acc, &a->t_inv[i & 3], &FR);
+#undef ROT
+#undef PUSH
+    }
+}
+
+int orc_quotient(uint32_t log_ext, uint32_t n_gate, uint32_t n_chunks, uint32_t chunk_len, uint32_t n_perm, uint32_t n_lookups,
+                 uint32_t single, uint32_t fx_table, uint32_t fx_qlookup, int32_t last_rot,
+                 const uint64_t *const *adv, const uint64_t *const *fix, const int32_t *fx_sel,
+                 const uint64_t *const *sigma, const uint64_t *const *perm_val, const uint64_t *const *z,
+                 const uint64_t *const *lk_z, const uint64_t *const *lk_a, const uint64_t *const *lk_s, const uint64_t *const *lk_in,
+                 const uint64_t *l0, const uint64_t *l_last, const uint64_t *l_blind, const uint64_t *xs,
+                 const uint64_t *beta, const uint64_t *gamma, const uint64_t *y, const uint64_t *delta_pow, const uint64_t *t_inv4,
+                 uint64_t *out, int nthreads) {
+    quot_ctx c;
+    c.log_ext = log_ext; c.n_gate = n_gate; c.n_chunks = n_chunks; c.chunk_len = chunk_len; c.n_perm = n_perm;
+    c.n_lookups = n_lookups; c.single = single; c.fx_table = fx_table; c.fx_qlookup = fx_qlookup; c.last_rot = last_rot;
+    c.adv = (const fe *const *)adv; c.fix = (const fe *const *)fix; c.fx_sel = fx_sel;
+    c.sigma = (const fe *const *)sigma; c.perm_val = (const fe *const *)perm_val; c.z = (const fe *const *)z;
+    c.lk_z = (const fe *const *)lk_z; c.lk_a = (const fe *const *)lk_a; c.lk_s = (const fe *const *)lk_s; c.lk_in = (const fe *const *)lk_in;
+    c.l0 = (const fe *)l0; c.l_last = (const fe *)l_last; c.l_blind = (const fe *)l_blind; c.xs = (const fe *)xs;
+    memcpy(&c.beta, beta, 32); memcpy(&c.gamma, gamma, 32); memcpy(&c.y, y, 32);
+    c.delta_pow = (const fe *)delta_pow; memcpy(c.t_inv, t_inv4, 128);
+    c.out = (fe *)out;
+    parallel_for((size_t)1 << log_ext, nthreads, quot_job, &c);
+    return 0;
+}
+
+/* rand_chacha ChaCha20Rng keystream (key = seed, nonce / stream 0, 64-bit block counter) -> one Fr per 64-byte
+ * block: halo2curves `Fr::random` = from_u512(eight next_u64).  out[i] = block first + i. */
+static inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define ORC_QR(a, b, c, d) a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+static void chacha20_block(const uint8_t key[32], uint64_t counter, uint8_t out[64]) {
+    uint32_t st[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
+    memcpy(st + 4, key, 32);
+    st[12] = (uint32_t)counter; st[13] = (uint32_t)(counter >> 32); st[14] = 0; st[15] = 0;
+    uint32_t w[16];
+    memcpy(w, st, 64);
+    for (int i = 0; i < 10; i++) {
+        ORC_QR(w[0], w[4], w[8], w[12]) ORC_QR(w[1], w[5], w[9], w[13]) ORC_QR(w[2], w[6], w[10], w[14]) ORC_QR(w[3], w[7], w[11], w[15])
+        ORC_QR(w[0], w[5], w[10], w[15]) ORC_QR(w[1], w[6], w[11], w[12]) ORC_QR(w[2], w[7], w[8], w[13]) ORC_QR(w[3], w[4], w[9], w[14])
+    }
+    for (int i = 0; i < 16; i++) w[i] += st[i];
+    memcpy(out, w, 64);
+}
+typedef struct { const uint8_t *key; uint64_t first; fe *out; fe r3; } cc_ctx;
+static void cc_job(void *p, size_t tid, size_t lo, size_t hi) {
+    (void)tid;
+    cc_ctx *c = p;
+    for (size_t i = lo; i < hi; i++) {
+        uint8_t b[64];
+        chacha20_block(c->key, c->first + i, b);
+        fe l, h, t, u;
+        memcpy(&l, b, 32); memcpy(&h, b + 32, 32);
+        /* (l + h 2^256) R mod r = l R + h R^2: CIOS tolerates one operand < 2^256 when the other is < r */
+        fe_mul(&t, &l, &FR.r2, &FR);
+        fe_mul(&u, &h, &c->r3, &FR);
+        fe_add(&c->out[i], &t, &u, &FR);
+    }
+}
+void orc_chacha20_fr(const uint8_t key[32], uint64_t first_block, size_t count, uint64_t *out_mont, int nthreads) {
+    cc_ctx c; c.key = key; c.first = first_block; c.out = (fe *)out_mont;
+    fe_mul(&c.r3, &FR.r2, &FR.r2, &FR);
+    parallel_for(count, nthreads, cc_job, &c);
+}
