@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/webauthn-halo2_amd"
 OUT=libzkmi355.so
-SRCS="csrc/engine.hip csrc/ntt.hip csrc/msm.hip csrc/poly.hip csrc/prover_kernels.hip csrc/quotient.hip csrc/prover.hip"
+SRCS="csrc/engine.hip csrc/ntt.hip csrc/msm.hip csrc/poly.hip csrc/prover_kernels.hip csrc/quotient.hip csrc/prover.hip csrc/serde.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 mkdir -p build
 objs=""

@@ -99,6 +99,22 @@ int zk_srs_k(const zk_ctx* ctx); /* -1 if none */
  * window_bits == 0: no window-multiple tables (k < 10).  For measurement (bench.py's ALU roofline). */
 int zk_srs_msm_plan(const zk_ctx* ctx, uint32_t* window_bits, uint32_t* windows);
 
+/* ---- the reference's files (SRS, proving key, verifying key) -------------------------------------------------
+ * halo2_proofs `SerdeFormat` (helpers.rs): how field elements and points are laid out in a file.  The reference writes
+ * and reads its keys with RawBytes (ecdsa_p256.rs:261-270, 339-343, 389-393); `Params::write` is RawBytes too. */
+#define ZK_SERDE_PROCESSED 0           /* canonical little-endian field elements, compressed points */
+#define ZK_SERDE_RAW_BYTES 1           /* in-memory Montgomery limbs, validated on read */
+#define ZK_SERDE_RAW_BYTES_UNCHECKED 2 /* the same bytes, no validation on read */
+/* replaces ParamsKZG::write_custom (halo2-base gen_srs writes ./params/kzg_bn254_{k}.srs): u32 LE k | g | g_lagrange | g2 |
+ * s_g2.  out == NULL: only *len is set.  ZK_ESTATE after zk_srs_load until zk_srs_set_g2 supplies the G2 half. */
+int zk_srs_write(zk_ctx* ctx, int format, uint8_t* out, size_t cap, size_t* len);
+/* replaces ParamsKZG::read_custom (run by gen_srs on EVERY request in the reference, ecdsa_p256.rs:338,388): decodes
+ * (decompresses / validates on the device), builds the window tables, keeps the SRS resident.  ZK_EINVAL on a
+ * malformed file; the previously loaded SRS is gone in that case. */
+int zk_srs_read(zk_ctx* ctx, const uint8_t* bytes, size_t len, int format);
+/* G2 half of a ParamsKZG adopted with zk_srs_load (G2Affine memory images: x.c0 || x.c1 || y.c0 || y.c1, Montgomery) */
+int zk_srs_set_g2(zk_ctx* ctx, const uint64_t g2[16], const uint64_t s_g2[16]);
+
 /* ---- resident polynomials -------------------------------------------------- */
 int zk_poly_alloc(zk_ctx* ctx, size_t n, zk_poly* out);
 int zk_poly_free(zk_ctx* ctx, zk_poly p);
@@ -159,6 +175,20 @@ int zk_pk_free(zk_ctx* ctx, zk_pk pk);
 /* the VerifyingKey half: commitments (affine Montgomery) and transcript_repr; counts = {n_fixed, n_perm} */
 int zk_vk_export(zk_ctx* ctx, zk_pk pk, uint64_t* fixed_commitments, uint64_t* perm_commitments,
                  uint64_t transcript_repr[4], uint32_t counts[2]);
+/* replaces VerifyingKey::write (ecdsa_p256.rs:266-270): u32 BE k | u32 BE #fixed | fixed commitments | permutation
+ * commitments | selector bits.  out == NULL: only *len is set. */
+int zk_vk_write(zk_ctx* ctx, zk_pk pk, int format, uint8_t* out, size_t cap, size_t* len);
+/* adopts the Rust host's VerifyingKey (a VerifyingKey::write image) for a resident key: ZK_EINVAL unless its commitments
+ * and selectors are the key's own; `transcript_repr` (may be NULL) is then what every transcript starts with. */
+int zk_vk_load(zk_ctx* ctx, zk_pk pk, const uint8_t* vk_bytes, size_t len, int format, const uint64_t transcript_repr_mont[4]);
+/* replaces ProvingKey::write (ecdsa_p256.rs:261-265): vk | l0 | l_last | l_active_row | fixed values / polys / cosets |
+ * permutation values / polys / cosets (k=17: 336 MiB, k=19: 768 MiB in RawBytes).  out == NULL: only *len is set. */
+int zk_pk_write(zk_ctx* ctx, zk_pk pk, int format, uint8_t* out, size_t cap, size_t* len);
+/* replaces ProvingKey::read::<_, ECDSACircuit<Fr>> (ecdsa_p256.rs:339-343, 389-393 — on every request there, once
+ * here): the key material comes from the file image, the column shape from `params` (what `ECDSACircuit::configure`
+ * tells halo2), transcript_repr from the caller (NULL: the stand-in).  Needs the SRS of params->k. */
+int zk_pk_read(zk_ctx* ctx, const zk_circuit_params* params, const uint8_t* bytes, size_t len, int format,
+               const uint64_t transcript_repr_mont[4], zk_pk* out);
 /* bytes zk_prove will write for this key / transcript / scheme (what `transcript.finalize().len()` is in
  * the reference, e.g. 960 at k=19 Blake2b, halo2-circuits/src/results/ecdsa_bench.csv:2) */
 int zk_proof_size(zk_ctx* ctx, zk_pk pk, int transcript, int scheme, size_t* out);

@@ -13,10 +13,11 @@ S = 28  # 2-adicity of Fr
 GENERATOR = 7  # multiplicative generator of Fr (halo2curves MULTIPLICATIVE_GENERATOR)
 ROOT_OF_UNITY = pow(GENERATOR, (R - 1) >> S, R)  # primitive 2^28-th root
 DELTA = pow(GENERATOR, 1 << S, R)  # generator of the odd-order subgroup (permutation cosets)
-# ZETA: primitive cube root of unity used by halo2's extended-domain coset
-# ("g_coset" = ZETA).  Any cube root gives the same h(X); fixed here for
-# operator-level parity between oracle and engine.
-ZETA = pow(GENERATOR, (R - 1) // 3, R)
+# ZETA: primitive cube root of unity used by halo2's extended-domain coset ("g_coset" = Fr::ZETA).  Either cube
+# root gives the same h(X), hence the same proof bytes; the extended cosets stored in a ProvingKey file differ, so
+# this is halo2curves' constant [RECALLED: bn256 Fr::ZETA; checked below to be (7^((r-1)/3))^2, a primitive cube root].
+ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23
+assert ZETA == pow(pow(GENERATOR, (R - 1) // 3, R), 2, R) and pow(ZETA, 3, R) == 1 and ZETA != 1
 
 
 def inv(a, m):

@@ -1,0 +1,189 @@
+"""The reference's files through the engine: the SRS file halo2-base `gen_srs` keeps under
+./params, and the RawBytes proving / verifying keys the reference writes at ecdsa_p256.rs:261-270 and re-reads on
+every request (:338-343).  The device's images equal the oracle's byte-for-byte restatement of the formats
+(oracle/zkoracle/serde.py) in all three SerdeFormats; keys and SRS round-trip through a fresh context into
+byte-identical proofs; a host-supplied transcript_repr replaces the stand-in; malformed input is refused."""
+import numpy as np
+import pytest
+
+import webauthn_halo2_amd as zk
+from webauthn_halo2_amd import engine as E
+from zkoracle import cops, curve as C, fastprover as fp, field as F, plonk, serde, srs
+from zkoracle.hashes import ChaCha20Rng
+
+pytestmark = pytest.mark.gpu
+FMTS = [E.ZK_SERDE_PROCESSED, E.ZK_SERDE_RAW_BYTES, E.ZK_SERDE_RAW_BYTES_UNCHECKED]
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_srs_file_equals_the_oracle_image_and_round_trips(fmt):
+    k = 10
+    eng = zk.Engine(0)
+    eng.srs_setup(k)
+    img = eng.srs_write(fmt).tobytes()
+    assert img == serde.srs_bytes(k, fmt)
+    # K1 (P256Verifier.yul:1131-1134): the file's s_g2 is [tau]G2 — the oracle image above holds C.g2_mul(G2, tau),
+    # which tests/test_oracle_kat.py ties to the Yul's constant
+    other = zk.Engine(0)
+    other.srs_read(img, fmt)
+    assert np.array_equal(other.srs_export(0, 0, 1 << k), eng.srs_export(0, 0, 1 << k))
+    assert np.array_equal(other.srs_export(1, 0, 1 << k), eng.srs_export(1, 0, 1 << k))
+    assert other.srs_write(E.ZK_SERDE_RAW_BYTES).tobytes() == serde.srs_bytes(k, E.ZK_SERDE_RAW_BYTES)
+    a = np.frombuffer(np.random.default_rng(1).bytes(32 << k), dtype=np.uint64).reshape(-1, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    assert np.array_equal(other.commit(other.poly(1 << k, a), 1), eng.commit(eng.poly(1 << k, a), 1))
+    # malformed images
+    bad = bytearray(img)
+    bad[4 + 5] ^= 1  # x of g[0]: no longer a curve point
+    if fmt != E.ZK_SERDE_RAW_BYTES_UNCHECKED:
+        with pytest.raises(zk.ZkError) as e:
+            other.srs_read(bytes(bad), fmt)
+        assert e.value.code == -1
+    for cut in (img[:-1], img + b"\0", img[:3], b"\x40\0\0\0" + img[4:]):
+        with pytest.raises(zk.ZkError):
+            other.srs_read(cut, fmt)
+    # an SRS adopted from arrays has no G2 half until the host supplies it
+    third = zk.Engine(0)
+    third.srs_load(k, eng.srs_export(0, 0, 1 << k), eng.srs_export(1, 0, 1 << k))
+    with pytest.raises(zk.ZkError) as e:
+        third.srs_write(fmt)
+    assert e.value.code == -5
+    raw = serde.srs_bytes(k, E.ZK_SERDE_RAW_BYTES)
+    g2 = np.frombuffer(raw[-256:-128], dtype=np.uint64)
+    sg2 = np.frombuffer(raw[-128:], dtype=np.uint64)
+    third.srs_set_g2(g2, sg2)
+    assert third.srs_write(fmt).tobytes() == img
+    for e_ in (eng, other, third):
+        e_.close()
+
+
+SHAPES = {"single": (1, 1, 1, 7, 6, 0), "multi": (4, 1, 1, 7, 5, 0), "idle": (5, 2, 2, 7, 5, 2)}
+
+
+def make(name):
+    A, L, Fx, k, lb, idle = SHAPES[name]
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=Fx, lookup_bits=lb, idle_gate_columns=idle)
+    return p, plonk.Shape(k, A, L, Fx, lb, idle), zk.circuit.synthesize(p, 0x5EED0019)
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_key_files_equal_the_oracle_images_and_round_trip(name):
+    p, sh, asg = make(name)
+    eng = zk.Engine(0)
+    eng.srs_setup(sh.k)
+    pk = eng.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)
+    fpk = fp.keygen(sh, asg.fixed, asg.copies)
+    polys = []
+    for col in asg.advice:
+        h = eng.poly(sh.n)
+        eng.upload_canonical(h, asg.to_limbs(col))
+        polys.append(h)
+    seed = b"\x42" * 32
+    want = eng.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM)
+    for fmt in FMTS:
+        vk_img = eng.vk_write(pk, fmt).tobytes()
+        assert vk_img == serde.vk_bytes(sh, fpk.vk.fixed_commitments, fpk.vk.permutation_commitments, serde.selectors_of(sh, asg.fixed), fmt)
+        fc, pc, sel = serde.vk_parse(sh, vk_img, fmt)
+        assert fc == fpk.vk.fixed_commitments and pc == fpk.vk.permutation_commitments and sel == serde.selectors_of(sh, asg.fixed)
+        pk_img = eng.pk_write(pk, fmt)
+        assert pk_img.tobytes() == serde.pk_bytes(fpk, asg.fixed, fmt)
+        # a fresh context: SRS from its file, key from its file, same advice -> the same proof bytes
+        other = zk.Engine(0)
+        other.srs_read(eng.srs_write(fmt), fmt)
+        pk2 = other.pk_read(p, pk_img, fmt)
+        polys2 = []
+        for col in asg.advice:
+            h = other.poly(sh.n)
+            other.upload_canonical(h, asg.to_limbs(col))
+            polys2.append(h)
+        assert other.prove(pk2, polys2, seed, E.ZK_TRANSCRIPT_EVM) == want
+        assert other.prove(pk2, polys2, seed, E.ZK_TRANSCRIPT_BLAKE2B) == eng.prove(pk, polys, seed, E.ZK_TRANSCRIPT_BLAKE2B)
+        assert other.pk_write(pk2, E.ZK_SERDE_RAW_BYTES).tobytes() == serde.pk_bytes(fpk, asg.fixed, E.ZK_SERDE_RAW_BYTES)
+        # malformed key images
+        for cut in (pk_img[:-1], np.concatenate([pk_img, np.zeros(1, np.uint8)])):
+            with pytest.raises(zk.ZkError):
+                other.pk_read(p, cut, fmt)
+        bad = pk_img.copy()
+        bad[3] ^= 1  # k in the vk header
+        with pytest.raises(zk.ZkError):
+            other.pk_read(p, bad, fmt)
+        if fmt != E.ZK_SERDE_RAW_BYTES_UNCHECKED:
+            bad = pk_img.copy()
+            off = len(vk_img) + 4  # first value of l0
+            bad[off:off + 32] = 0xFF  # >= r
+            with pytest.raises(zk.ZkError):
+                other.pk_read(p, bad, fmt)
+        wrong = zk.circuit.CircuitParams(degree=p.degree, num_advice=p.num_advice + 1, num_lookup_advice=p.num_lookup_advice,
+                                         num_fixed=p.num_fixed, lookup_bits=p.lookup_bits)
+        with pytest.raises(zk.ZkError):
+            other.pk_read(wrong, pk_img, fmt)
+        other.close()
+    eng.close()
+
+
+def test_host_verifying_key_and_transcript_repr_replace_the_stand_in():
+    """A Rust host hands over ITS VerifyingKey image and `vk.transcript_repr`: the engine adopts the digest only if the
+    image's commitments and selectors are the resident key's own; proofs then start their transcript from the host's
+    value (the oracle verifier accepts them under that value and rejects them under the stand-in)."""
+    p, sh, asg = make("multi")
+    eng = zk.Engine(0)
+    eng.srs_setup(sh.k)
+    pk = eng.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)
+    fc, pc, tr0 = eng.vk_export(pk)
+    polys = []
+    for col in asg.advice:
+        h = eng.poly(sh.n)
+        eng.upload_canonical(h, asg.to_limbs(col))
+        polys.append(h)
+    host_repr = 0x15CECFB8FA438E3F1D7BB5E3F61677B50739D2306F19CD66971E3473E1D8CA24  # the reference's k=17 digest (yul:34), as a value
+    img = eng.vk_write(pk, E.ZK_SERDE_RAW_BYTES)
+    eng.vk_load(pk, img, E.ZK_SERDE_RAW_BYTES, cops.fr_mont([host_repr])[0])
+    proof = eng.prove(pk, polys, b"\x01" * 32, E.ZK_TRANSCRIPT_EVM)
+    mk = lambda t: plonk.VerifyingKey(sh, cops.affine_arr_to_ints(fc), cops.affine_arr_to_ints(pc), t)
+    assert plonk.verify(mk(host_repr), proof, "evm")
+    assert not plonk.verify(mk(cops.fr_ints(tr0.reshape(1, 4))[0]), proof, "evm")
+    assert cops.fr_ints(eng.vk_export(pk)[2].reshape(1, 4))[0] == host_repr
+    # and it equals what the oracle prover makes under that digest
+    fpk = fp.keygen(sh, asg.fixed, asg.copies)
+    fpk.vk.transcript_repr = host_repr
+    assert proof == fp.create_proof(fpk, asg.advice, ChaCha20Rng(b"\x01" * 32), "evm")
+    # a vk of another circuit (one commitment swapped) or with other selector bits is refused
+    bad = img.copy()
+    bad[8:8 + 64], bad[8 + 64:8 + 128] = img[8 + 64:8 + 128].copy(), img[8:8 + 64].copy()
+    with pytest.raises(zk.ZkError) as e:
+        eng.vk_load(pk, bad, E.ZK_SERDE_RAW_BYTES, cops.fr_mont([5])[0])
+    assert e.value.code == -1
+    bad = img.copy()
+    bad[-1] ^= 0x10
+    with pytest.raises(zk.ZkError):
+        eng.vk_load(pk, bad, E.ZK_SERDE_RAW_BYTES)
+    with pytest.raises(zk.ZkError):
+        eng.pk_set_transcript_repr(pk, np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))  # not < r
+    assert cops.fr_ints(eng.vk_export(pk)[2].reshape(1, 4))[0] == host_repr  # refused loads change nothing
+    eng.close()
+
+
+def test_reference_k17_verifying_key_image(engine):
+    """K3 (P256Verifier.yul:34, 880-980): the reference's own k=17 verifying key, laid out as VerifyingKey::write
+    would (RawBytes), against the engine at k=17: the range-table commitment (K2, yul:889-890) is the resident key's
+    own; the other commitments belong to the real ECDSA circuit's cells, which the synthetic same-shape circuit does
+    not share — so zk_vk_load refuses the image, as it must for any vk that is not the resident key's."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vk_k17.json")))
+    pt = lambda q: (int(q[0], 16), int(q[1], 16))
+    sh = plonk.Shape(17, 4, 1, 1, 16)
+    p = zk.circuit.K17
+    asg = zk.circuit.synthesize(p, 0)
+    engine.srs_setup(17)
+    pk = engine.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)
+    ref_fixed, ref_perm = [pt(q) for q in d["fixed_commitments"]], [pt(q) for q in d["permutation_commitments"]]
+    img = serde.vk_bytes(sh, ref_fixed, ref_perm, serde.selectors_of(sh, asg.fixed), serde.RAW_BYTES)
+    assert len(img) == len(engine.vk_write(pk, E.ZK_SERDE_RAW_BYTES)) == 8 + 12 * 64 + 4 * (1 << 17) // 8
+    assert serde.vk_parse(sh, img, serde.RAW_BYTES)[:2] == (ref_fixed, ref_perm)  # every point of the reference's vk is on the curve
+    mine = cops.affine_arr_to_ints(engine.vk_export(pk)[0])
+    assert mine[sh.fx_table] == ref_fixed[1]  # K2
+    with pytest.raises(zk.ZkError) as e:
+        engine.vk_load(pk, img, E.ZK_SERDE_RAW_BYTES, cops.fr_mont([int(d["transcript_repr"], 16)])[0])
+    assert e.value.code == -1
+    engine.pk_free(pk)

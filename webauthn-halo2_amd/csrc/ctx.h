@@ -32,6 +32,10 @@ struct zk_ctx {
     G1Affine* g_table = nullptr;           // window multiples of g / g_lagrange (fixed-base MSM)
     G1Affine* g_lagrange_table = nullptr;
     uint32_t table_c = 0;
+    // G2 half of ParamsKZG (g2, s_g2 = [s]G2) as raw Montgomery images x.c0 || x.c1 || y.c0 || y.c1: the engine never
+    // computes with it, it only travels through the SRS file (zk_srs_write / zk_srs_read)
+    bool g2_valid = false;
+    uint8_t g2_raw[128] = {0}, s_g2_raw[128] = {0};
     uint64_t srs_gen = 0;  // bumped by every zk_srs_setup / zk_srs_load / zk_srs_read: keys remember the SRS they were made under
     // tuning options (zk_ctx_set_option); 0 = built-in choice
     uint32_t opt_msm_window = 0, opt_msm_batch = 0, opt_ntt_max_r = 0, opt_gp_batch_invert = 0;
@@ -119,3 +123,7 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
                   bool coset, size_t n_out);
 uint32_t ctx_ntt_max_batch(uint32_t log_n);
 void pk_destroy_all(zk_ctx* c);
+// SRS plumbing shared by engine.hip (setup / load) and serde.hip (read)
+int srs_alloc(zk_ctx* c, uint32_t k);
+int srs_build_tables(zk_ctx* c, uint32_t k);
+void srs_set_g2_from_secret(zk_ctx* c, const Fr& s_mont);

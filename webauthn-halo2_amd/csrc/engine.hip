@@ -204,8 +204,6 @@ int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size
 
 // ------------------------------------------------------------------ C ABI --
 
-extern "C" {
-
 int zk_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -488,7 +486,7 @@ ZK_API(zk_ntt_bn254_fr, (zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32
 
 // ---- SRS ---------------------------------------------------------------------
 // window-multiple tables of both bases for the fixed-base MSM (k >= 10; smaller SRS use the generic path)
-static int srs_build_tables(zk_ctx* c, uint32_t k) {
+int srs_build_tables(zk_ctx* c, uint32_t k) {
     if (k < 10) return ZK_OK;
     const uint32_t n = 1u << k;
     const uint32_t cw = msm_auto_window(n, c->opt_msm_window);
@@ -507,8 +505,9 @@ static int srs_build_tables(zk_ctx* c, uint32_t k) {
     return ZK_OK;
 }
 
-static int srs_alloc(zk_ctx* c, uint32_t k) {
+int srs_alloc(zk_ctx* c, uint32_t k) {
     if (k < 1 || k > 24) return ZK_EINVAL;
+    c->g2_valid = false;
     c->srs_gen++;  // proving keys made under the previous SRS are refused from now on (ZK_ESTATE)
     const size_t n = (size_t)1 << k;
     if (c->g) hipFree(c->g);
@@ -599,7 +598,10 @@ ZK_API(zk_srs_setup, (zk_ctx* c, uint32_t k, const uint8_t seed[32]), (c, k, see
     hipFree(d_table);
     hipFree(d_sc);
     if (rc == ZK_OK) rc = srs_build_tables(c, k);
-    if (rc == ZK_OK) c->srs_k = (int)k;
+    if (rc == ZK_OK) {
+        srs_set_g2_from_secret(c, s);  // g2 = G2 generator, s_g2 = [s]G2 (host side: it only travels through zk_srs_write)
+        c->srs_k = (int)k;
+    }
     return rc;
 }
 
@@ -767,7 +769,6 @@ ZK_API(zk_commit_batch, (zk_ctx* c, const zk_poly* hs, size_t count, int basis, 
     return ZK_OK;
 }
 
-}  // extern "C"
 
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
     return ctx_ntt_batch(c, &src, src_n, &dst, 1, log_n, inverse, coset, n_out);
@@ -828,8 +829,6 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
 static int ntt_resident(zk_ctx* c, PolyRec* src, PolyRec* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out) {
     return ctx_ntt(c, src->ptr, src->n, dst->ptr, log_n, inverse, coset, n_out);
 }
-
-extern "C" {
 
 static uint32_t log2_exact(size_t n) {
     uint32_t l = 0;
@@ -905,4 +904,3 @@ ZK_API(zk_eval, (zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]), (c
     return ZK_OK;
 }
 
-}  // extern "C"

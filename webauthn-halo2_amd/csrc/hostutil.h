@@ -62,7 +62,11 @@ inline Fr fr_omega(uint32_t k) {  // primitive 2^k-th root: ROOT^(2^(28-k))
     return w;
 }
 
-inline Fr fr_zeta() {  // 7^((r-1)/3): halo2curves Fr::ZETA (extended-domain coset generator)
+// halo2curves bn256 Fr::ZETA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23 [RECALLED constant; it is a
+// primitive cube root of unity, namely (7^((r-1)/3))^2], the extended-domain coset generator `g_coset` of halo2's
+// EvaluationDomain.  h(X) — and so every proof byte — is the same for either cube root; the extended cosets inside a
+// ProvingKey file (zk_pk_read / zk_pk_write) are not, hence halo2's choice.
+inline Fr fr_zeta_root() {  // 7^((r-1)/3)
     // (r-1)/3
     uint32_t rm1[8];
     for (int i = 0; i < 8; i++) rm1[i] = FrParams::P[i];
@@ -76,6 +80,7 @@ inline Fr fr_zeta() {  // 7^((r-1)/3): halo2curves Fr::ZETA (extended-domain cos
     }
     return fe_pow(fr_from_u64(7), q);
 }
+inline Fr fr_zeta() { return fe_sqr(fr_zeta_root()); }
 
 // ---- ChaCha20 ---------------------------------------------------------------
 inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }

@@ -1,0 +1,127 @@
+// pk.h — the resident proving key record shared by prover.hip (keygen / create_proof) and serde.hip
+// (ProvingKey / VerifyingKey read & write).  Not part of the public C-ABI.
+#pragma once
+#include <utility>
+#include <vector>
+
+#include "ctx.h"
+#include "prover.h"
+
+struct Col {
+    int fixed;  // 1 = fixed column, 0 = advice
+    uint32_t idx;
+};
+
+struct Layout {
+    uint32_t k, n, A, L, F, lookup_bits, idle;
+    bool single;
+    uint32_t n_gate, n_lookup_cols, n_adv, fx_table, fx_qlookup, n_fix;
+    std::vector<uint32_t> fx_sel;
+    std::vector<Col> perm_cols;
+    uint32_t n_lookups, degree, chunk_len, n_chunks, n_h, ext_k, usable;
+    int last_rot;
+    std::vector<std::pair<uint32_t, int>> advice_queries;
+
+    bool init(const zk_circuit_params& p) {
+        k = p.k; A = p.num_advice; L = p.num_lookup_advice; F = p.num_fixed; lookup_bits = p.lookup_bits;
+        idle = p.num_idle_gate_columns;
+        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1 || idle >= A) return false;
+        if (lookup_bits < 1 || lookup_bits >= k) return false;  // the range table 0 .. 2^lookup_bits - 1 must fit in the usable rows
+        n = 1u << k;
+        single = A == 1;
+        n_gate = A;
+        n_lookup_cols = single ? 0 : L;
+        n_adv = A + n_lookup_cols;
+        fx_table = F;
+        fx_sel.clear();
+        if (single) {
+            fx_sel.push_back(F + 1);
+            fx_qlookup = F + 2;
+            n_fix = F + 3;
+        } else {
+            for (uint32_t j = 0; j < A; j++) fx_sel.push_back(j < A - idle ? F + 1 + j : NO_SELECTOR);
+            fx_qlookup = 0;
+            n_fix = F + 1 + A - idle;
+        }
+        perm_cols.clear();
+        for (uint32_t f = 0; f < F; f++) perm_cols.push_back(Col{1, f});
+        for (uint32_t j = 0; j < n_adv; j++) perm_cols.push_back(Col{0, j});
+        n_lookups = single ? 1 : L;
+        degree = single ? 5 : 4;
+        chunk_len = degree - 2;
+        n_chunks = ((uint32_t)perm_cols.size() + chunk_len - 1) / chunk_len;
+        n_h = degree - 1;
+        ext_k = k + 2;
+        usable = n - (BLINDING_FACTORS + 1);
+        last_rot = -(int)(BLINDING_FACTORS + 1);
+        advice_queries.clear();
+        for (uint32_t j = 0; j < A; j++)
+            for (int r = 0; r < 4; r++) advice_queries.push_back({j, r});
+        for (uint32_t l = 0; l < n_lookup_cols; l++) advice_queries.push_back({A + l, 0});
+        if ((1u << lookup_bits) >= usable) return false;
+        return n_adv <= MAX_ADV && n_fix <= MAX_FIX && perm_cols.size() <= MAX_PERM && n_chunks <= MAX_CHUNKS &&
+               n_lookups <= MAX_LOOKUPS;
+    }
+};
+
+static constexpr uint32_t ROWS_CAP = 512, ROWS_BLOCKS = 16;  // staged row writes per flush / flushes per ring
+
+struct zk_pk_rec {
+    Layout lay;
+    uint64_t srs_gen = 0;  // the context's SRS generation the key's commitments belong to
+    std::vector<Fr*> dev;  // every device allocation (freed together)
+    std::vector<Fr*> fixed_val, fixed_poly, fixed_coset, sigma_val, sigma_poly, sigma_coset;
+    Fr *l0_coset = nullptr, *l_last_coset = nullptr, *l_active_coset = nullptr;
+    std::vector<G1Affine> fixed_commit, perm_commit;
+    Fr transcript_repr;
+    // prover workspace
+    std::vector<Fr*> adv_val, adv_poly, adv_coset;
+    std::vector<Fr*> z_val, z_poly, z_coset;
+    std::vector<Fr*> lk_in, lk_ap, lk_ap_poly, lk_ap_coset, lk_sp, lk_sp_poly, lk_sp_coset, lk_z, lk_z_poly, lk_z_coset,
+        lk_in_coset;
+    Fr *random_poly = nullptr, *h_ext = nullptr, *h_comb = nullptr;
+    Fr *t_num = nullptr, *t_den = nullptr, *t_frac = nullptr, *t_a = nullptr, *t_b = nullptr, *t_small = nullptr;
+    Fr* kd_scratch = nullptr;  // Kate divisions: KD_MAX_BATCH x kate_division_scratch(n)
+    Fr* tail_host = nullptr;  // pinned staging for evaluations / scalars
+    RowEntry* rows_host = nullptr;  // pinned: ROWS_BLOCKS blocks of ROWS_CAP staged row writes (Prover::set_rows)
+    RowEntry* rows_dev = nullptr;
+    LookupScratch lks{};
+    uint32_t* lk_u32 = nullptr;
+    // all grand products of a proof in one batch (launch_gp_batch_*)
+    std::vector<Fr*> gp_num, gp_den, gp_loc_p, gp_loc_r;  // per product, n each
+    Fr* gp_tot = nullptr;        // 2 x blocks per product
+    Fr* gp_scal = nullptr;       // device: q, q_inv, k, init (n_prod each)
+    Fr* gp_host = nullptr;       // pinned: q and q_inv
+    GpItem* d_gp_items = nullptr;
+    QuotientArgs* d_qargs = nullptr;
+    QuotientArgs* h_qargs = nullptr;  // pinned staging of the same
+    EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
+    uint32_t max_evals = 0;
+    Fr *ev_scratch = nullptr, *ev_out = nullptr;
+};
+
+
+// every device allocation of a key goes through Dev (freed together by pk_destroy)
+struct Dev {
+    zk_ctx* c;
+    zk_pk_rec* pk;
+    int rc = ZK_OK;
+
+    Fr* alloc(size_t n) {
+        Fr* p = nullptr;
+        if (rc) return nullptr;
+        if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
+            rc = ZK_ENOMEM;
+            return nullptr;
+        }
+        pk->dev.push_back(p);
+        return p;
+    }
+};
+
+void pk_destroy(zk_pk_rec* pk);
+// the per-proof workspace (advice / z / lookup forms, quotient buffer, scan and evaluation scratch): everything a key
+// needs beyond the key material itself; called at the end of zk_keygen and zk_pk_read
+int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk);
+// stand-in transcript_repr of a key made here (same rule as the oracle's keygen); a host-supplied value replaces it
+Fr pk_standin_transcript_repr(const zk_pk_rec* pk);

@@ -19,108 +19,10 @@
 #include <deque>
 #include <vector>
 
-#include "ctx.h"
-#include "prover.h"
+#include "pk.h"
 #include "transcript.h"
 
 using namespace zk;
-
-namespace {
-
-struct Col {
-    int fixed;  // 1 = fixed column, 0 = advice
-    uint32_t idx;
-};
-
-struct Layout {
-    uint32_t k, n, A, L, F, lookup_bits, idle;
-    bool single;
-    uint32_t n_gate, n_lookup_cols, n_adv, fx_table, fx_qlookup, n_fix;
-    std::vector<uint32_t> fx_sel;
-    std::vector<Col> perm_cols;
-    uint32_t n_lookups, degree, chunk_len, n_chunks, n_h, ext_k, usable;
-    int last_rot;
-    std::vector<std::pair<uint32_t, int>> advice_queries;
-
-    bool init(const zk_circuit_params& p) {
-        k = p.k; A = p.num_advice; L = p.num_lookup_advice; F = p.num_fixed; lookup_bits = p.lookup_bits;
-        idle = p.num_idle_gate_columns;
-        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1 || idle >= A) return false;
-        if (lookup_bits < 1 || lookup_bits >= k) return false;  // the range table 0 .. 2^lookup_bits - 1 must fit in the usable rows
-        n = 1u << k;
-        single = A == 1;
-        n_gate = A;
-        n_lookup_cols = single ? 0 : L;
-        n_adv = A + n_lookup_cols;
-        fx_table = F;
-        fx_sel.clear();
-        if (single) {
-            fx_sel.push_back(F + 1);
-            fx_qlookup = F + 2;
-            n_fix = F + 3;
-        } else {
-            for (uint32_t j = 0; j < A; j++) fx_sel.push_back(j < A - idle ? F + 1 + j : NO_SELECTOR);
-            fx_qlookup = 0;
-            n_fix = F + 1 + A - idle;
-        }
-        perm_cols.clear();
-        for (uint32_t f = 0; f < F; f++) perm_cols.push_back(Col{1, f});
-        for (uint32_t j = 0; j < n_adv; j++) perm_cols.push_back(Col{0, j});
-        n_lookups = single ? 1 : L;
-        degree = single ? 5 : 4;
-        chunk_len = degree - 2;
-        n_chunks = ((uint32_t)perm_cols.size() + chunk_len - 1) / chunk_len;
-        n_h = degree - 1;
-        ext_k = k + 2;
-        usable = n - (BLINDING_FACTORS + 1);
-        last_rot = -(int)(BLINDING_FACTORS + 1);
-        advice_queries.clear();
-        for (uint32_t j = 0; j < A; j++)
-            for (int r = 0; r < 4; r++) advice_queries.push_back({j, r});
-        for (uint32_t l = 0; l < n_lookup_cols; l++) advice_queries.push_back({A + l, 0});
-        if ((1u << lookup_bits) >= usable) return false;
-        return n_adv <= MAX_ADV && n_fix <= MAX_FIX && perm_cols.size() <= MAX_PERM && n_chunks <= MAX_CHUNKS &&
-               n_lookups <= MAX_LOOKUPS;
-    }
-};
-
-}  // namespace
-
-static constexpr uint32_t ROWS_CAP = 512, ROWS_BLOCKS = 16;  // staged row writes per flush / flushes per ring
-
-struct zk_pk_rec {
-    Layout lay;
-    uint64_t srs_gen = 0;  // the context's SRS generation the key's commitments belong to
-    std::vector<Fr*> dev;  // every device allocation (freed together)
-    std::vector<Fr*> fixed_val, fixed_poly, fixed_coset, sigma_val, sigma_poly, sigma_coset;
-    Fr *l0_coset = nullptr, *l_last_coset = nullptr, *l_active_coset = nullptr;
-    std::vector<G1Affine> fixed_commit, perm_commit;
-    Fr transcript_repr;
-    // prover workspace
-    std::vector<Fr*> adv_val, adv_poly, adv_coset;
-    std::vector<Fr*> z_val, z_poly, z_coset;
-    std::vector<Fr*> lk_in, lk_ap, lk_ap_poly, lk_ap_coset, lk_sp, lk_sp_poly, lk_sp_coset, lk_z, lk_z_poly, lk_z_coset,
-        lk_in_coset;
-    Fr *random_poly = nullptr, *h_ext = nullptr, *h_comb = nullptr;
-    Fr *t_num = nullptr, *t_den = nullptr, *t_frac = nullptr, *t_a = nullptr, *t_b = nullptr, *t_small = nullptr;
-    Fr* kd_scratch = nullptr;  // Kate divisions: KD_MAX_BATCH x kate_division_scratch(n)
-    Fr* tail_host = nullptr;  // pinned staging for evaluations / scalars
-    RowEntry* rows_host = nullptr;  // pinned: ROWS_BLOCKS blocks of ROWS_CAP staged row writes (Prover::set_rows)
-    RowEntry* rows_dev = nullptr;
-    LookupScratch lks{};
-    uint32_t* lk_u32 = nullptr;
-    // all grand products of a proof in one batch (launch_gp_batch_*)
-    std::vector<Fr*> gp_num, gp_den, gp_loc_p, gp_loc_r;  // per product, n each
-    Fr* gp_tot = nullptr;        // 2 x blocks per product
-    Fr* gp_scal = nullptr;       // device: q, q_inv, k, init (n_prod each)
-    Fr* gp_host = nullptr;       // pinned: q and q_inv
-    GpItem* d_gp_items = nullptr;
-    QuotientArgs* d_qargs = nullptr;
-    QuotientArgs* h_qargs = nullptr;  // pinned staging of the same
-    EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
-    uint32_t max_evals = 0;
-    Fr *ev_scratch = nullptr, *ev_out = nullptr;
-};
 
 namespace {
 
@@ -134,23 +36,6 @@ __global__ void sigma_kernel(const uint2* __restrict__ map, const Fr* __restrict
 }
 
 // ------------------------------------------------------------ small utils ---
-struct Dev {
-    zk_ctx* c;
-    zk_pk_rec* pk;
-    int rc = ZK_OK;
-
-    Fr* alloc(size_t n) {
-        Fr* p = nullptr;
-        if (rc) return nullptr;
-        if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
-            rc = ZK_ENOMEM;
-            return nullptr;
-        }
-        pk->dev.push_back(p);
-        return p;
-    }
-};
-
 bool commit(zk_ctx* c, const Fr* poly, size_t len, int basis, G1Affine* out) {
     G1Jac j;
     if (ctx_msm_device(c, poly, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, len, &j) != ZK_OK) return false;
@@ -235,6 +120,110 @@ void pk_destroy(zk_pk_rec* pk) {
 void pk_destroy_all(zk_ctx* c) {
     for (auto& kv : c->pks) pk_destroy(kv.second);
     c->pks.clear();
+}
+
+Fr pk_standin_transcript_repr(const zk_pk_rec* pk) {
+    const Layout& lay = pk->lay;
+    // stand-in for halo2's pinned-vk hash (same rule as the oracle's keygen)
+    {
+        Blake2b h("zkmi355-vk-repr");
+        const uint16_t hdr[6] = {(uint16_t)lay.k, (uint16_t)lay.A,           (uint16_t)lay.L,
+                                 (uint16_t)lay.F, (uint16_t)lay.lookup_bits, (uint16_t)lay.idle};
+        h.update((const uint8_t*)hdr, 12);
+        auto absorb = [&](const G1Affine& p) {
+            const Fq x = fe_from_mont(p.x), y = fe_from_mont(p.y);
+            h.update((const uint8_t*)x.v, 32);
+            h.update((const uint8_t*)y.v, 32);
+        };
+        for (auto& p : pk->fixed_commit) absorb(p);
+        for (auto& p : pk->perm_commit) absorb(p);
+        uint8_t dg[64];
+        h.finalize_copy(dg);
+        return fr_from_u512_le(dg);
+    }
+}
+
+int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk) {
+    const Layout& lay = pk->lay;
+    const uint32_t n = lay.n, N = 4 * n, T = 1u << lay.lookup_bits;
+    Dev d{c, pk};
+    auto fail = [&](int code) { return code; };  // the caller destroys the key
+    // ---- prover workspace
+    for (uint32_t j = 0; j < lay.n_adv; j++) {
+        pk->adv_val.push_back(d.alloc(n));
+        pk->adv_poly.push_back(d.alloc(n));
+        pk->adv_coset.push_back(d.alloc(N));
+    }
+    for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+        pk->z_val.push_back(d.alloc(n));
+        pk->z_poly.push_back(d.alloc(n));
+        pk->z_coset.push_back(d.alloc(N));
+    }
+    for (uint32_t l = 0; l < lay.n_lookups; l++) {
+        pk->lk_in.push_back(lay.single ? d.alloc(n) : nullptr);
+        pk->lk_ap.push_back(d.alloc(n));
+        pk->lk_ap_poly.push_back(d.alloc(n));
+        pk->lk_ap_coset.push_back(d.alloc(N));
+        pk->lk_sp.push_back(d.alloc(n));
+        pk->lk_sp_poly.push_back(d.alloc(n));
+        pk->lk_sp_coset.push_back(d.alloc(N));
+        pk->lk_z.push_back(d.alloc(n));
+        pk->lk_z_poly.push_back(d.alloc(n));
+        pk->lk_z_coset.push_back(d.alloc(N));
+    }
+    pk->random_poly = d.alloc(n);
+    pk->h_ext = d.alloc(N);
+    pk->h_comb = d.alloc(n);
+    pk->t_num = d.alloc(n);
+    pk->t_den = d.alloc(n);
+    pk->t_frac = d.alloc(n);
+    pk->t_a = d.alloc(n);
+    pk->t_b = d.alloc(n);
+    pk->t_small = d.alloc(n / 16 + 8192);
+    pk->kd_scratch = d.alloc((size_t)KD_MAX_BATCH * kate_division_scratch(n));
+    {
+        const uint32_t nprod = lay.n_chunks + lay.n_lookups;
+        for (uint32_t p = 0; p < nprod; p++) {
+            pk->gp_num.push_back(d.alloc(n));
+            pk->gp_den.push_back(d.alloc(n));
+            pk->gp_loc_p.push_back(d.alloc(n));
+            pk->gp_loc_r.push_back(d.alloc(n));
+        }
+        pk->gp_tot = d.alloc((size_t)2 * gp_blocks(n) * nprod);
+        pk->gp_scal = d.alloc((size_t)4 * nprod);
+        if (hipHostMalloc(&pk->gp_host, (size_t)2 * nprod * sizeof(Fr)) != hipSuccess ||
+            hipMalloc(&pk->d_gp_items, nprod * sizeof(GpItem)) != hipSuccess)
+            return fail(ZK_ENOMEM);
+    }
+    if (d.rc) return fail(d.rc);
+    if (hipHostMalloc(&pk->tail_host, (pk->max_evals + 16) * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->rows_host, (size_t)ROWS_BLOCKS * ROWS_CAP * sizeof(RowEntry)) != hipSuccess ||
+        hipMalloc(&pk->rows_dev, (size_t)ROWS_BLOCKS * ROWS_CAP * sizeof(RowEntry)) != hipSuccess)
+        return fail(ZK_ENOMEM);
+    if (hipHostMalloc(&pk->h_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess ||
+        hipMalloc(&pk->d_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess)
+        return fail(ZK_ENOMEM);
+    pk->ev_scratch = d.alloc((size_t)pk->max_evals * eval_blocks(n));
+    pk->ev_out = d.alloc(pk->max_evals);
+    if (d.rc) return fail(d.rc);
+    {
+        // per lookup: six arrays of T + 2 words and 3 x blocks block sums; one error flag for all
+        const uint32_t stride = 6 * (T + 2) + 3 * (T / 1024 + 2);
+        if (hipMalloc(&pk->lk_u32, ((size_t)stride * lay.n_lookups + 4) * 4) != hipSuccess) return fail(ZK_ENOMEM);
+        uint32_t* b = pk->lk_u32;
+        pk->lks.hist = b;
+        pk->lks.present = b + (T + 2);
+        pk->lks.absent = b + 2 * (T + 2);
+        pk->lks.off = b + 3 * (T + 2);
+        pk->lks.dex = b + 4 * (T + 2);
+        pk->lks.aex = b + 5 * (T + 2);
+        pk->lks.bsum = b + 6 * (T + 2);
+        pk->lks.stride = stride;
+        pk->lks.err = b + (size_t)stride * lay.n_lookups;
+    }
+    if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess || hipHostMalloc(&pk->h_qargs, sizeof(QuotientArgs)) != hipSuccess)
+        return fail(ZK_ENOMEM);
+    return ZK_OK;
 }
 
 // =================================================================== keygen ==
@@ -380,98 +369,8 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
         for (uint32_t r = 0; r < n; r++) tmp[r] = r < lay.usable ? Fr::one() : Fr::zero();
         if ((rc = make(pk->l_active_coset))) return fail(rc);
     }
-    // ---- transcript_repr: stand-in for halo2's pinned-vk hash (same rule as the oracle's keygen)
-    {
-        Blake2b h("zkmi355-vk-repr");
-        const uint16_t hdr[6] = {(uint16_t)lay.k, (uint16_t)lay.A,           (uint16_t)lay.L,
-                                 (uint16_t)lay.F, (uint16_t)lay.lookup_bits, (uint16_t)lay.idle};
-        h.update((const uint8_t*)hdr, 12);
-        auto absorb = [&](const G1Affine& p) {
-            const Fq x = fe_from_mont(p.x), y = fe_from_mont(p.y);
-            h.update((const uint8_t*)x.v, 32);
-            h.update((const uint8_t*)y.v, 32);
-        };
-        for (auto& p : pk->fixed_commit) absorb(p);
-        for (auto& p : pk->perm_commit) absorb(p);
-        uint8_t dg[64];
-        h.finalize_copy(dg);
-        pk->transcript_repr = fr_from_u512_le(dg);
-    }
-    // ---- prover workspace
-    for (uint32_t j = 0; j < lay.n_adv; j++) {
-        pk->adv_val.push_back(d.alloc(n));
-        pk->adv_poly.push_back(d.alloc(n));
-        pk->adv_coset.push_back(d.alloc(N));
-    }
-    for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
-        pk->z_val.push_back(d.alloc(n));
-        pk->z_poly.push_back(d.alloc(n));
-        pk->z_coset.push_back(d.alloc(N));
-    }
-    for (uint32_t l = 0; l < lay.n_lookups; l++) {
-        pk->lk_in.push_back(lay.single ? d.alloc(n) : nullptr);
-        pk->lk_ap.push_back(d.alloc(n));
-        pk->lk_ap_poly.push_back(d.alloc(n));
-        pk->lk_ap_coset.push_back(d.alloc(N));
-        pk->lk_sp.push_back(d.alloc(n));
-        pk->lk_sp_poly.push_back(d.alloc(n));
-        pk->lk_sp_coset.push_back(d.alloc(N));
-        pk->lk_z.push_back(d.alloc(n));
-        pk->lk_z_poly.push_back(d.alloc(n));
-        pk->lk_z_coset.push_back(d.alloc(N));
-    }
-    pk->random_poly = d.alloc(n);
-    pk->h_ext = d.alloc(N);
-    pk->h_comb = d.alloc(n);
-    pk->t_num = d.alloc(n);
-    pk->t_den = d.alloc(n);
-    pk->t_frac = d.alloc(n);
-    pk->t_a = d.alloc(n);
-    pk->t_b = d.alloc(n);
-    pk->t_small = d.alloc(n / 16 + 8192);
-    pk->kd_scratch = d.alloc((size_t)KD_MAX_BATCH * kate_division_scratch(n));
-    {
-        const uint32_t nprod = lay.n_chunks + lay.n_lookups;
-        for (uint32_t p = 0; p < nprod; p++) {
-            pk->gp_num.push_back(d.alloc(n));
-            pk->gp_den.push_back(d.alloc(n));
-            pk->gp_loc_p.push_back(d.alloc(n));
-            pk->gp_loc_r.push_back(d.alloc(n));
-        }
-        pk->gp_tot = d.alloc((size_t)2 * gp_blocks(n) * nprod);
-        pk->gp_scal = d.alloc((size_t)4 * nprod);
-        if (hipHostMalloc(&pk->gp_host, (size_t)2 * nprod * sizeof(Fr)) != hipSuccess ||
-            hipMalloc(&pk->d_gp_items, nprod * sizeof(GpItem)) != hipSuccess)
-            return fail(ZK_ENOMEM);
-    }
-    if (d.rc) return fail(d.rc);
-    if (hipHostMalloc(&pk->tail_host, (pk->max_evals + 16) * sizeof(Fr)) != hipSuccess) return fail(ZK_ENOMEM);
-    if (hipHostMalloc(&pk->rows_host, (size_t)ROWS_BLOCKS * ROWS_CAP * sizeof(RowEntry)) != hipSuccess ||
-        hipMalloc(&pk->rows_dev, (size_t)ROWS_BLOCKS * ROWS_CAP * sizeof(RowEntry)) != hipSuccess)
-        return fail(ZK_ENOMEM);
-    if (hipHostMalloc(&pk->h_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess ||
-        hipMalloc(&pk->d_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess)
-        return fail(ZK_ENOMEM);
-    pk->ev_scratch = d.alloc((size_t)pk->max_evals * eval_blocks(n));
-    pk->ev_out = d.alloc(pk->max_evals);
-    if (d.rc) return fail(d.rc);
-    {
-        // per lookup: six arrays of T + 2 words and 3 x blocks block sums; one error flag for all
-        const uint32_t stride = 6 * (T + 2) + 3 * (T / 1024 + 2);
-        if (hipMalloc(&pk->lk_u32, ((size_t)stride * lay.n_lookups + 4) * 4) != hipSuccess) return fail(ZK_ENOMEM);
-        uint32_t* b = pk->lk_u32;
-        pk->lks.hist = b;
-        pk->lks.present = b + (T + 2);
-        pk->lks.absent = b + 2 * (T + 2);
-        pk->lks.off = b + 3 * (T + 2);
-        pk->lks.dex = b + 4 * (T + 2);
-        pk->lks.aex = b + 5 * (T + 2);
-        pk->lks.bsum = b + 6 * (T + 2);
-        pk->lks.stride = stride;
-        pk->lks.err = b + (size_t)stride * lay.n_lookups;
-    }
-    if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess || hipHostMalloc(&pk->h_qargs, sizeof(QuotientArgs)) != hipSuccess)
-        return fail(ZK_ENOMEM);
+    pk->transcript_repr = pk_standin_transcript_repr(pk);
+    if ((rc = pk_alloc_workspace(c, pk))) return fail(rc);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
     const uint64_t h = c->next_handle++;
     c->pks[h] = pk;

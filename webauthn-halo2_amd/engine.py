@@ -19,6 +19,7 @@ ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS =
 
 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
+ZK_SERDE_PROCESSED, ZK_SERDE_RAW_BYTES, ZK_SERDE_RAW_BYTES_UNCHECKED = 0, 1, 2
 ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT = 1, 2, 3, 4
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
@@ -94,6 +95,13 @@ def load_library():
         "zk_proof_size": ([vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_prove": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.c_char_p, ctypes.c_int,
                       ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_srs_write": ([vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_srs_read": ([vp, vp, sz, ctypes.c_int], ctypes.c_int),
+        "zk_srs_set_g2": ([vp, u64p, u64p], ctypes.c_int),
+        "zk_vk_write": ([vp, ctypes.c_uint64, ctypes.c_int, vp, sz, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_vk_load": ([vp, ctypes.c_uint64, vp, sz, ctypes.c_int, u64p], ctypes.c_int),
+        "zk_pk_write": ([vp, ctypes.c_uint64, ctypes.c_int, vp, sz, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_pk_read": ([vp, ctypes.POINTER(CircuitParamsC), vp, sz, ctypes.c_int, u64p, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_poly_upload_canonical": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
     }
     for name, (args, res) in sig.items():
@@ -202,6 +210,50 @@ class Engine:
         out = np.zeros((count, 8), dtype=np.uint64)
         self._chk(self.L.zk_srs_export(self.ctx, basis, _p(out), first, count), "zk_srs_export")
         return out
+
+    # ---- the reference's files (ParamsKZG / VerifyingKey / ProvingKey images) ------------
+    def _write(self, fn, what, *args):
+        ln = ctypes.c_size_t()
+        self._chk(fn(self.ctx, *args, None, 0, ctypes.byref(ln)), what)
+        buf = np.empty(ln.value, dtype=np.uint8)
+        self._chk(fn(self.ctx, *args, buf.ctypes.data, buf.size, ctypes.byref(ln)), what)
+        return buf  # numpy uint8 (a k=19 proving key is 768 MiB: no bytes() copy unless the caller wants one)
+
+    @staticmethod
+    def _bytes_arg(data):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        return a, a.ctypes.data, a.size
+
+    def srs_write(self, fmt=ZK_SERDE_RAW_BYTES):
+        return self._write(self.L.zk_srs_write, "zk_srs_write", fmt)
+
+    def srs_read(self, data, fmt=ZK_SERDE_RAW_BYTES):
+        keep, ptr, n = self._bytes_arg(data)
+        self._chk(self.L.zk_srs_read(self.ctx, ptr, n, fmt), "zk_srs_read")
+
+    def srs_set_g2(self, g2, s_g2):
+        a, b = (np.ascontiguousarray(v, dtype=np.uint64).reshape(16) for v in (g2, s_g2))
+        self._chk(self.L.zk_srs_set_g2(self.ctx, _p(a), _p(b)), "zk_srs_set_g2")
+
+    def vk_write(self, pk, fmt=ZK_SERDE_RAW_BYTES):
+        return self._write(self.L.zk_vk_write, "zk_vk_write", pk, fmt)
+
+    def vk_load(self, pk, data, fmt=ZK_SERDE_RAW_BYTES, transcript_repr=None):
+        keep, ptr, n = self._bytes_arg(data)
+        t = None if transcript_repr is None else _p(np.ascontiguousarray(transcript_repr, dtype=np.uint64).reshape(4))
+        self._chk(self.L.zk_vk_load(self.ctx, pk, ptr, n, fmt, t), "zk_vk_load")
+
+    def pk_write(self, pk, fmt=ZK_SERDE_RAW_BYTES):
+        return self._write(self.L.zk_pk_write, "zk_pk_write", pk, fmt)
+
+    def pk_read(self, params, data, fmt=ZK_SERDE_RAW_BYTES, transcript_repr=None):
+        cp = CircuitParamsC(params.degree, params.num_advice, params.num_lookup_advice, params.num_fixed, params.lookup_bits,
+                            getattr(params, "idle_gate_columns", 0))
+        keep, ptr, n = self._bytes_arg(data)
+        t = None if transcript_repr is None else _p(np.ascontiguousarray(transcript_repr, dtype=np.uint64).reshape(4))
+        h = ctypes.c_uint64()
+        self._chk(self.L.zk_pk_read(self.ctx, ctypes.byref(cp), ptr, n, fmt, t, ctypes.byref(h)), "zk_pk_read")
+        return h.value
 
     # ---- resident polynomials ---------------------------------------------------
     def poly(self, n, data=None):
