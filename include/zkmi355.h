@@ -63,7 +63,7 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
  * environment variables. */
 #define ZK_OPT_MSM_WINDOW 1          /* signed window bits of the fixed-base MSM, 9..15; takes effect at the next SRS load */
 #define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..64 */
-#define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..9 */
+#define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..11 (clamped to the tile) */
 #define ZK_OPT_GP_BATCH_INVERT 4     /* 1: grand products always take halo2's batch_invert form (the fallback path) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 base=$(basename $src .hip)
 hipcc $FLAGS $defs -c csrc/$src -o build/${base}_$tag.o
 objs=""
-for s in engine ntt msm poly prover_kernels quotient prover; do
+for s in engine ntt msm poly prover_kernels quotient prover serde; do
   if [ $s = $base ]; then objs="$objs build/${base}_$tag.o"; else objs="$objs build/$s.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o build/libzkmi355_$tag.so $objs

@@ -20,7 +20,7 @@ struct NttJob {
     uint32_t batch;
     const Fr* srcs[NTT_MAX_BATCH];
     Fr* dsts[NTT_MAX_BATCH];
-    const Fr* tw;       // twiddle table w^i, i < 2^log_n
+    const Fr* tw;       // twiddle table in the NTT's internal form: w^i * 2^261 mod p, i < 2^log_n (launch_twiddles_internal)
     uint32_t log_n;
     uint32_t inverse;   // use w^-1
     uint32_t n_in, n_out;
@@ -29,7 +29,8 @@ struct NttJob {
     uint32_t max_log_r; // 0 = default
 };
 hipError_t ntt_run(const NttJob& job, hipStream_t st);
-void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);
+void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);           // w^i, standard Montgomery form
+void launch_twiddles_internal(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);  // w^i * 2^261 (plain words): ntt.hip's own form
 int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
 
 // ---- MSM (msm.hip) ---------------------------------------------------------

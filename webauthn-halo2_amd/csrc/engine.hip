@@ -68,6 +68,22 @@ int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
     return ZK_OK;
 }
 
+int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out) {
+    auto it = c->twiddles_ntt.find(log_n);
+    if (it != c->twiddles_ntt.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    if (log_n > 28) return ZK_EINVAL;
+    Fr* tw = nullptr;
+    const size_t n = (size_t)1 << log_n;
+    if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    launch_twiddles_internal(tw, fr_omega(log_n), (uint32_t)n, c->stream);
+    c->twiddles_ntt[log_n] = tw;
+    *out = tw;
+    return ZK_OK;
+}
+
 // columns per fixed-base launch.  Batching makes the accumulate launch bigger (fuller waves: -15 % per column
 // already at two columns of 2^19) and replaces several reduction tails by one longer one; measured best
 // (whole proofs): 2 at 2^19, growing as the columns get shorter and launch overheads dominate
@@ -265,6 +281,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
+    for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
     pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
     if (c->g) hipFree(c->g);
@@ -356,7 +373,7 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
             c->opt_msm_batch = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_NTT_MAX_RADIX_LOG2:
-            if (value && (value < 1 || value > 9)) return ZK_EINVAL;
+            if (value && (value < 1 || value > 11)) return ZK_EINVAL;  // clamped to the tile size in ntt_run
             c->opt_ntt_max_r = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_GP_BATCH_INVERT:
@@ -434,13 +451,13 @@ ZK_API(zk_ntt_bn254_fr, (zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32
     Fr* own_tw = nullptr;
     uint32_t inverse = 0;
     if (w == std_w) {
-        rc = ctx_get_twiddles(c, log_n, &tw);
+        rc = ctx_get_twiddles_ntt(c, log_n, &tw);
     } else if (fe_mul(w, std_w) == Fr::one()) {
-        rc = ctx_get_twiddles(c, log_n, &tw);
+        rc = ctx_get_twiddles_ntt(c, log_n, &tw);
         inverse = 1;
     } else {
         if (hipMalloc(&own_tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
-        launch_twiddles(own_tw, w, (uint32_t)n, c->stream);
+        launch_twiddles_internal(own_tw, w, (uint32_t)n, c->stream);
         tw = own_tw;
     }
     if (rc) return rc;
@@ -787,7 +804,7 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
     int rc = ctx_ensure_scratch(c, N * batch);
     if (rc) return rc;
     const Fr* tw;
-    if ((rc = ctx_get_twiddles(c, log_n, &tw)) != ZK_OK) return rc;
+    if ((rc = ctx_get_twiddles_ntt(c, log_n, &tw)) != ZK_OK) return rc;
     NttJob job;
     memset(&job, 0, sizeof(job));
     job.batch = batch;

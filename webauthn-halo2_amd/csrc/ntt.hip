@@ -1,4 +1,4 @@
-// ntt.hip — radix-2^b Stockham NTT over BN254 Fr for gfx950.
+// ntt.hip — Stockham NTT over BN254 Fr for gfx950: register radix-4 butterflies on the carry-free field.
 //
 // Device replacement for halo2_proofs `arithmetic::best_fft` and the
 // `EvaluationDomain::{lagrange_to_coeff, coeff_to_extended, extended_to_coeff}`
@@ -6,45 +6,155 @@
 // halo2-circuits/src/ecc/ecdsa_p256.rs:366-373,416-423).  Natural order in,
 // natural order out: out[i] = sum_j in[j] * w^(i*j).
 //
-// One launch = one Stockham pass of radix R = 2^log_r.  A 256-thread workgroup
-// owns T consecutive butterflies-groups j, stages the R x T tile in LDS
-// (R*T = 512 elements = 16 KiB, so ~8 workgroups share a CU and hide each other's load latency;
-// 2048-element tiles measured 24 % slower), applies the inter-pass twiddle on load, runs
-// log_r DIF stages entirely in LDS, and writes the tile out in autosort order.
-// Global traffic per pass is one read + one write of the vector; coset scaling
-// (zeta^i pre-multiply, zero-extension) is fused into the first pass's load and
-// 1/N, coset un-scaling and truncation into the last pass's store.
-#include "field.hip.h"
+// One launch = one Stockham pass of radix R = 2^log_r.  A 128-thread workgroup owns T consecutive
+// butterfly groups j and the R x T tile (512 elements) lives in LDS.  What makes a pass cheap — the
+// passes are bound by instruction issue, not by HBM — is that everything between the
+// global load and the global store happens on the carry-free 9 x 29-bit form of field29.hip.h:
+//   * a butterfly is ONE product (258 instructions) plus limb-wise add / subtract (9 instructions each,
+//     no reduction): decimation in TIME, (u, v) -> (u + w v, u - w v), so that both outputs are sums of a
+//     lazily bounded value and a fresh product (< 2p) and the bound grows by +3 per stage instead of doubling;
+//   * two stages at a time run in registers (radix 4: four elements per lane, three twiddles), so a radix-2^7
+//     pass makes four LDS round trips (4 + 4 + 4 + 2-point rounds) instead of seven; limbs are
+//     re-normalised (carry propagation, no reduction) once per round, when they are written back;
+//   * values are only reduced where they leave the pass: to "< 2^256" (a multiple of p subtracted by one
+//     small multiply-add pass) between passes, to the canonical standard form with the one product that
+//     also applies 1/N and the coset un-scaling on the last pass.
+// Field forms: the engine's memory image is the Rust one (x * 2^256 mod p, canonical); inside a transform
+// values are x * 2^261 mod p ("internal", field29.hip.h): the first pass converts on load (for free: the
+// limbs of 32 x, or with the coset pre-scaling product, whose constant carries the factor), intermediate
+// buffers hold internal values < 2^256 in eight words, the twiddle table handed to this file is in internal
+// canonical form (w^i * 2^261), and the last pass's final product divides by 32 again.
+// Global traffic per pass is one read + one write of the vector; coset scaling (zeta^i pre-multiply,
+// zero-extension) is fused into the first pass's load and 1/N, coset un-scaling and truncation into the last
+// pass's store.  blockIdx.y = vector: the coefficient / coset forms of a whole column batch take one launch per pass.
 #include <stdlib.h>
 #include <string.h>
 
 #include "engine.h"
+#include "field29.hip.h"
 
 namespace zk {
 
-static constexpr int NTT_TILE_LOG = 9;   // 512 elements x 32 B = 16 KiB LDS: many workgroups per CU hide the load latency
-static constexpr int NTT_THREADS = 256;
+#ifndef ZK_NTT_TILE_LOG  // build-time tuning knobs (tools/ab_variants.sh)
+#define ZK_NTT_TILE_LOG 9
+#endif
+#ifndef ZK_NTT_MINW
+#define ZK_NTT_MINW 1
+#endif
+#ifndef ZK_NTT_PAD
+#define ZK_NTT_PAD 1
+#endif
+static constexpr int NTT_TILE_LOG = ZK_NTT_TILE_LOG;      // 512 elements x 36 B = 18 KiB of LDS: ~7 workgroups share a CU
+static constexpr int NTT_THREADS = 1 << (NTT_TILE_LOG - 2);  // one radix-4 butterfly group per lane and round
+typedef Fe29<FrParams> Fr29;
 
 struct NttPassArgs {
     const Fr* in[NTT_MAX_BATCH];   // one vector per blockIdx.y
     Fr* out[NTT_MAX_BATCH];
-    const Fr* tw;        // w_N^i for i in [0, N)
+    const Fr* tw;        // w_N^i * 2^261 mod p (canonical words), i in [0, N)
     uint32_t log_n;
     uint32_t log_r;      // this pass's radix
-    uint32_t log_ns;     // product of radices of earlier passes
+    uint32_t log_ns;     // product of radices of earlier passes (0: first pass, input in standard form)
     uint32_t log_t;      // j's per workgroup
     uint32_t inverse;    // use w^-1 (index N - e)
+    uint32_t last;       // last pass: output in canonical standard form
     uint32_t n_in;       // elements >= n_in read as zero (first pass only; else N)
     uint32_t n_out;      // elements >= n_out are not stored (last pass only; else N)
     uint32_t has_pre;    // multiply in[i] by pre[i % 3] on load (first pass)
     uint32_t has_post;   // multiply out[i] by post[i % 3] on store (last pass)
-    Fr pre[3];
-    Fr post[3];
+    Fr pre[3];           // pre-scale factors * 2^266 (plain words): product with a standard-form input is internal
+    Fr post[3];          // post-scale factors in standard Montgomery form: product with an internal value is standard
 };
 
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Fr* s = reinterpret_cast<Fr*>(smem_raw);
+// ---- 9 x 29-bit element <-> LDS.  Tile elements are stored limb-major ("SoA": word = limb * tile + slot) with the slot
+// index swizzled (bits 4-5 ^= bits 6-7) so that the access patterns of all rounds — lanes walk consecutive slots in runs
+// of 4 .. 64, the runs 64 slots or more apart — spread over the 64 banks; the in-tile twiddles are 9 consecutive words.
+#ifndef ZK_NTT_SOA
+#define ZK_NTT_SOA 0
+#endif
+__device__ __forceinline__ uint32_t swz(uint32_t i) { return i ^ (((i >> 6) & 3u) << 4); }
+__device__ __forceinline__ Fr29 tile_load(const uint32_t* lds, uint32_t tile, uint32_t row, uint32_t p, uint32_t t, uint32_t log_t) {
+    Fr29 r;
+#if ZK_NTT_SOA
+    const uint32_t* q = lds + swz((p << log_t) | t);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = q[i * tile];
+#else
+    const uint32_t* q = lds + p * row + t * 9;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = q[i];
+#endif
+    return r;
+}
+__device__ __forceinline__ void tile_store(uint32_t* lds, uint32_t tile, uint32_t row, uint32_t p, uint32_t t, uint32_t log_t, const Fr29& a) {
+#if ZK_NTT_SOA
+    uint32_t* q = lds + swz((p << log_t) | t);
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i * tile] = a.l[i];
+#else
+    uint32_t* q = lds + p * row + t * 9;
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = a.l[i];
+#endif
+}
+__device__ __forceinline__ Fr29 lds_load29(const uint32_t* p) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ void lds_store29(uint32_t* p, const Fr29& a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) p[i] = a.l[i];
+}
+
+// a normalised (limbs < 2^29, top limb free), value < 160 p  ->  the same residue as an integer < 2^256:
+// with t = floor(a / 2^254) subtract m p, m = floor(1.3125 t) (p / 2^254 = 0.7561, so 0 <= a - m p < 2.7 * 2^254)
+__device__ __forceinline__ Fr29 reduce_below_2_256(const Fr29& a) {
+    const uint32_t t = a.l[8] >> 22;
+    const uint32_t m = (t * 84u) >> 6;
+    Fr29 r;
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        acc += (int64_t)a.l[i] - (int64_t)((uint64_t)m * Lim29<FrParams>::P[i]);
+        r.l[i] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    acc += (int64_t)a.l[8] - (int64_t)((uint64_t)m * Lim29<FrParams>::P[8]);
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+// decimation-in-time butterflies.  Bounds (value as a multiple of p ; limb bits), "fresh" = product output (< 2p ; 29):
+//   bfly_mul    t = v w fresh;  u' = u + t (k_u + 2),  v' = u - t + 3p (k_u + 3)
+//   bfly_plain  trivial twiddle, v bounded by KV:  u' = u + v,  v' = u - v + (KV + 1) p
+template <int E = 29>
+__device__ __forceinline__ void bfly_mul(Fr29& u, Fr29& v, const Fr29& w) {
+    const Fr29 t = mul29(v, w);
+    v = sub29<3, 29>(u, t);
+    u = add29(u, t);
+}
+template <uint32_t K, int E>
+__device__ __forceinline__ void bfly_plain(Fr29& u, Fr29& v) {
+    const Fr29 t = v;
+    v = sub29<K, E>(u, t);
+    u = add29(u, t);
+}
+
+// first two stages (half = 1, 2) of an R-point DIT transform: the only non-trivial twiddle is the 4th root of unity.
+// KIN bounds the loaded values (first pass: limbs of 32 x -> 32 p;  later passes: < 2^256 -> 5.3 p).
+template <uint32_t KIN>
+__device__ __forceinline__ void round0(Fr29& e0, Fr29& e1, Fr29& e2, Fr29& e3, const Fr29& w4) {
+    bfly_plain<KIN + 1, 29>(e0, e1);          // e0 <= 2 KIN (limbs < 2^30), e1 <= 2 KIN + 1
+    bfly_plain<KIN + 1, 29>(e2, e3);
+    bfly_plain<2 * KIN + 1, 30>(e0, e2);      // sums of sums: limbs < 2^30 -> spread with E = 30;  <= 4 KIN + 1
+    bfly_mul(e1, e3, w4);                     // <= 2 KIN + 4
+}
+
+template <uint32_t KIN>
+__global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(const NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Fr* __restrict__ vin = a.in[blockIdx.y];
     Fr* __restrict__ vout = a.out[blockIdx.y];
 
@@ -57,59 +167,130 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
     const uint32_t col_stride = N >> a.log_r;               // N / R
     const uint32_t tw_shift = a.log_n - a.log_ns - a.log_r;  // N / (Ns * R)
     const uint32_t nmask = N - 1;
+    const uint32_t row = T * 9 + ZK_NTT_PAD;                 // words per position p (padded)
+    uint32_t* wr = lds + (ZK_NTT_SOA ? 9 * tile : R * row);  // R / 2 in-tile twiddles w_R^j, 9 words each
+    const uint32_t brev_shift = 32 - a.log_r;
 
-    // ---- the R/2 twiddles of the in-tile stages (w_R^j = w_N^(j N/R)) go to LDS once per workgroup
-    Fr* wr = s + tile;
+    // ---- the R/2 twiddles of the in-tile stages (w_R^j = w_N^(j N/R), internal form) go to LDS once per workgroup
     for (uint32_t j = threadIdx.x; j < (R >> 1); j += NTT_THREADS) {
         const uint32_t ex = j << (a.log_n - a.log_r);
-        wr[j] = fe_load(a.tw + (a.inverse ? ((N - ex) & nmask) : ex));
+        lds_store29(wr + j * 9, to29(fe_load(a.tw + (a.inverse ? ((N - ex) & nmask) : ex))));
     }
 
-    // ---- load: s[r*T + t] = in[j + r*N/R] * pre * w_{Ns*R}^{r*(j mod Ns)}
-    for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
-        const uint32_t t = e & (T - 1), r = e >> a.log_t;
-        const uint32_t j = j0 + t;
-        const uint32_t idx = j + r * col_stride;
-        Fr x;
+    // ---- load: position brev(r) of column t  <-  in[j + r N/R] * pre * w_{Ns R}^{r (j mod Ns)}   (internal form)
+    auto src_index = [&](uint32_t e, uint32_t& t, uint32_t& r) {
+        t = e & (T - 1);
+        r = e >> a.log_t;
+        return j0 + t + r * col_stride;
+    };
+    auto tw_index = [&](uint32_t t, uint32_t r) {
+        const uint32_t ex = (r * ((j0 + t) & ns_mask)) << tw_shift;
+        return a.inverse ? ((N - ex) & nmask) : ex;  // 0 <=> trivial twiddle
+    };
+    auto place = [&](uint32_t t, uint32_t r, uint32_t idx, const Fr& v, const Fr& w, uint32_t ti) {
+        Fr29 x;
         if (idx < a.n_in) {
-            x = fe_load(vin + idx);
-            if (a.has_pre) {
-                const uint32_t m = idx % 3;
-                if (m) x = fe_mul(x, a.pre[m]);
-            }
-            const uint32_t ex = (r * (j & ns_mask)) << tw_shift;
-            if (ex) {
-                const uint32_t ti = a.inverse ? ((N - ex) & nmask) : ex;
-                x = fe_mul(x, fe_load(a.tw + ti));
+            if (a.log_ns == 0) {
+                // first pass: standard form in.  32 v is a valid internal form (bound 32 p); the coset factor's
+                // constant carries 2^266 so that the product lands in internal form
+                const uint32_t m = a.has_pre ? idx % 3 : 0;
+                x = m ? mul29(to29(v), to29(a.pre[m])) : to29_x32(v);
+            } else {
+                x = to29(v);  // internal value < 2^256
+                if (ti) x = mul29(x, to29(w));
             }
         } else {
-            x = Fr::zero();
+#pragma unroll
+            for (int i = 0; i < 9; i++) x.l[i] = 0;
         }
-        s[e] = x;
+        const uint32_t pos = a.log_r ? (__brev(r) >> brev_shift) : 0;
+        tile_store(lds, tile, row, pos, t, a.log_t, x);
+    };
+    constexpr uint32_t EPT = (1u << NTT_TILE_LOG) / NTT_THREADS;  // elements per lane of a full tile
+    if (tile == (1u << NTT_TILE_LOG)) {
+        // full tile: the lane's loads (data and inter-pass twiddles) are all issued before the first product
+        Fr v[EPT], w[EPT];
+        uint32_t tt[EPT], rr[EPT], ii[EPT], ti[EPT];
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; k++) {
+            ii[k] = src_index(threadIdx.x + k * NTT_THREADS, tt[k], rr[k]);
+            ti[k] = a.log_ns ? tw_index(tt[k], rr[k]) : 0;
+            v[k] = ii[k] < a.n_in ? fe_load(vin + ii[k]) : Fr::zero();
+            w[k] = ti[k] ? fe_load(a.tw + ti[k]) : Fr::zero();
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; k++) place(tt[k], rr[k], ii[k], v[k], w[k], ti[k]);
+    } else {
+        for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+            uint32_t t, r;
+            const uint32_t idx = src_index(e, t, r);
+            const uint32_t ti = a.log_ns ? tw_index(t, r) : 0;
+            const Fr v = idx < a.n_in ? fe_load(vin + idx) : Fr::zero();
+            const Fr w = ti ? fe_load(a.tw + ti) : Fr::zero();
+            place(t, r, idx, v, w, ti);
+        }
     }
     __syncthreads();
 
-    // ---- log_r DIF stages over the r dimension (natural in, bit-reversed out)
-    const uint32_t nbf = tile >> 1;
-    for (int st = (int)a.log_r - 1; st >= 0; st--) {
-        const uint32_t half = 1u << st;
-        for (uint32_t b = threadIdx.x; b < nbf; b += NTT_THREADS) {
-            const uint32_t t = b & (T - 1), p = b >> a.log_t;
-            const uint32_t lo = p & (half - 1);
-            const uint32_t i = ((p >> st) << (st + 1)) | lo;
-            Fr* pu = s + i * T + t;
-            Fr* pv = pu + half * T;
-            const Fr u = *pu, v = *pv;
-            *pu = fe_add(u, v);
-            Fr d = fe_sub(u, v);
-            if (lo) d = fe_mul(d, wr[lo << (a.log_r - st - 1)]);  // w_R^(lo * R/(2*half))
-            *pv = d;
+    // ---- log_r DIT stages over the position index, two per round in registers
+    uint32_t s = 0;
+    if (a.log_r >= 2) {
+        // stages 0 and 1: groups of four adjacent positions
+        const Fr29 w4 = lds_load29(wr + (R >> 2) * 9);  // w_R^(R/4)
+        for (uint32_t q = threadIdx.x; q < (tile >> 2); q += NTT_THREADS) {
+            const uint32_t t = q & (T - 1), g = q >> a.log_t;
+            const uint32_t b = g << 2;
+            Fr29 e0 = tile_load(lds, tile, row, b, t, a.log_t), e1 = tile_load(lds, tile, row, b + 1, t, a.log_t),
+                 e2 = tile_load(lds, tile, row, b + 2, t, a.log_t), e3 = tile_load(lds, tile, row, b + 3, t, a.log_t);
+            round0<KIN>(e0, e1, e2, e3, w4);
+            tile_store(lds, tile, row, b, t, a.log_t, norm29(e0));
+            tile_store(lds, tile, row, b + 1, t, a.log_t, norm29(e1));
+            tile_store(lds, tile, row, b + 2, t, a.log_t, norm29(e2));
+            tile_store(lds, tile, row, b + 3, t, a.log_t, norm29(e3));
+        }
+        __syncthreads();
+        s = 2;
+    }
+    for (; s + 1 < a.log_r; s += 2) {
+        const uint32_t h = 1u << s;
+        for (uint32_t q = threadIdx.x; q < (tile >> 2); q += NTT_THREADS) {
+            const uint32_t t = q & (T - 1), g = q >> a.log_t;
+            const uint32_t lo = g & (h - 1);
+            const uint32_t base = ((g >> s) << (s + 2)) | lo;
+            Fr29 e0 = tile_load(lds, tile, row, base, t, a.log_t), e1 = tile_load(lds, tile, row, base + h, t, a.log_t),
+                 e2 = tile_load(lds, tile, row, base + 2 * h, t, a.log_t), e3 = tile_load(lds, tile, row, base + 3 * h, t, a.log_t);
+            {
+                const Fr29 w1 = lds_load29(wr + (lo << (a.log_r - s - 1)) * 9);   // w_{2h}^lo
+                bfly_mul(e0, e1, w1);
+                bfly_mul(e2, e3, w1);
+            }
+            bfly_mul(e0, e2, lds_load29(wr + (lo << (a.log_r - s - 2)) * 9));        // w_{4h}^lo
+            bfly_mul(e1, e3, lds_load29(wr + ((lo + h) << (a.log_r - s - 2)) * 9));  // w_{4h}^(lo + h)
+            tile_store(lds, tile, row, base, t, a.log_t, norm29(e0));
+            tile_store(lds, tile, row, base + h, t, a.log_t, norm29(e1));
+            tile_store(lds, tile, row, base + 2 * h, t, a.log_t, norm29(e2));
+            tile_store(lds, tile, row, base + 3 * h, t, a.log_t, norm29(e3));
+        }
+        __syncthreads();
+    }
+    if (s < a.log_r) {  // one stage left (odd log_r, or log_r == 1): half = R / 2
+        const uint32_t h = R >> 1;
+        for (uint32_t q = threadIdx.x; q < (tile >> 1); q += NTT_THREADS) {
+            const uint32_t t = q & (T - 1), lo = q >> a.log_t;
+            Fr29 e0 = tile_load(lds, tile, row, lo, t, a.log_t), e1 = tile_load(lds, tile, row, lo + h, t, a.log_t);
+            if (a.log_r == 1) {
+                bfly_plain<KIN + 1, 29>(e0, e1);
+            } else {
+                bfly_mul(e0, e1, lds_load29(wr + lo * 9));  // w_R^lo
+            }
+            tile_store(lds, tile, row, lo, t, a.log_t, norm29(e0));
+            tile_store(lds, tile, row, lo + h, t, a.log_t, norm29(e1));
         }
         __syncthreads();
     }
 
-    // ---- store: out[(j / Ns) * Ns * R + (j mod Ns) + r * Ns] = X_r
-    const uint32_t brev_shift = 32 - a.log_r;
+    // ---- store: out[(j / Ns) Ns R + (j mod Ns) + r Ns] = X_r
+    const Fr29 one_std = const_pow2_29<256, FrParams>();  // internal -> standard: times 2^256 * 2^-261
     for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
         uint32_t t, r;
         if (a.log_ns == 0) {  // dst = j*R + r : contiguous over r
@@ -122,21 +303,27 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
         const uint32_t j = j0 + t;
         const uint32_t dst = ((j >> a.log_ns) << (a.log_ns + a.log_r)) + (j & ns_mask) + (r << a.log_ns);
         if (dst < a.n_out) {
-            const uint32_t rb = a.log_r ? (__brev(r) >> brev_shift) : 0;
-            Fr x = s[rb * T + t];
-            if (a.has_post) x = fe_mul(x, a.post[dst % 3]);
-            fe_store(vout + dst, x);
+            const Fr29 x = tile_load(lds, tile, row, r, t, a.log_t);
+            Fr o;
+            if (a.last) {
+                o = from29(mul29(x, a.has_post ? to29(a.post[dst % 3]) : one_std));
+                reduce_once(o);
+            } else {
+                o = from29(reduce_below_2_256(x));
+            }
+            fe_store(vout + dst, o);
         }
     }
 }
 
 // Twiddle table: tw[i] = w^i, i in [0, N).  Each thread seeds w^(i0) by
-// square-and-multiply, then walks 64 consecutive powers.
-__global__ void ntt_twiddle_kernel(Fr* tw, Fr w, uint32_t n) {
+// square-and-multiply, then walks 64 consecutive powers.  `scale` multiplies every entry (standard form): the
+// NTT's own table is made with scale = 32, i.e. w^i * 2^261 as plain words.
+__global__ void ntt_twiddle_kernel(Fr* tw, Fr w, Fr scale, uint32_t n) {
     const uint32_t CH = 64;
     const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * CH;
     if (i0 >= n) return;
-    Fr cur = Fr::one();
+    Fr cur = scale;
     Fr base = w;
     for (uint32_t e = i0; e; e >>= 1) {
         if (e & 1) cur = fe_mul(cur, base);
@@ -150,7 +337,18 @@ __global__ void ntt_twiddle_kernel(Fr* tw, Fr w, uint32_t n) {
 
 void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st) {
     const uint32_t threads = (n + 63) / 64;
-    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, tw, w, n);
+    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, tw, w, Fr::one(), n);
+}
+
+static Fr fr_small_mont(uint32_t x) {
+    Fr a = Fr::zero();
+    a.v[0] = x;
+    return fe_to_mont(a);
+}
+
+void launch_twiddles_internal(Fr* tw, const Fr& w, uint32_t n, hipStream_t st) {
+    const uint32_t threads = (n + 63) / 64;
+    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, tw, w, fr_small_mont(32), n);
 }
 
 // Plan the passes of a 2^log_n transform: radices as even as possible, each <= max_log_r.
@@ -180,7 +378,9 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         dsts[b] = job.batch ? job.dsts[b] : job.dst;
     }
     uint32_t bits[8];
-    const int np = ntt_plan(log_n, job.max_log_r ? job.max_log_r : 7, bits);
+    uint32_t max_r = job.max_log_r ? job.max_log_r : 7;
+    if (max_r > (uint32_t)NTT_TILE_LOG) max_r = NTT_TILE_LOG;
+    const int np = ntt_plan(log_n, max_r, bits);
     if (np == 0) {  // N == 1
         for (uint32_t b = 0; b < batch; b++)
             if (dsts[b] != srcs[b]) {
@@ -205,6 +405,10 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
             cur_in[b] = job.tmp + (size_t)b * N;
         }
     }
+    // pre-scale constants with the 2^266 that turns (standard input) x (constant) into internal form:
+    // c * 2^256 (Montgomery image) times 2^10
+    Fr pre266[3];
+    for (int i = 0; i < 3; i++) pre266[i] = job.has_pre ? fe_mul(job.pre[i], fr_small_mont(1024)) : Fr::zero();
     int which = (np & 1) ? 0 : 1;  // 0: dst, 1: tmp
     uint32_t log_ns = 0;
     for (int p = 0; p < np; p++) {
@@ -222,17 +426,22 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         if (log_t > log_n - a.log_r) log_t = log_n - a.log_r;
         a.log_t = log_t;
         a.inverse = job.inverse;
+        a.last = p == np - 1;
         a.n_in = (p == 0) ? job.n_in : N;
         a.n_out = (p == np - 1) ? job.n_out : N;
         a.has_pre = (p == 0) ? job.has_pre : 0;
         a.has_post = (p == np - 1) ? job.has_post : 0;
         for (int i = 0; i < 3; i++) {
-            a.pre[i] = job.pre[i];
+            a.pre[i] = pre266[i];
             a.post[i] = job.post[i];
         }
         const uint32_t blocks = N >> (a.log_r + a.log_t);
-        const size_t lds = ((size_t)sizeof(Fr) << (a.log_r + a.log_t)) + (sizeof(Fr) << a.log_r) / 2;
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        const size_t lds = (ZK_NTT_SOA ? ((size_t)36 << (a.log_t + a.log_r)) : (((size_t)9 << a.log_t) + ZK_NTT_PAD) * ((size_t)4 << a.log_r)) +
+                           ((size_t)36 << a.log_r) / 2;
+        if (p == 0)
+            hipLaunchKernelGGL(ntt_pass_kernel<32>, dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        else
+            hipLaunchKernelGGL(ntt_pass_kernel<6>, dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
         for (uint32_t b = 0; b < batch; b++) cur_in[b] = a.out[b];
         which ^= 1;
         log_ns += bits[p];
