@@ -189,6 +189,20 @@ int zk_pk_write(zk_ctx* ctx, zk_pk pk, int format, uint8_t* out, size_t cap, siz
  * tells halo2), transcript_repr from the caller (NULL: the stand-in).  Needs the SRS of params->k. */
 int zk_pk_read(zk_ctx* ctx, const zk_circuit_params* params, const uint8_t* bytes, size_t len, int format,
                const uint64_t transcript_repr_mont[4], zk_pk* out);
+/* the column shape of a key, for a host that drives the phases itself:
+ * out = {k, extended k, #advice columns, #fixed columns, #permutation columns, #permutation chunks, #lookups, #h pieces} */
+int zk_pk_shape(zk_ctx* ctx, zk_pk pk, uint32_t out[8]);
+/* replaces plonk::evaluation::Evaluator::evaluate_h — and, with divide != 0, the EvaluationDomain::divide_by_vanishing_poly
+ * that follows it in create_proof — for a Rust host that keeps halo2's own prover flow and off-loads phase by phase (the
+ * [patch] route of INTEGRATION.md).  Every operand is a resident vector over the extended coset (2^(k+2) elements, as
+ * zk_coeff_to_extended makes them): the advice columns, the permutation grand products z (one per chunk), and per lookup
+ * the triple (permuted input a', permuted table s', product zL) — lookup_ext holds 3 * n_lookups handles in that order.
+ * The fixed / sigma / l_0 / l_last / l_active cosets are the key's own.  beta, gamma, y: Montgomery images (theta does not
+ * enter: every lookup of this circuit family is a single expression).  out_ext receives h on the extended coset
+ * (zk_extended_to_coeff then gives the h pieces); it must not alias an input. */
+int zk_quotient(zk_ctx* ctx, zk_pk pk, const zk_poly* advice_ext, size_t n_advice, const zk_poly* perm_z_ext, size_t n_chunks,
+                const zk_poly* lookup_ext, size_t n_lookups, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4],
+                int divide, zk_poly out_ext);
 /* bytes zk_prove will write for this key / transcript / scheme (what `transcript.finalize().len()` is in
  * the reference, e.g. 960 at k=19 Blake2b, halo2-circuits/src/results/ecdsa_bench.csv:2) */
 int zk_proof_size(zk_ctx* ctx, zk_pk pk, int transcript, int scheme, size_t* out);

@@ -341,3 +341,59 @@ def test_concurrent_pipelines_are_deterministic():
     for o in outs:
         assert len(o) == 12
         assert all(o[i] == ref[i % 2] for i in range(12))
+
+
+@pytest.mark.parametrize("name", ["k19like", "k17like", "idle"])
+def test_quotient_entry_point_matches_oracle_h(engine, name):
+    """zk_quotient (Evaluator::evaluate_h + divide_by_vanishing_poly for a host that drives the phases itself): fed the
+    oracle prover's own intermediate columns (blinded advice, permutation products, permuted lookup columns — its `trace`)
+    and challenges, the device quotient's coefficients equal the oracle's h(X), and the undivided numerator equals
+    h(X) (X^n - 1) on the coset."""
+    from zkoracle import field as F
+    shp = SHAPES[name]
+    A, L, Fx, k, lb = shp[:5]
+    idle = shp[5] if len(shp) > 5 else 0
+    p, asg, pk, polys = setup(engine, A, L, Fx, k, lb, idle=idle)
+    sh = plonk.Shape(k, A, L, Fx, lb, idle)
+    opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
+    tr = {}
+    prover.create_proof(opk, asg.advice, ChaCha20Rng(b"\x09" * 32), "evm", trace=tr)
+    n, N = sh.n, 4 * sh.n
+    shape = engine.pk_shape(pk)
+    assert (shape["k"], shape["ext_k"], shape["n_advice"], shape["n_chunks"], shape["n_lookups"], shape["n_h"]) == \
+           (k, k + 2, sh.n_adv, sh.n_chunks, sh.n_lookups, sh.n_h)
+
+    def ext_of(values):
+        v = engine.poly(n, cops.fr_mont(values))
+        engine.lagrange_to_coeff(v)
+        e = engine.poly(N)
+        engine.coeff_to_extended(v, e)
+        v.free()
+        return e
+
+    adv = [ext_of(c) for c in tr["adv"]]
+    zs = [ext_of(z) for z in tr["zs"]]
+    lks = [(ext_of(d["ap"]), ext_of(d["sp"]), ext_of(d["z"])) for d in tr["lk"]]
+    out = engine.poly(N)
+    ch = [cops.fr_mont([tr[c]])[0] for c in ("beta", "gamma", "y")]
+    engine.quotient(pk, adv, zs, lks, *ch, out)
+    engine.extended_to_coeff(out, N)
+    assert cops.fr_ints(engine.download(out)) == tr["h_coeff"]
+    # the bare numerator (divide = 0): h(X) * (X^n - 1) on the coset
+    engine.quotient(pk, adv, zs, lks, *ch, out, divide=False)
+    num = cops.fr_ints(engine.download(out, 8))
+    hx = engine.poly(N, cops.fr_mont(tr["h_coeff"]))
+    he = engine.poly(N)
+    engine.coeff_to_extended(hx, he)
+    hvals = cops.fr_ints(engine.download(he, 8))
+    wext = F.omega(k + 2)
+    for i in range(8):
+        x = F.ZETA * pow(wext, i, F.R) % F.R
+        assert num[i] == hvals[i] * (pow(x, n, F.R) - 1) % F.R
+    with pytest.raises(zk.ZkError):
+        engine.quotient(pk, adv[:-1] if len(adv) > 1 else [], zs, lks, *ch, out)   # wrong operand count
+    with pytest.raises(zk.ZkError):
+        engine.quotient(pk, adv, zs, lks, *ch, adv[0])                               # output aliases an input
+    for h in adv + zs + [x for t in lks for x in t] + [out, hx, he] + polys:
+        h.free()
+    engine.pk_free(pk)

@@ -25,6 +25,7 @@ struct zk_ctx {
     int last_hip = 0;
     std::mutex mu;
     std::map<uint32_t, Fr*> twiddles;      // log_n -> w_{2^log_n}^i table (standard form: quotient, permutation kernels)
+    std::map<uint32_t, Fr*> coset_points;  // zeta * w^i (standard form): the x of the quotient's permutation terms
     std::map<uint32_t, Fr*> twiddles_ntt;  // the same powers in the NTT's internal form (x 2^261, ntt.hip)
     // SRS
     int srs_k = -1;
@@ -106,6 +107,7 @@ int ctx_bind(zk_ctx* c);
 int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);
 int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out);
+int ctx_get_coset_points(zk_ctx* c, uint32_t log_n, const Fr** out);  // zeta * w^i: the points of the extended coset
 // MSM of device-resident scalars against device-resident bases -> Jacobian on host (synchronises)
 int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out);
 // split form: begin enqueues the MSM on lane `lane` (head on the context stream, tail on the

@@ -84,6 +84,31 @@ int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out) {
     return ZK_OK;
 }
 
+namespace zk {
+void launch_scale(Fr* a, const Fr& c, uint32_t n, hipStream_t st);
+}
+int ctx_get_coset_points(zk_ctx* c, uint32_t log_n, const Fr** out) {
+    auto it = c->coset_points.find(log_n);
+    if (it != c->coset_points.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    const Fr* tw = nullptr;
+    int rc = ctx_get_twiddles(c, log_n, &tw);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log_n;
+    Fr* xs = nullptr;
+    if (hipMalloc(&xs, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    if (hipMemcpyAsync(xs, tw, n * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+        hipFree(xs);
+        return ZK_EHIP;
+    }
+    launch_scale(xs, c->zeta, (uint32_t)n, c->stream);
+    c->coset_points[log_n] = xs;
+    *out = xs;
+    return ZK_OK;
+}
+
 // columns per fixed-base launch.  Batching makes the accumulate launch bigger (fuller waves: -15 % per column
 // already at two columns of 2^19) and replaces several reduction tails by one longer one; measured best
 // (whole proofs): 2 at 2^19, growing as the columns get shorter and launch overheads dominate
@@ -282,6 +307,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
+    for (auto& kv : c->coset_points) hipFree(kv.second);
     pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
     if (c->g) hipFree(c->g);

@@ -242,7 +242,11 @@ __global__ __launch_bounds__(256) void msm_recode_hist_kernel(MsmBatch batch, ui
     }
 }
 
-__global__ __launch_bounds__(256) void msm_scatter_fixed_kernel(const int16_t* __restrict__ digits_all, uint32_t n, uint32_t stride,
+#ifndef ZK_SCAT_T
+#define ZK_SCAT_T 256
+#endif
+static constexpr uint32_t SCAT_T = ZK_SCAT_T;  // lanes of a scatter workgroup (FCHUNK / SCAT_T scalars per lane)
+__global__ __launch_bounds__(SCAT_T) void msm_scatter_fixed_kernel(const int16_t* __restrict__ digits_all, uint32_t n, uint32_t stride,
                                                                 uint32_t nwin, uint32_t nb, uint32_t table_stride,
                                                                 const uint32_t* __restrict__ totals_all,
                                                                 const uint32_t* __restrict__ bucket_start_all,
@@ -256,21 +260,21 @@ __global__ __launch_bounds__(256) void msm_scatter_fixed_kernel(const int16_t* _
     const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
     const uint32_t* __restrict__ bucket_start = bucket_start_all + (size_t)col * nb;
     const uint32_t* __restrict__ blockbase = blockbase_all + (size_t)col * gridDim.x * nb;
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) lds[b] = bucket_start[b] + blockbase[(size_t)blockIdx.x * nb + b];
+    for (uint32_t b = threadIdx.x; b < nb; b += SCAT_T) lds[b] = bucket_start[b] + blockbase[(size_t)blockIdx.x * nb + b];
     // this workgroup's share of the bucket padding (skip markers up to the next multiple of PAD)
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
+    for (uint32_t b = blockIdx.x * SCAT_T + threadIdx.x; b < nb; b += gridDim.x * SCAT_T) {
         const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
         for (uint32_t q = beg; q < end; q++) entries[q] = SKIP_ENTRY;
     }
     __syncthreads();
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    constexpr uint32_t PER = FCHUNK / 256;  // scalars per thread
+    constexpr uint32_t PER = FCHUNK / SCAT_T;  // scalars per thread
     // the digits of window w + 1 are loaded while those of window w are scattered (the loop is otherwise a
     // chain of load -> LDS atomic -> store latencies at two waves per SIMD)
     int32_t cur[PER], nxt[PER];
 #pragma unroll
     for (uint32_t q = 0; q < PER; q++) {
-        const uint32_t i = lo + threadIdx.x + q * 256;
+        const uint32_t i = lo + threadIdx.x + q * SCAT_T;
         cur[q] = i < hi ? digits[i] : 0;
     }
     for (uint32_t w = 0; w < nwin; w++) {
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void msm_scatter_fixed_kernel(const int16_t* _
             const int16_t* dg = digits + (size_t)(w + 1) * stride;
 #pragma unroll
             for (uint32_t q = 0; q < PER; q++) {
-                const uint32_t i = lo + threadIdx.x + q * 256;
+                const uint32_t i = lo + threadIdx.x + q * SCAT_T;
                 nxt[q] = i < hi ? dg[i] : 0;
             }
         }
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void msm_scatter_fixed_kernel(const int16_t* _
         for (uint32_t q = 0; q < PER; q++) {
             const int32_t d = cur[q];
             if (d == 0) continue;
-            const uint32_t i = lo + threadIdx.x + q * 256;
+            const uint32_t i = lo + threadIdx.x + q * SCAT_T;
             const uint32_t pos = atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
             entries[pos] = (w * table_stride + i) | (d < 0 ? SIGN_BIT : 0);
         }
@@ -701,7 +705,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
             // four columns of 2^19).  Short columns: one launch for all (launch-bound otherwise).
             const uint32_t per_launch = n32 >= (1u << 18) ? 1 : batch;
             for (uint32_t q = 0; q < batch; q += per_launch)
-                hipLaunchKernelGGL(msm_scatter_fixed_kernel, dim3(nblk, per_launch), dim3(256), nb * 4, st,
+                hipLaunchKernelGGL(msm_scatter_fixed_kernel, dim3(nblk, per_launch), dim3(SCAT_T), nb * 4, st,
                                    ws->digits + (size_t)q * nwin * stride, n32, stride, nwin, nb, table_stride,
                                    ws->totals + (size_t)q * nb, ws->bucket_start + (size_t)q * nb,
                                    ws->blockbase + (size_t)q * nblk * nb, ws->entries);

@@ -119,6 +119,11 @@ struct Dev {
     }
 };
 
+// extended cosets the quotient reads beside the key's own: advice columns, permutation products, per lookup a', s', zL
+struct QuotientCosets {
+    std::vector<const Fr*> adv, z, lk_a, lk_s, lk_z;
+};
+int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& beta, const Fr& gamma, const Fr& y, bool divide, Fr* out);
 void pk_destroy(zk_pk_rec* pk);
 // the per-proof workspace (advice / z / lookup forms, quotient buffer, scan and evaluation scratch): everything a key
 // needs beyond the key material itself; called at the end of zk_keygen and zk_pk_read

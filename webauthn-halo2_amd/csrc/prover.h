@@ -14,6 +14,7 @@ static constexpr uint32_t MAX_FIX = 304;
 static constexpr uint32_t MAX_PERM = 352;
 static constexpr uint32_t MAX_CHUNKS = 176;
 static constexpr uint32_t MAX_LOOKUPS = 56;
+static constexpr uint32_t MAX_TERMS = MAX_ADV + 2 * MAX_CHUNKS + 1 + 5 * MAX_LOOKUPS;  // y-combination terms of the quotient
 static_assert(MAX_CHUNKS + MAX_LOOKUPS <= 256, "gp_chain_kernel scans all grand products of a proof in one 256-lane block");
 static constexpr uint32_t NO_SELECTOR = 0xffffffffu;  // gate column whose selector was compressed to the constant 0
 static constexpr uint32_t BLINDING_FACTORS = 6;  // max(3, 4 queries per gate column) + 2
@@ -73,12 +74,17 @@ struct QuotientArgs {
     const Fr* lk_s[MAX_LOOKUPS];
     const Fr* lk_in[MAX_LOOKUPS]; // A >= 2: lookup advice coset; A == 1: unused (q_lookup * adv[0])
     const Fr *l0, *l_last, *l_active;
-    const Fr* tw_ext;             // w_ext^i
-    Fr zeta, beta, gamma, y;
-    Fr delta_pow[MAX_PERM];       // beta * delta^c  (times x on the fly)
+    const Fr* xs;                 // zeta * w_ext^i: the coset points
+    Fr beta, gamma, delta;
     Fr t_inv[4];                  // 1 / ((zeta w_ext^i)^n - 1), period 4
+    uint32_t divide, n_terms;     // divide: multiply by t_inv (divide_by_vanishing_poly); 0: the bare numerator of evaluate_h
     Fr* out;
+    Fr ypow[MAX_TERMS];           // y^(T-1-j) for term j of the y-combination, T = n_terms
 };
+// terms of the y-combination: gates, 2 + (chunks - 1) + chunks permutation terms, 5 per lookup
+static constexpr uint32_t quotient_terms(uint32_t n_gate, uint32_t n_chunks, uint32_t n_lookups) {
+    return n_gate + 2 + (n_chunks - 1) + n_chunks + 5 * n_lookups;
+}
 
 void launch_to_mont(Fr* a, uint32_t n, hipStream_t st);
 void launch_mul(Fr* out, const Fr* a, const Fr* b, uint32_t n, hipStream_t st);

@@ -407,6 +407,127 @@ ZK_API(zk_vk_export, (zk_ctx* c, zk_pk h, uint64_t* fixed_commitments, uint64_t*
     return ZK_OK;
 }
 
+// Evaluator::evaluate_h (+ divide_by_vanishing_poly when `divide`) over resident extended cosets: the key's fixed /
+// sigma / l_* cosets and the caller's advice, permutation-product and lookup cosets.  Enqueued on the context stream.
+int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& beta, const Fr& gamma, const Fr& y, bool divide, Fr* out) {
+    const Layout& lay = pk->lay;
+    if (qc.adv.size() != lay.n_adv || qc.z.size() != lay.n_chunks || qc.lk_a.size() != lay.n_lookups ||
+        qc.lk_s.size() != lay.n_lookups || qc.lk_z.size() != lay.n_lookups)
+        return ZK_EINVAL;
+    const Fr* xs = nullptr;
+    int rc = ctx_get_coset_points(c, lay.ext_k, &xs);
+    if (rc) return rc;
+    QuotientArgs& q = *pk->h_qargs;  // pinned: the upload below does not stall the host (the previous use is complete)
+    memset(&q, 0, sizeof(q) - sizeof(q.ypow));
+    q.log_ext = lay.ext_k;
+    q.n_gate = lay.n_gate;
+    q.n_adv = lay.n_adv;
+    q.n_chunks = lay.n_chunks;
+    q.chunk_len = lay.chunk_len;
+    q.n_perm = (uint32_t)lay.perm_cols.size();
+    q.n_lookups = lay.n_lookups;
+    q.single = lay.single ? 1 : 0;
+    q.last_rot = lay.last_rot;
+    q.fx_table = lay.fx_table;
+    q.fx_qlookup = lay.fx_qlookup;
+    for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = qc.adv[j];
+    for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
+    for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.fx_sel[j];
+    for (uint32_t p = 0; p < q.n_perm; p++) {
+        q.sigma[p] = pk->sigma_coset[p];
+        const Col& col = lay.perm_cols[p];
+        q.perm_val[p] = col.fixed ? pk->fixed_coset[col.idx] : qc.adv[col.idx];
+    }
+    for (uint32_t ci = 0; ci < lay.n_chunks; ci++) q.z[ci] = qc.z[ci];
+    for (uint32_t l = 0; l < lay.n_lookups; l++) {
+        q.lk_z[l] = qc.lk_z[l];
+        q.lk_a[l] = qc.lk_a[l];
+        q.lk_s[l] = qc.lk_s[l];
+        q.lk_in[l] = lay.single ? nullptr : qc.adv[lay.n_gate + l];
+    }
+    q.l0 = pk->l0_coset;
+    q.l_last = pk->l_last_coset;
+    q.l_active = pk->l_active_coset;
+    q.xs = xs;
+    q.beta = beta;
+    q.gamma = gamma;
+    q.delta = fr_delta();
+    // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
+    const Fr zn = fe_pow_u64(c->zeta, lay.n);
+    const Fr w4 = fe_pow_u64(fr_omega(lay.ext_k), lay.n);
+    Fr cur = zn;
+    for (int i = 0; i < 4; i++) {
+        q.t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
+        cur = fe_mul(cur, w4);
+    }
+    q.divide = divide ? 1 : 0;
+    q.n_terms = quotient_terms(lay.n_gate, lay.n_chunks, lay.n_lookups);
+    if (q.n_terms > MAX_TERMS) return ZK_EINVAL;
+    Fr yp = Fr::one();
+    for (uint32_t j = q.n_terms; j-- > 0;) {  // ypow[j] = y^(T - 1 - j)
+        q.ypow[j] = yp;
+        yp = fe_mul(yp, y);
+    }
+    q.out = out;
+    hipStream_t st = c->stream;
+    hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
+    const size_t bytes = sizeof(q) - sizeof(q.ypow) + (size_t)q.n_terms * sizeof(Fr);
+    if (hipMemcpyAsync(pk->d_qargs, &q, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
+    launch_quotient_dev(pk->d_qargs, lay.ext_k, st);
+    hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
+    c->ev_valid[ZK_T_QUOTIENT] = true;
+    return ZK_OK;
+}
+
+ZK_API(zk_pk_shape, (zk_ctx* c, zk_pk h, uint32_t out[8]), (c, h, out)) {
+    if (!c || !out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    const Layout& lay = it->second->lay;
+    const uint32_t v[8] = {lay.k, lay.ext_k, lay.n_adv, lay.n_fix, (uint32_t)lay.perm_cols.size(), lay.n_chunks, lay.n_lookups, lay.n_h};
+    memcpy(out, v, sizeof(v));
+    return ZK_OK;
+}
+
+ZK_API(zk_quotient, (zk_ctx* c, zk_pk h, const zk_poly* advice_ext, size_t n_advice, const zk_poly* perm_z_ext, size_t n_chunks, const zk_poly* lookup_ext, size_t n_lookups, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], int divide, zk_poly out_ext), (c, h, advice_ext, n_advice, perm_z_ext, n_chunks, lookup_ext, n_lookups, beta, gamma, y, divide, out_ext)) {
+    if (!c || !advice_ext || !perm_z_ext || !lookup_ext || !beta || !gamma || !y) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    zk_pk_rec* pk = it->second;
+    const Layout& lay = pk->lay;
+    if (pk->srs_gen != c->srs_gen) return ZK_ESTATE;
+    if (n_advice != lay.n_adv || n_chunks != lay.n_chunks || n_lookups != lay.n_lookups) return ZK_EINVAL;
+    const size_t N = (size_t)4 * lay.n;
+    auto ext = [&](zk_poly p) -> Fr* {
+        auto q = c->polys.find(p);
+        return (q == c->polys.end() || q->second.n != N) ? nullptr : q->second.ptr;
+    };
+    QuotientCosets qc;
+    for (size_t j = 0; j < n_advice; j++) qc.adv.push_back(ext(advice_ext[j]));
+    for (size_t j = 0; j < n_chunks; j++) qc.z.push_back(ext(perm_z_ext[j]));
+    for (size_t l = 0; l < n_lookups; l++) {
+        qc.lk_a.push_back(ext(lookup_ext[3 * l]));
+        qc.lk_s.push_back(ext(lookup_ext[3 * l + 1]));
+        qc.lk_z.push_back(ext(lookup_ext[3 * l + 2]));
+    }
+    Fr* out = ext(out_ext);
+    if (!out) return ZK_EINVAL;
+    for (auto* v : {&qc.adv, &qc.z, &qc.lk_a, &qc.lk_s, &qc.lk_z})
+        for (const Fr* p : *v)
+            if (!p || p == out) return ZK_EINVAL;
+    Fr b, g, yy;
+    memcpy(&b, beta, 32);
+    memcpy(&g, gamma, 32);
+    memcpy(&yy, y, 32);
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    if ((rc = pk_quotient(c, pk, qc, b, g, yy, divide != 0, out))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the argument block is reused by the next call
+    return ZK_OK;
+}
+
 ZK_API(zk_pk_set_transcript_repr, (zk_ctx* c, zk_pk h, const uint64_t transcript_repr[4]), (c, h, transcript_repr)) {
     if (!c || !transcript_repr) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -653,62 +774,17 @@ struct Prover {
     // h(X) on the extended coset (one lane per row, quotient.hip), divided by X^n - 1, back to coefficients:
     // the first (degree - 1) * n coefficients of h_ext are the h pieces
     int quotient(const Fr& beta, const Fr& gamma, const Fr& y) {
-        QuotientArgs& q = *pk->h_qargs;  // pinned: the upload below does not stall the host (the previous proof is complete)
-        memset(&q, 0, sizeof(q));
-        q.log_ext = lay.ext_k;
-        q.n_gate = lay.n_gate;
-        q.n_adv = lay.n_adv;
-        q.n_chunks = lay.n_chunks;
-        q.chunk_len = lay.chunk_len;
-        q.n_perm = (uint32_t)lay.perm_cols.size();
-        q.n_lookups = lay.n_lookups;
-        q.single = lay.single ? 1 : 0;
-        q.last_rot = lay.last_rot;
-        q.fx_table = lay.fx_table;
-        q.fx_qlookup = lay.fx_qlookup;
-        for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = pk->adv_coset[j];
-        for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
-        for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.fx_sel[j];
-        const Fr delta = fr_delta();
-        Fr dcur = beta;
-        for (uint32_t p = 0; p < q.n_perm; p++) {
-            q.sigma[p] = pk->sigma_coset[p];
-            q.perm_val[p] = col_coset(lay.perm_cols[p]);
-            q.delta_pow[p] = dcur;
-            dcur = fe_mul(dcur, delta);
-        }
-        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) q.z[ci] = pk->z_coset[ci];
+        QuotientCosets qc;
+        for (uint32_t j = 0; j < lay.n_adv; j++) qc.adv.push_back(pk->adv_coset[j]);
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) qc.z.push_back(pk->z_coset[ci]);
         for (uint32_t l = 0; l < lay.n_lookups; l++) {
-            q.lk_z[l] = pk->lk_z_coset[l];
-            q.lk_a[l] = pk->lk_ap_coset[l];
-            q.lk_s[l] = pk->lk_sp_coset[l];
-            q.lk_in[l] = lay.single ? nullptr : pk->adv_coset[lay.n_gate + l];
+            qc.lk_a.push_back(pk->lk_ap_coset[l]);
+            qc.lk_s.push_back(pk->lk_sp_coset[l]);
+            qc.lk_z.push_back(pk->lk_z_coset[l]);
         }
-        q.l0 = pk->l0_coset;
-        q.l_last = pk->l_last_coset;
-        q.l_active = pk->l_active_coset;
-        q.tw_ext = tw_ext;
-        q.zeta = c->zeta;
-        q.beta = beta;
-        q.gamma = gamma;
-        q.y = y;
-        // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
-        const Fr zn = fr_pow(c->zeta, n);
-        const Fr w4 = fr_pow(fr_omega(lay.ext_k), n);
-        Fr cur = zn;
-        for (int i = 0; i < 4; i++) {
-            q.t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
-            cur = fe_mul(cur, w4);
-        }
-        q.out = pk->h_ext;
-        hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
-        hipMemcpyAsync(pk->d_qargs, &q, sizeof(q), hipMemcpyHostToDevice, st);
-        launch_quotient_dev(pk->d_qargs, lay.ext_k, st);
-        hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
-        c->ev_valid[ZK_T_QUOTIENT] = true;
-        int r = ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
+        int r = pk_quotient(c, pk, qc, beta, gamma, y, true, pk->h_ext);
         if (r) return r;
-        return ZK_OK;
+        return ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
     }
 
     // an opening: polynomial, rotation of the point, value

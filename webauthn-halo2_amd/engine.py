@@ -102,6 +102,9 @@ def load_library():
         "zk_vk_load": ([vp, ctypes.c_uint64, vp, sz, ctypes.c_int, u64p], ctypes.c_int),
         "zk_pk_write": ([vp, ctypes.c_uint64, ctypes.c_int, vp, sz, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_pk_read": ([vp, ctypes.POINTER(CircuitParamsC), vp, sz, ctypes.c_int, u64p, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_pk_shape": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)], ctypes.c_int),
+        "zk_quotient": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.POINTER(ctypes.c_uint64), sz,
+                         ctypes.POINTER(ctypes.c_uint64), sz, u64p, u64p, u64p, ctypes.c_int, ctypes.c_uint64], ctypes.c_int),
         "zk_poly_upload_canonical": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
     }
     for name, (args, res) in sig.items():
@@ -324,6 +327,19 @@ class Engine:
         self._chk(self.L.zk_keygen(self.ctx, ctypes.byref(cp), _p(fx), fx.shape[0],
                                    cps.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cps.shape[0], ctypes.byref(h)), "zk_keygen")
         return h.value
+
+    def pk_shape(self, pk):
+        out = (ctypes.c_uint32 * 8)()
+        self._chk(self.L.zk_pk_shape(self.ctx, pk, out), "zk_pk_shape")
+        return dict(zip(("k", "ext_k", "n_advice", "n_fixed", "n_perm", "n_chunks", "n_lookups", "n_h"), out))
+
+    def quotient(self, pk, advice_ext, perm_z_ext, lookup_ext, beta, gamma, y, out_ext, divide=True):
+        """Evaluator::evaluate_h (+ divide_by_vanishing_poly) over resident extended cosets; lookup_ext: (a', s', zL) per lookup."""
+        arr = lambda ps: (ctypes.c_uint64 * max(len(ps), 1))(*[p.h for p in ps])
+        flat = [p for trip in lookup_ext for p in trip]
+        f = lambda v: _p(np.ascontiguousarray(v, dtype=np.uint64).reshape(4))
+        self._chk(self.L.zk_quotient(self.ctx, pk, arr(advice_ext), len(advice_ext), arr(perm_z_ext), len(perm_z_ext), arr(flat),
+                                     len(lookup_ext), f(beta), f(gamma), f(y), 1 if divide else 0, out_ext.h), "zk_quotient")
 
     def pk_set_transcript_repr(self, pk, repr_mont):
         t = np.ascontiguousarray(repr_mont, dtype=np.uint64).reshape(4)
