@@ -226,7 +226,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torchrun (also with one rank: the same barrier / reduce path runs)
         import torch
         import torch.distributed as dist
 
