@@ -1,0 +1,39 @@
+"""Determinism soak: N proofs of the k=19 shape over two concurrent pipelines, every proof of a job compared with the first
+proof of that job (same witness, same RNG seed -> same bytes).  A race between streams / lanes / pipelines shows up as a
+differing proof.  usage: soak.py [proofs_per_pipeline] [k]"""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import webauthn_halo2_amd as zk
+from webauthn_halo2_amd import batch, circuit, engine as E
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 19
+p = circuit.K19 if k == 19 else circuit.K17
+jobs = list(range(4))
+wit = batch.synthesize_jobs(p, jobs)
+fixed, copies = batch.structure(p)
+pipes = [batch.Pipeline(0, p, fixed, copies) for _ in range(2)]
+for pl in pipes:
+    for j in jobs:
+        pl.load(j, wit[j])
+ref = {(j, t): pipes[0].prove(j, t, keep=True) for j in jobs for t in (E.ZK_TRANSCRIPT_BLAKE2B, E.ZK_TRANSCRIPT_EVM)}
+bad = []
+
+
+def work(pl, off):
+    for i in range(reps):
+        j = jobs[(i + off) % len(jobs)]
+        t = E.ZK_TRANSCRIPT_EVM if (i // len(jobs)) & 1 else E.ZK_TRANSCRIPT_BLAKE2B
+        if pl.prove(j, t, keep=True) != ref[(j, t)]:
+            bad.append((off, i, j, t))
+
+
+t0 = time.time()
+ths = [threading.Thread(target=work, args=(pl, q)) for q, pl in enumerate(pipes)]
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+dt = time.time() - t0
+print("soak k=%d: %d proofs over 2 pipelines in %.1f s (%.1f proofs/s), mismatches: %d %s" % (k, 2 * reps, dt, 2 * reps / dt, len(bad), bad[:5]))
+sys.exit(1 if bad else 0)
