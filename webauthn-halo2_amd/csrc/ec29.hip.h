@@ -53,18 +53,42 @@ __device__ __forceinline__ bool g1x29_add_affine(G1X29& acc, const Fq& x, const 
     const Fq29 s2 = mul29(y2, acc.zzz);
     const Fq29 p = norm29(sub29<10, 29>(u2, acc.x));              // (12 ; 29)   X < 9p
     const Fq29 r = norm29(sub29<6, 29>(s2, acc.y));               // (8 ; 29)    Y < 5p
+#ifndef ZK_EC29_SQR
+#define ZK_EC29_SQR 1
+#endif
+#ifndef ZK_EC29_FUSE
+#define ZK_EC29_FUSE 1
+#endif
+#if ZK_EC29_SQR
+    const Fq29 pp = sqr29(p);                                     // 144
+#else
     const Fq29 pp = mul29(p, p);                                  // 144
+#endif
     if (is_zero29(pp)) return false;                              // p prime: P = 0 (mod p) <=> P^2 = 0
     const Fq29 ppp = mul29(p, pp);                                // 24
     const Fq29 q = mul29(acc.x, pp);                              // 18
+#if ZK_EC29_SQR
+    const Fq29 rr = sqr29(r);                                     // 64
+#else
     const Fq29 rr = mul29(r, r);                                  // 64
+#endif
     const Fq29 t = add29(ppp, add29(q, q));                       // (6 ; < 3 * 2^29)
     const Fq29 x3 = norm29(sub29<7, 31>(rr, t));                  // (9 ; 29)
     const Fq29 v = sub29<10, 29>(q, x3);                          // (12 ; 30.6)
+#if ZK_EC29_FUSE
+    // Y3 = R (Q - X3) - Y1 PPP as ONE reduction: R v + Y1 (3p - PPP); bounds 8 * 12 + 5 * 3 = 111 <= 168, columns
+    // 9 (2^29 * 2^30.6) + 9 (2^29 * 2^30) + 9 * 2^58 < 2^64
+    Fq29 zero;
+#pragma unroll
+    for (int i = 0; i < 9; i++) zero.l[i] = 0;
+    acc.x = x3;
+    acc.y = mul2add29(r, v, acc.y, sub29<3, 29>(zero, ppp));      // (2 ; 29)
+#else
     const Fq29 t1 = mul29(r, v);                                  // 96 ; limbs 2^29 * 2^30.6
     const Fq29 t2 = mul29(acc.y, ppp);                            // 10
     acc.x = x3;
     acc.y = norm29(sub29<3, 29>(t1, t2));                         // (5 ; 29)
+#endif
     acc.zz = mul29(acc.zz, pp);
     acc.zzz = mul29(acc.zzz, ppp);
     return true;

@@ -140,6 +140,72 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
     return r;
 }
 
+// (a * b + c * d) * 2^-261 mod p with ONE Montgomery reduction: both products are summed column by column before the
+// m * p terms (243 instead of 324 multiply-adds).  All four operands need limbs <= ~2^30 so that a column
+// (9 + 9 products + 9 reduction terms) stays below 2^64: a_i b_j + c_i d_j < 2^60.6 each side is too much — callers pass
+// normalised (29-bit) a, c and b, d with limbs < 2^30.7.  Value bounds: k_a k_b + k_c k_d <= 168.
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PRM>& b, const Fe29<PRM>& c, const Fe29<PRM>& d) {
+    uint32_t m[9];
+    Fe29<PRM> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+        m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
+        acc += (uint64_t)m[k] * Lim29<PRM>::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+        r.l[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+// a * a * 2^-261 mod p: the 36 cross products are taken once against the doubled operand (45 instead of 81 products of a * a)
+template <class PRM>
+__device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
+    uint32_t m[9], a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+    Fe29<PRM> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        // sum_{i + j = k, i < j} (2 a_i) a_j + [k even] a_{k/2}^2
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+            m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
+            acc += (uint64_t)m[k] * Lim29<PRM>::P[0];
+        } else {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+            r.l[k - 9] = (uint32_t)acc & M29;
+        }
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
 template <class PRM>
 __device__ __forceinline__ Fe29<PRM> add29(const Fe29<PRM>& a, const Fe29<PRM>& b) {
     Fe29<PRM> r;
