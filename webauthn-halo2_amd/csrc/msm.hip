@@ -69,6 +69,12 @@ struct MsmWorkspace {
     uint32_t* blockbase;        // [nblk][nb]
     uint32_t* counts;           // [4]
     uint32_t* entries;          // [max_n * nwin + padding]: +-base index, bucket implied by position
+    // two-level sort (fixed-base mode): entries first grouped by coarse bin (bucket / 64) in `inter`, then by bucket
+    uint32_t* inter;            // [max_batch][max_n * nwin]
+    uint32_t* coarse;           // per column: COARSE_WORDS (coarse-bin starts, chunk prefix, append cursors), then [blocks][CBINS_MAX] reserved bases
+    uint32_t coarse_stride;     // words per column in `coarse`
+    uint32_t* cursor;           // [max_batch * nb] per-bucket write cursors of the second level
+    size_t inter_stride;        // entries per column in `inter`
     G1X* slot_pt;               // [entries / SEG0]
     G1X* partial;               // [entries / PAD]
     G1X* part;                  // [nbt * parts]
@@ -242,6 +248,239 @@ __global__ __launch_bounds__(256) void msm_recode_hist_kernel(MsmBatch batch, ui
     }
 }
 
+// ---- two-level counting sort (ZK_SORT2).  The one-pass scatter below writes every entry to a random place of a 40 MB
+// list: 10.5 M uncoalesced 4-byte stores, 128 us per 2^19 column against 24 us for the same kernel with coalesced stores
+// (tools/scat_exp.sh).  Here the entries are first grouped by coarse bin (bucket / 64) and then, inside a bin, by bucket; in
+// both levels a workgroup sorts 4096 entries in LDS by a 6-bit key and writes them out in runs (~64 entries = 256 B per key),
+// so that consecutive lanes store to consecutive addresses.  The 6-bit fine key rides in bits 24..29 of the entry between
+// the two levels (an entry is sign << 31 | window * n + i, which needs 24 bits up to 20 windows x 2^19).
+#ifndef ZK_SORT2
+#define ZK_SORT2 1
+#endif
+static constexpr uint32_t CBINS_MAX = 128;   // coarse bins = buckets / 64 (64 at 13-bit windows, 128 at 14)
+#ifndef ZK_SORT_SUB
+#define ZK_SORT_SUB 4096
+#endif
+static constexpr uint32_t SUB = ZK_SORT_SUB;  // entries sorted in LDS at a time
+static constexpr uint32_t COARSE_WORDS = 3 * (CBINS_MAX + 1);  // per column: bin starts, chunk prefix, append cursors
+
+// digits + fine histogram: the global bucket totals (the workgroup's counts are added with one atomic per non-empty bucket)
+__global__ __launch_bounds__(256) void msm_recode_hist2_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c, uint32_t nwin,
+                                                               uint32_t nb, int16_t* __restrict__ digits_all,
+                                                               uint32_t* __restrict__ totals_all, uint32_t* __restrict__ coarse_all,
+                                                               uint32_t coarse_stride) {
+    extern __shared__ uint32_t lds[];  // nb counters, then 256 x 9 limbs
+    const uint32_t col = blockIdx.y;
+    const Fr* __restrict__ scalars = batch.s[col];
+    int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
+    uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
+    uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    uint32_t* hist = lds;
+    uint32_t* L = lds + nb + threadIdx.x * 9;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const Fr s = fe_from_mont(fe_load(scalars + i));
+#pragma unroll
+        for (int k = 0; k < 8; k++) L[k] = s.v[k];
+        L[8] = 0;
+        msm_digits_of(L, c, nwin, i, stride, digits, hist);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const uint32_t cnt = hist[b];
+        if (cnt) atomicAdd(&totals[b], cnt);
+    }
+    // the workgroup's range inside every coarse bin of `inter`: one returning atomic per bin on the append cursors
+    const uint32_t bins = nb >> 6;
+    if (threadIdx.x < bins) {
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < 64; q++) sum += hist[threadIdx.x * 64 + ((q + threadIdx.x) & 63)];  // staggered: no bank conflict
+        chdr[COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX + threadIdx.x] = sum ? atomicAdd(&chdr[2 * (CBINS_MAX + 1) + threadIdx.x], sum) : 0;
+    }
+}
+
+// per column: coarse-bin totals (sums of 64 bucket totals), their exclusive scan (the bins' places in `inter`), the chunk
+// prefix of the second level (ceil(total / SUB) chunks per bin), and the first level's append cursors (zero)
+__global__ __launch_bounds__(128) void msm_scan_coarse_kernel(const uint32_t* __restrict__ totals_all, uint32_t nb,
+                                                              uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t bins) {
+    __shared__ uint32_t tot[CBINS_MAX];
+    const uint32_t* totals = totals_all + (size_t)blockIdx.x * nb;
+    uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
+    if (threadIdx.x < bins) {
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < 64; q++) sum += totals[threadIdx.x * 64 + q];
+        tot[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, chunks = 0;
+        for (uint32_t b = 0; b < bins; b++) {
+            c[b] = run;
+            c[(CBINS_MAX + 1) + b] = chunks;
+            run += tot[b];
+            chunks += (tot[b] + SUB - 1) / SUB;
+        }
+        c[bins] = run;
+        c[(CBINS_MAX + 1) + bins] = chunks;
+    }
+}
+
+// one LDS counting sort of up to SUB entries by a 6-bit (7-bit) key held in `key[]`, then the coalesced write-out:
+// slot q of the sorted run goes to dst[gbase[key] + q - lstart[key]]
+struct SortLds {
+    uint32_t cnt[CBINS_MAX], lstart[CBINS_MAX + 1], gbase[CBINS_MAX];
+    uint32_t sorted[SUB];
+    uint8_t kid[SUB];
+};
+
+__device__ __forceinline__ void sort_scan(SortLds& S, uint32_t bins) {
+    // exclusive scan of S.cnt over `bins` <= 128 keys by the first wave
+    if (threadIdx.x < 64) {
+        uint32_t a = threadIdx.x < bins ? S.cnt[threadIdx.x] : 0;
+        uint32_t b = threadIdx.x + 64 < bins ? S.cnt[threadIdx.x + 64] : 0;
+        uint32_t x = a;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if ((int)threadIdx.x >= off) x += y;
+        }
+        const uint32_t tot_a = __shfl(x, 63);
+        uint32_t z = b;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(z, off);
+            if ((int)threadIdx.x >= off) z += y;
+        }
+        S.lstart[threadIdx.x] = x - a;
+        S.lstart[threadIdx.x + 64] = tot_a + z - b;
+        if (threadIdx.x == 63) S.lstart[128] = tot_a + z;
+    }
+}
+
+// level 1: a workgroup's FCHUNK scalars x nwin windows, SUB entry slots (SUB / FCHUNK windows) at a time: sorted in LDS by
+// coarse bin and appended to the workgroup's range of every bin of `inter` (reserved by msm_recode_hist2_kernel)
+__global__ __launch_bounds__(256) void msm_scatter1_kernel(const int16_t* __restrict__ digits_all, uint32_t n, uint32_t stride, uint32_t nwin,
+                                                           uint32_t nb, uint32_t table_stride, const uint32_t* __restrict__ coarse_all,
+                                                           uint32_t coarse_stride, uint32_t* __restrict__ inter_all, size_t inter_stride) {
+    __shared__ SortLds S;
+    const uint32_t col = blockIdx.y;
+    const int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
+    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    const uint32_t* __restrict__ cbase = chdr + COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX;
+    uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
+    const uint32_t bins = nb >> 6;
+    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    if (threadIdx.x < bins) S.gbase[threadIdx.x] = chdr[threadIdx.x] + cbase[threadIdx.x];
+    constexpr uint32_t WPS = SUB / FCHUNK;      // windows per sub-round
+    constexpr uint32_t PER = SUB / 256;         // entry slots per lane and sub-round
+    for (uint32_t w0 = 0; w0 < nwin; w0 += WPS) {
+        if (threadIdx.x < CBINS_MAX) S.cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t ent[PER], meta[PER];  // meta = key << 16 | rank, 0xffffffff = no entry
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            const uint32_t e = threadIdx.x + q * 256;  // slot: window w0 + e / FCHUNK, scalar lo + e % FCHUNK
+            const uint32_t w = w0 + e / FCHUNK, i = lo + (e % FCHUNK);
+            meta[q] = 0xffffffffu;
+            if (w < nwin && i < hi) {
+                const int32_t d = digits[(size_t)w * stride + i];
+                if (d != 0) {
+                    const uint32_t bkt = (uint32_t)(d < 0 ? -d : d) - 1;
+                    const uint32_t key = bkt >> 6;
+                    ent[q] = (w * table_stride + i) | ((bkt & 63u) << 24) | (d < 0 ? SIGN_BIT : 0);
+                    meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        sort_scan(S, bins);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++)
+            if (meta[q] != 0xffffffffu) {
+                const uint32_t key = meta[q] >> 16, pos = S.lstart[key] + (meta[q] & 0xffffu);
+                S.sorted[pos] = ent[q];
+                S.kid[pos] = (uint8_t)key;
+            }
+        __syncthreads();
+        const uint32_t total = S.lstart[128];
+        for (uint32_t q = threadIdx.x; q < total; q += 256) {
+            const uint32_t key = S.kid[q];
+            inter[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < bins) S.gbase[threadIdx.x] += S.cnt[threadIdx.x];
+    }
+}
+
+// level 2: one chunk (<= SUB entries) of one coarse bin into its 64 buckets; also the bucket padding (skip markers)
+__global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                           const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
+                                                           const uint32_t* __restrict__ totals_all,
+                                                           const uint32_t* __restrict__ bucket_start_all, uint32_t* __restrict__ cursor_all,
+                                                           uint32_t* __restrict__ entries) {
+    __shared__ SortLds S;
+    __shared__ uint32_t s_bin, s_chunk;
+    const uint32_t col = blockIdx.y;
+    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
+    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
+    const uint32_t* __restrict__ bucket_start = bucket_start_all + (size_t)col * nb;
+    uint32_t* __restrict__ cursor = cursor_all + (size_t)col * nb;
+    const uint32_t bins = nb >> 6;
+    // this workgroup's share of the bucket padding (skip markers up to the next multiple of PAD)
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
+        const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
+        for (uint32_t q = beg; q < end; q++) entries[q] = SKIP_ENTRY;
+    }
+    const uint32_t* cpre = chdr + (CBINS_MAX + 1);
+    if (blockIdx.x >= cpre[bins]) return;  // the grid is sized for the worst case
+    if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        while (cpre[b + 1] <= blockIdx.x) b++;
+        s_bin = b;
+        s_chunk = blockIdx.x - cpre[b];
+    }
+    if (threadIdx.x < 64) S.cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    const uint32_t beg = chdr[bin] + s_chunk * SUB;
+    const uint32_t end = min(chdr[bin + 1], beg + SUB);
+    constexpr uint32_t PER = SUB / 256;
+    uint32_t ent[PER], meta[PER];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t p = beg + threadIdx.x + q * 256;
+        meta[q] = 0xffffffffu;
+        if (p < end) {
+            const uint32_t e = inter[p];
+            const uint32_t key = (e >> 24) & 63u;
+            ent[q] = e & ~(63u << 24);
+            meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
+        }
+    }
+    __syncthreads();
+    sort_scan(S, 64);
+    if (threadIdx.x < 64) {
+        const uint32_t cnt = S.cnt[threadIdx.x], b = bin * 64 + threadIdx.x;
+        S.gbase[threadIdx.x] = bucket_start[b] + (cnt ? atomicAdd(&cursor[b], cnt) : 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++)
+        if (meta[q] != 0xffffffffu) {
+            const uint32_t key = meta[q] >> 16, pos = S.lstart[key] + (meta[q] & 0xffffu);
+            S.sorted[pos] = ent[q];
+            S.kid[pos] = (uint8_t)key;
+        }
+    __syncthreads();
+    const uint32_t total = end - beg;
+    for (uint32_t q = threadIdx.x; q < total; q += 256) {
+        const uint32_t key = S.kid[q];
+        entries[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
+    }
+}
+
 #ifndef ZK_SCAT_T
 #define ZK_SCAT_T 256
 #endif
@@ -372,11 +611,14 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __re
 
 // start-of-MSM reset in one launch: bucket parts = identity, bucket totals = 0, counts = 0
 __global__ void msm_clear_kernel(G1X* __restrict__ p, uint32_t m, uint32_t* __restrict__ totals, uint32_t nt,
-                                 uint32_t* __restrict__ counts) {
+                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, uint32_t ncur,
+                                 uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) g1x_store(p + i, G1X::identity());
     if (i < nt) totals[i] = 0;
     if (i < 4) counts[i] = 0;
+    if (i < ncur) cursor[i] = 0;  // second-level write cursors (two-level sort)
+    if (i < ncols * CBINS_MAX) coarse[(size_t)(i / CBINS_MAX) * coarse_stride + 2 * (CBINS_MAX + 1) + (i % CBINS_MAX)] = 0;  // first-level append cursors
 }
 
 // ---- "cold" group arithmetic for the low-parallelism reduction kernels: the field
@@ -642,6 +884,14 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     }
     MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
     MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint32_t)));
+    {
+        const size_t nblk_max = (max_n + FCHUNK - 1) / FCHUNK;
+        ws->inter_stride = max_n * ws->nwin;
+        ws->coarse_stride = (uint32_t)(COARSE_WORDS + nblk_max * CBINS_MAX);
+        MSM_TRY(hipMalloc(&ws->inter, (size_t)max_batch * ws->inter_stride * sizeof(uint32_t)));
+        MSM_TRY(hipMalloc(&ws->coarse, (size_t)max_batch * ws->coarse_stride * sizeof(uint32_t)));
+        MSM_TRY(hipMalloc(&ws->cursor, (size_t)max_batch * ws->nb * sizeof(uint32_t)));
+    }
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
@@ -657,6 +907,9 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->blockbase);
     hipFree(ws->counts);
     hipFree(ws->entries);
+    hipFree(ws->inter);
+    hipFree(ws->coarse);
+    hipFree(ws->cursor);
     hipFree(ws->slot_pt);
     hipFree(ws->partial);
     hipFree(ws->part);
@@ -685,14 +938,31 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     hipError_t e;
     {
         const uint32_t m = nbt * parts > nbt + 1 ? nbt * parts : nbt + 1;
+        const bool sort2 = ZK_SORT2 && fused && nb >= 64 && (nb >> 6) <= CBINS_MAX && (uint64_t)nwin * table_stride <= (1u << 24);
         hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, nbt * parts, ws->totals, nbt + 1,
-                           ws->counts);
+                           ws->counts, ws->cursor, sort2 ? nbt : 0u, ws->coarse, ws->coarse_stride, sort2 ? batch : 0u);
     }
     if (n > 0) {
         const uint32_t n32 = (uint32_t)n;
         const uint32_t stride = (uint32_t)ws->max_n;
         const uint32_t nchunks = (n32 + CHUNK - 1) / CHUNK;
-        if (fused) {
+        const bool sort2 = ZK_SORT2 && fused && nb >= 64 && (nb >> 6) <= CBINS_MAX && (uint64_t)nwin * table_stride <= (1u << 24);
+        if (sort2) {
+            // two-level counting sort with coalesced stores (see msm_scatter1_kernel)
+            const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
+            MsmBatch mb;
+            memset(&mb, 0, sizeof(mb));
+            for (uint32_t q = 0; q < batch; q++) mb.s[q] = scalars_list[q];
+            hipLaunchKernelGGL(msm_recode_hist2_kernel, dim3(nblk, batch), dim3(256), (nb + 256 * 9) * 4, st, mb, n32, stride, c, nwin, nb,
+                               ws->digits, ws->totals, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
+            hipLaunchKernelGGL(msm_scan_coarse_kernel, dim3(batch), dim3(128), 0, st, ws->totals, nb, ws->coarse, ws->coarse_stride, nb >> 6);
+            hipLaunchKernelGGL(msm_scatter1_kernel, dim3(nblk, batch), dim3(256), 0, st, ws->digits, n32, stride, nwin, nb, table_stride,
+                               ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride);
+            const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> 6);
+            hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                               ws->coarse_stride, nb, ws->totals, ws->bucket_start, ws->cursor, ws->entries);
+        } else if (fused) {
             const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
             MsmBatch mb;
             memset(&mb, 0, sizeof(mb));
