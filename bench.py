@@ -136,12 +136,13 @@ def pmc_traffic_bytes(kernel="zk::msm_accumulate_kernel"):
 
 # Hardware ceiling of the bucket accumulation: the only wide integer multiplier of CDNA4 is v_mad_u64_u32, issued at
 # MAD_CYCLES cycles per wave64 instruction per SIMD (tools/ubench_isa.hip on MI355X, profiles/r2_ubench_isa.txt: independent
-# mads, 4 waves/SIMD).  One XYZZ mixed addition is 8M + 2S = 10 field products; a product on the carry-free 9x29-bit
-# form is 81 (a*b) + 81 (m*p) multiply-adds and nothing cheaper exists on this ISA (8x32-bit limbs: 128 + carries).
+# mads, 4 waves/SIMD).  One XYZZ mixed addition as the kernel computes it (csrc/ec29.hip.h): 6 products (81 a*b + 81 m*p
+# multiply-adds each on the carry-free 9x29-bit form), 2 squarings (45 + 81) and the fused R*(Q - X3) - Y1*PPP (2 x 81 + one
+# reduction of 81) = 1 467 multiply-adds; nothing cheaper exists on this ISA (8x32-bit limbs: 128 + carries per product).
 MAD_CYCLES = 4.7
 SIMDS, CLOCK_GHZ = 1024, 2.4
-MADS_PER_ADD = 10 * 162
-ALU_PEAK_GADDS = SIMDS * CLOCK_GHZ / MAD_CYCLES * 64 / MADS_PER_ADD  # = 20.7 G mixed adds/s
+MADS_PER_ADD = 6 * 162 + 2 * 126 + 243
+ALU_PEAK_GADDS = SIMDS * CLOCK_GHZ / MAD_CYCLES * 64 / MADS_PER_ADD  # = 22.8 G mixed adds/s
 
 
 def alu_roofline(eng, k):

@@ -176,9 +176,10 @@ def test_srs_setup_matches_reference_known_answers(engine):
     p.free()
 
 
-def test_commit_tau_oracle_k19(engine):
-    """MSM(s, SRS) == [sum s_i tau^i] G1 at the BASELINE size 2^19 (any-n oracle)."""
-    k = 19
+@pytest.mark.parametrize("k", [18, 19])
+def test_commit_tau_oracle_k19(engine, k):
+    """MSM(s, SRS) == [sum s_i tau^i] G1 at the BASELINE size 2^19 (any-n oracle); 2^18 is the shortest column that
+    takes the two-level counting sort (msm.hip sort2_applies)."""
     n = 1 << k
     engine.srs_setup(k)
     a = np.frombuffer(np.random.default_rng(0x5EED0019).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()

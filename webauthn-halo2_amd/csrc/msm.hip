@@ -261,6 +261,16 @@ static constexpr uint32_t CBINS_MAX = 128;   // coarse bins = buckets / 64 (64 a
 #ifndef ZK_SORT_SUB
 #define ZK_SORT_SUB 4096
 #endif
+#ifndef ZK_SORT2_MIN_N
+#define ZK_SORT2_MIN_N (1u << 18)
+#endif
+// The two extra launches and the 4096-entry sub-rounds only pay for long columns: single proofs of the k <= 16 rows of
+// bench_ecdsa.config are 2-6 % slower with it, k = 17 1-2 %, k >= 18 equal, and batches of k = 19 proofs 4 % faster.
+static bool sort2_applies(bool fused, size_t n, uint32_t nb, uint32_t nwin, size_t table_stride) {
+    return ZK_SORT2 && fused && n >= ZK_SORT2_MIN_N && nb >= 64 && (nb >> 6) <= CBINS_MAX &&
+           (uint64_t)nwin * table_stride <= (1u << 24);
+}
+
 static constexpr uint32_t SUB = ZK_SORT_SUB;  // entries sorted in LDS at a time
 static constexpr uint32_t COARSE_WORDS = 3 * (CBINS_MAX + 1);  // per column: bin starts, chunk prefix, append cursors
 
@@ -938,7 +948,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     hipError_t e;
     {
         const uint32_t m = nbt * parts > nbt + 1 ? nbt * parts : nbt + 1;
-        const bool sort2 = ZK_SORT2 && fused && nb >= 64 && (nb >> 6) <= CBINS_MAX && (uint64_t)nwin * table_stride <= (1u << 24);
+        const bool sort2 = sort2_applies(fused, n, nb, nwin, table_stride);
         hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, nbt * parts, ws->totals, nbt + 1,
                            ws->counts, ws->cursor, sort2 ? nbt : 0u, ws->coarse, ws->coarse_stride, sort2 ? batch : 0u);
     }
@@ -946,7 +956,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
         const uint32_t n32 = (uint32_t)n;
         const uint32_t stride = (uint32_t)ws->max_n;
         const uint32_t nchunks = (n32 + CHUNK - 1) / CHUNK;
-        const bool sort2 = ZK_SORT2 && fused && nb >= 64 && (nb >> 6) <= CBINS_MAX && (uint64_t)nwin * table_stride <= (1u << 24);
+        const bool sort2 = sort2_applies(fused, n, nb, nwin, table_stride);
         if (sort2) {
             // two-level counting sort with coalesced stores (see msm_scatter1_kernel)
             const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
