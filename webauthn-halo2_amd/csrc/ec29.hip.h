@@ -94,4 +94,181 @@ __device__ __forceinline__ bool g1x29_add_affine(G1X29& acc, const Fq& x, const 
     return true;
 }
 
+// ---- partial sums kept in internal form between the accumulation and the reduction tails (msm.hip) ----
+// Memory image of a G1X29: 4 x 9 limbs (144 bytes), every coordinate with normalised limbs (< 2^29) and the bounds
+// of the header; the identity is all-zero (a point that is not the identity has ZZ != 0, hence a non-zero limb).
+struct alignas(16) G1X29S {
+    uint32_t w[36];
+};
+
+__device__ __forceinline__ G1X29 g1x29_load(const G1X29S* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint32_t w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    G1X29 r;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.l[i] = w[i];
+        r.y.l[i] = w[9 + i];
+        r.zz.l[i] = w[18 + i];
+        r.zzz.l[i] = w[27 + i];
+        any |= w[18 + i];
+    }
+    r.inf = any == 0;
+    return r;
+}
+
+__device__ __forceinline__ void g1x29_store(G1X29S* p, const G1X29& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    uint32_t w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        w[i] = a.inf ? 0u : a.x.l[i];
+        w[9 + i] = a.inf ? 0u : a.y.l[i];
+        w[18 + i] = a.inf ? 0u : a.zz.l[i];
+        w[27 + i] = a.inf ? 0u : a.zzz.l[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+__device__ __forceinline__ G1X29 g1x29_identity() {
+    G1X29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.x.l[i] = r.y.l[i] = r.zz.l[i] = r.zzz.l[i] = 0;
+    r.inf = true;
+    return r;
+}
+
+// out-of-line product for the rare paths; vector-typed arguments travel in registers (a struct of nine words would
+// go through the stack, i.e. scratch memory)
+typedef uint32_t Limbs9 __attribute__((ext_vector_type(9)));
+typedef uint32_t Words8 __attribute__((ext_vector_type(8)));
+__device__ __noinline__ Limbs9 mul29_vcall(Limbs9 a, Limbs9 b) {
+    Fq29 x, y;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        x.l[i] = a[i];
+        y.l[i] = b[i];
+    }
+    const Fq29 z = mul29(x, y);
+    Limbs9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r[i] = z.l[i];
+    return r;
+}
+__device__ __forceinline__ Fq29 mul29_call(const Fq29& a, const Fq29& b) {
+    Limbs9 x, y;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        x[i] = a.l[i];
+        y[i] = b.l[i];
+    }
+    const Limbs9 z = mul29_vcall(x, y);
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = z[i];
+    return r;
+}
+
+__device__ __forceinline__ Fq29 zero29() {
+    Fq29 z;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z.l[i] = 0;
+    return z;
+}
+
+// 2 * p (dbl-2008-s-1, a = 0) on the lazy field; rare (two equal partial sums): inlined, but its products are calls.
+// In: X (9 ; 29), Y (5 ; 29), ZZ, ZZZ (2 ; 29).  Out: X (7 ; 29), Y (5 ; 29), ZZ, ZZZ (2 ; 29).
+__device__ __forceinline__ void g1x29_dbl_rare(G1X29& p) {
+    if (p.inf) return;
+    const Fq29 u = add29(p.y, p.y);                                        // (10 ; 30)
+    const Fq29 v = mul29_call(u, u);                                       // 100
+    const Fq29 w = mul29_call(u, v);                                       // 20
+    const Fq29 s = mul29_call(p.x, v);                                     // 18
+    const Fq29 xx = mul29_call(p.x, p.x);                                  // 81
+    const Fq29 m = norm29(add29(xx, add29(xx, xx)));                       // (6 ; 29)
+    const Fq29 mm = mul29_call(m, m);                                      // 36
+    const Fq29 x3 = norm29(sub29<5, 30>(mm, add29(s, s)));                 // (7 ; 29)
+    const Fq29 t1 = mul29_call(m, sub29<8, 29>(s, x3));                    // 6 * 10 = 60
+    const Fq29 t2 = mul29_call(w, p.y);                                    // 10
+    p.zz = mul29_call(v, p.zz);
+    p.zzz = mul29_call(w, p.zzz);
+    p.x = x3;
+    p.y = norm29(sub29<3, 29>(t1, t2));                                    // (5 ; 29)
+}
+
+// acc += b, both XYZZ partial sums in internal form (add-2008-s), all special cases handled; the products are inlined,
+// so a kernel should have ONE call site (3 300 instructions).  Bounds in and out as in the header (X < 9p, Y < 5p).
+__device__ __forceinline__ void g1x29_add(G1X29& acc, const G1X29& b) {
+    if (b.inf) return;
+    if (acc.inf) {
+        acc = b;
+        return;
+    }
+    const Fq29 u1 = mul29(acc.x, b.zz);                                    // 18
+    const Fq29 u2 = mul29(b.x, acc.zz);
+    const Fq29 s1 = mul29(acc.y, b.zzz);                                   // 10
+    const Fq29 s2 = mul29(b.y, acc.zzz);
+    const Fq29 p = norm29(sub29<3, 29>(u2, u1));                           // (5 ; 29)
+    const Fq29 r = norm29(sub29<3, 29>(s2, s1));                           // (5 ; 29)
+    const Fq29 pp = sqr29(p);                                              // 25
+    if (is_zero29(pp)) {                                                   // same x: doubling or cancellation
+        if (is_zero29(mul29_call(r, r))) g1x29_dbl_rare(acc);
+        else acc = g1x29_identity();
+        return;
+    }
+    const Fq29 ppp = mul29(p, pp);                                         // 10
+    const Fq29 q = mul29(u1, pp);                                          // 4
+    const Fq29 rr = sqr29(r);                                              // 25
+    const Fq29 t = add29(ppp, add29(q, q));                                // (6 ; < 3 * 2^29)
+    const Fq29 x3 = norm29(sub29<7, 31>(rr, t));                           // (9 ; 29)
+    const Fq29 v = sub29<10, 29>(q, x3);                                   // (12 ; 30.6)
+    acc.y = mul2add29(r, v, s1, sub29<3, 29>(zero29(), ppp));              // 5 * 12 + 2 * 3 = 66: (2 ; 29)
+    acc.x = x3;
+    acc.zz = mul29(mul29(acc.zz, b.zz), pp);
+    acc.zzz = mul29(mul29(acc.zzz, b.zzz), ppp);
+}
+
+__device__ __forceinline__ G1X29 g1x29_shfl_down(const G1X29& v, int off) {
+    G1X29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        r.x.l[k] = __shfl_down(v.x.l[k], off);
+        r.y.l[k] = __shfl_down(v.y.l[k], off);
+        r.zz.l[k] = __shfl_down(v.zz.l[k], off);
+        r.zzz.l[k] = __shfl_down(v.zzz.l[k], off);
+    }
+    r.inf = __shfl_down((int)v.inf, off) != 0;
+    return r;
+}
+
+// out-of-line conversion for the one lane that hands a bit sum to the host
+__device__ __noinline__ Words8 internal_to_std_vcall(Limbs9 a) {
+    Fq29 x;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x.l[i] = a[i];
+    Fq r = from29(mul29(x, const_pow2_29<256, FqParams>()));
+    reduce_once(r);
+    Words8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = r.v[i];
+    return o;
+}
+__device__ __forceinline__ Fq internal_to_std_call(const Fq29& a) {
+    Limbs9 x;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] = a.l[i];
+    const Words8 o = internal_to_std_vcall(x);
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = o[i];
+    return r;
+}
+
 }  // namespace zk

@@ -75,9 +75,9 @@ struct MsmWorkspace {
     uint32_t coarse_stride;     // words per column in `coarse`
     uint32_t* cursor;           // [max_batch * nb] per-bucket write cursors of the second level
     size_t inter_stride;        // entries per column in `inter`
-    G1X* slot_pt;               // [entries / SEG0]
-    G1X* partial;               // [entries / PAD]
-    G1X* part;                  // [nbt * parts]
+    G1X29S* slot_pt;            // [entries / SEG0]  partial sums stay in the accumulation's internal form (ec29.hip.h)
+    G1X29S* partial;            // [entries / PAD]
+    G1X29S* part;                  // [nbt * parts]
     G1X* bit_sum;               // [nwin * c]
 };
 
@@ -594,13 +594,13 @@ __global__ void msm_pad_kernel(const uint32_t* __restrict__ totals, const uint32
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
                                                             const uint32_t* __restrict__ counts,
-                                                            G1X* __restrict__ slot_pt) {
+                                                            G1X29S* __restrict__ slot_pt) {
     const uint32_t total = counts[0];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
     const uint32_t* e = entries + (size_t)t * SEG0;
     // the running sum lives on the carry-free 29-bit-limb field (ec29.hip.h); bases are read in
-    // their standard memory form and the slot is written back in it
+    // their standard memory form, the slot is written in the internal one (the reduction tails stay on that field)
     G1X29 acc;
     acc.inf = true;
     for (uint32_t k = 0; k < SEG0; k++) {
@@ -616,105 +616,41 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __re
             acc = g1x29_from_std(s);
         }
     }
-    g1x_store(slot_pt + t, g1x29_to_std(acc));
+    g1x29_store(slot_pt + t, acc);
 }
 
 // start-of-MSM reset in one launch: bucket parts = identity, bucket totals = 0, counts = 0
-__global__ void msm_clear_kernel(G1X* __restrict__ p, uint32_t m, uint32_t* __restrict__ totals, uint32_t nt,
+__global__ void msm_clear_kernel(G1X29S* __restrict__ p, uint32_t m, uint32_t* __restrict__ totals, uint32_t nt,
                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, uint32_t ncur,
                                  uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) g1x_store(p + i, G1X::identity());
+    if (i < m) g1x29_store(p + i, g1x29_identity());
     if (i < nt) totals[i] = 0;
     if (i < 4) counts[i] = 0;
     if (i < ncur) cursor[i] = 0;  // second-level write cursors (two-level sort)
     if (i < ncols * CBINS_MAX) coarse[(size_t)(i / CBINS_MAX) * coarse_stride + 2 * (CBINS_MAX + 1) + (i % CBINS_MAX)] = 0;  // first-level append cursors
 }
 
-// ---- "cold" group arithmetic for the low-parallelism reduction kernels: the field
-// product is an out-of-line call, which keeps these kernels at ~100 VGPRs (8 waves/SIMD,
-// no scratch) instead of 248 + spills when fourteen products are inlined per addition.
-__device__ __noinline__ Fq fq_mul_call(Fq a, Fq b) { return fe_mul(a, b); }
-
-__device__ void g1x_dbl_cold(G1X& p) {
-    if (p.is_identity()) return;
-    const Fq u = fe_dbl(p.y);
-    const Fq v = fq_mul_call(u, u);
-    const Fq w = fq_mul_call(u, v);
-    const Fq s = fq_mul_call(p.x, v);
-    const Fq xx = fq_mul_call(p.x, p.x);
-    const Fq m = fe_add(fe_dbl(xx), xx);
-    const Fq x3 = fe_sub(fq_mul_call(m, m), fe_dbl(s));
-    const Fq y3 = fe_sub(fq_mul_call(m, fe_sub(s, x3)), fq_mul_call(w, p.y));
-    p.zz = fq_mul_call(v, p.zz);
-    p.zzz = fq_mul_call(w, p.zzz);
-    p.x = x3;
-    p.y = y3;
-}
-
-__device__ void g1x_add_cold(G1X& acc, const G1X& b) {
-    if (b.is_identity()) return;
-    if (acc.is_identity()) {
-        acc = b;
-        return;
-    }
-    const Fq u1 = fq_mul_call(acc.x, b.zz);
-    const Fq u2 = fq_mul_call(b.x, acc.zz);
-    const Fq s1 = fq_mul_call(acc.y, b.zzz);
-    const Fq s2 = fq_mul_call(b.y, acc.zzz);
-    const Fq p = fe_sub(u2, u1);
-    const Fq r = fe_sub(s2, s1);
-    if (p.is_zero()) {
-        if (r.is_zero()) g1x_dbl_cold(acc);
-        else acc = G1X::identity();
-        return;
-    }
-    const Fq pp = fq_mul_call(p, p);
-    const Fq ppp = fq_mul_call(p, pp);
-    const Fq q = fq_mul_call(u1, pp);
-    const Fq x3 = fe_sub(fe_sub(fq_mul_call(r, r), ppp), fe_dbl(q));
-    const Fq y3 = fe_sub(fq_mul_call(r, fe_sub(q, x3)), fq_mul_call(s1, ppp));
-    acc.zz = fq_mul_call(fq_mul_call(acc.zz, b.zz), pp);
-    acc.zzz = fq_mul_call(fq_mul_call(acc.zzz, b.zzz), ppp);
-    acc.x = x3;
-    acc.y = y3;
-}
-
-__device__ __forceinline__ G1X g1x_shfl_down(const G1X& v, int off) {
-    G1X r;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        r.x.v[k] = __shfl_down(v.x.v[k], off);
-        r.y.v[k] = __shfl_down(v.y.v[k], off);
-        r.zz.v[k] = __shfl_down(v.zz.v[k], off);
-        r.zzz.v[k] = __shfl_down(v.zzz.v[k], off);
-    }
-    return r;
-}
-
-// sum over aligned groups of `width` lanes (power of two <= 64); result in the group's lane 0
-__device__ __forceinline__ void group_sum(G1X& acc, int width) {
-#pragma unroll 1
-    for (int off = width >> 1; off > 0; off >>= 1) {
-        const G1X o = g1x_shfl_down(acc, off);
-        if ((int)(threadIdx.x & (width - 1)) < off) g1x_add_cold(acc, o);
-    }
-}
+// ---- reduction tails.  The partial sums stay on the carry-free 29-bit-limb field (ec29.hip.h: 3 300 instructions per
+// general XYZZ addition with the products inlined, against 4 600 through out-of-line 8 x 32-bit products, and no dependent
+// carry chains — these kernels run at one or two waves per SIMD, where a chained product is latency-bound).  Every kernel
+// is shaped so that it has ONE inlined addition (a loop that fetches its operand from memory, from a shuffle or from LDS
+// and then adds): three copies of the addition would not fit the instruction cache.
 
 // First-level gather: every lane sums GA consecutive slots serially (same bucket by alignment):
 // dense lanes, no idle tree steps — this is where most of the slot additions happen.
-__global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X* __restrict__ slot_pt, const uint32_t* __restrict__ counts,
-                                                         G1X* __restrict__ partial) {
+__global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X29S* __restrict__ slot_pt, const uint32_t* __restrict__ counts,
+                                                         G1X29S* __restrict__ partial) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if ((size_t)t * PAD >= counts[0]) return;
-    const G1X* src = slot_pt + (size_t)t * GA;
-    G1X acc = g1x_load(src);
+    const G1X29S* src = slot_pt + (size_t)t * GA;
+    G1X29 acc = g1x29_load(src);
 #pragma unroll 1
     for (uint32_t k = 1; k < GA; k++) {
-        const G1X v = g1x_load(src + k);
-        g1x_add_cold(acc, v);
+        const G1X29 v = g1x29_load(src + k);
+        g1x29_add(acc, v);
     }
-    g1x_store(partial + t, acc);
+    g1x29_store(partial + t, acc);
 }
 
 // Second level: one LANES-lane group per (bucket b, part p) sums the p-th share of the bucket's
@@ -723,13 +659,13 @@ __global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X* __restrict__
 // (at most `parts`); the others stay identity.
 template <uint32_t LANES>
 __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restrict__ bucket_start,
-                                                         const G1X* __restrict__ partial, uint32_t parts, uint32_t ngroups,
-                                                         G1X* __restrict__ part) {
+                                                         const G1X29S* __restrict__ partial, uint32_t parts, uint32_t ngroups,
+                                                         G1X29S* __restrict__ part) {
     const uint32_t gid = (blockIdx.x * 256 + threadIdx.x) / LANES;
     const uint32_t lane = threadIdx.x & (LANES - 1);
-    G1X acc = G1X::identity();
+    G1X29 acc = g1x29_identity();
     bool active = false;
-    uint32_t b = 0, p = 0;
+    uint32_t b = 0, p = 0, s = 0, a1 = 0;
     if (gid < ngroups) {
         // part-major: the groups of part 0 (the only one most buckets use) are adjacent, so their waves are
         // full and the waves of the unused parts exit at once
@@ -742,17 +678,31 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
         if (p < used) {
             active = true;
             const uint32_t share = (len + used - 1) / used;
-            const uint32_t a0 = s0 + p * share, a1 = min(s1, a0 + share);
-#pragma unroll 1
-            for (uint32_t s = a0 + lane; s < a1; s += LANES) {
-                const G1X v = g1x_load(partial + s);
-                g1x_add_cold(acc, v);
-            }
+            const uint32_t a0 = s0 + p * share;
+            a1 = min(s1, a0 + share);
+            s = a0 + lane;
         }
     }
     if (!__any(active)) return;  // wave-uniform: no group of this wave has work
-    group_sum(acc, LANES);       // every lane of the wave takes part in the shuffles
-    if (active && lane == 0) g1x_store(part + (size_t)b * parts + p, acc);
+    // the serial part (lanes stride over the share) and the shuffle tree feed the same addition
+    int off = LANES >> 1;
+#pragma unroll 1
+    for (;;) {
+        G1X29 v;
+        bool have;
+        if (__any(active && s < a1)) {  // wave-uniform
+            have = active && s < a1;
+            if (have) v = g1x29_load(partial + s);
+            s += LANES;
+        } else {
+            if (off == 0) break;
+            v = g1x29_shfl_down(acc, off);  // every lane of the wave takes part in the shuffles
+            have = (int)lane < off;
+            off >>= 1;
+        }
+        if (have) g1x29_add(acc, v);
+    }
+    if (active && lane == 0) g1x29_store(part + (size_t)b * parts + p, acc);
 }
 
 // ---------------------------------------------------------------- reduce ---
@@ -761,7 +711,8 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
 // grid = slices * c * split workgroups of THREADS lanes, one multiplier per lane: the shape follows the
 // bucket count (2^(c-1) / 2 multipliers per bit: 4 x 512 lanes at c = 13, 1 x 128 at c = 9), so that the
 // tree is no deeper than the data and small bucket sets do not launch idle waves.  The host adds the
-// `split` partials of a bit and runs the c-term Horner.
+// `split` partials of a bit and runs the c-term Horner (on the standard form: the one lane that writes a
+// bit sum converts it).
 static constexpr uint32_t BITSUM_MAX_SPLIT = 4;
 static uint32_t bitsum_threads(uint32_t nb) {
     uint32_t t = nb >> 1;  // multipliers per bit
@@ -776,37 +727,64 @@ static uint32_t bitsum_split(uint32_t nb) {
     return s;
 }
 template <uint32_t THREADS>
-__global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X* __restrict__ part, uint32_t parts, uint32_t nb,
+__global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __restrict__ part, uint32_t parts, uint32_t nb,
                                                              uint32_t c, uint32_t split, G1X* __restrict__ out) {
-    __shared__ G1X sh[THREADS / 64];
+    __shared__ G1X29S sh[THREADS / 64];
     const uint32_t q = blockIdx.x % split;
     const uint32_t st = blockIdx.x / split;
     const uint32_t slice = st / c, t = st - slice * c;
-    G1X acc = G1X::identity();
+    const uint32_t wave = threadIdx.x >> 6;
+    G1X29 acc = g1x29_identity();
     // the multipliers j in [1, nb] with bit t set, enumerated densely (no lane idles on a clear bit):
     // t < c-1: j = i with a 1 inserted at bit t, i < nb/2;  t = c-1: j = nb only
     const uint32_t items = t + 1 < c ? nb >> 1 : 1;
+    uint32_t i = q * THREADS + threadIdx.x, k = 0;
+    // stage 0: the lane's multipliers (serial), then a shuffle tree over the wave; stage 1 (wave 0 only): the
+    // per-wave sums from LDS and a shuffle tree over them.  One loop, one addition.
+    int off = 32;
+    uint32_t lanes = 64;
 #pragma unroll 1
-    for (uint32_t i = q * THREADS + threadIdx.x; i < items; i += THREADS * split) {
-        const uint32_t j = t + 1 < c ? (((i >> t) << (t + 1)) | (1u << t) | (i & ((1u << t) - 1))) : nb;
-        const G1X* src = part + ((size_t)slice * nb + (j - 1)) * parts;
+    for (uint32_t stage = 0;; stage++) {
 #pragma unroll 1
-        for (uint32_t k = 0; k < parts; k++) {
-            const G1X v = g1x_load(src + k);
-            g1x_add_cold(acc, v);
+        for (;;) {
+            G1X29 v;
+            bool have;
+            if (stage == 0 && __any(i < items)) {  // wave-uniform
+                have = i < items;
+                if (have) {
+                    const uint32_t j = t + 1 < c ? (((i >> t) << (t + 1)) | (1u << t) | (i & ((1u << t) - 1))) : nb;
+                    v = g1x29_load(part + ((size_t)slice * nb + (j - 1)) * parts + k);
+                    if (++k == parts) {
+                        k = 0;
+                        i += THREADS * split;
+                    }
+                }
+            } else {
+                if (off == 0) break;
+                v = g1x29_shfl_down(acc, off);
+                have = (threadIdx.x & (lanes - 1)) < (uint32_t)off;
+                off >>= 1;
+            }
+            if (have) g1x29_add(acc, v);
         }
-    }
-    group_sum(acc, 64);
-    if (THREADS > 64) {
-        const uint32_t wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) g1x_store(sh + wave, acc);
+        if (THREADS == 64 || stage == 1) break;
+        if ((threadIdx.x & 63) == 0) g1x29_store(sh + wave, acc);
         __syncthreads();
-        if (wave == 0) {
-            acc = (threadIdx.x < THREADS / 64) ? g1x_load(sh + threadIdx.x) : G1X::identity();
-            group_sum(acc, THREADS / 64);
-        }
+        if (wave != 0) return;
+        acc = (threadIdx.x < THREADS / 64) ? g1x29_load(sh + threadIdx.x) : g1x29_identity();
+        lanes = THREADS / 64;
+        off = (int)(THREADS / 128);
     }
-    if (threadIdx.x == 0) g1x_store(out + blockIdx.x, acc);
+    if (threadIdx.x == 0) {
+        G1X r = G1X::identity();
+        if (!acc.inf) {
+            r.x = internal_to_std_call(acc.x);
+            r.y = internal_to_std_call(acc.y);
+            r.zz = internal_to_std_call(acc.zz);
+            r.zzz = internal_to_std_call(acc.zzz);
+        }
+        g1x_store(out + blockIdx.x, r);
+    }
 }
 
 // ------------------------------------------------------ fixed-base tables ---
@@ -902,9 +880,9 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
         MSM_TRY(hipMalloc(&ws->coarse, (size_t)max_batch * ws->coarse_stride * sizeof(uint32_t)));
         MSM_TRY(hipMalloc(&ws->cursor, (size_t)max_batch * ws->nb * sizeof(uint32_t)));
     }
-    MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X)));
-    MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X)));
-    MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X)));
+    MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X29S)));
+    MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X29S)));
+    MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->bit_sum, slices * c * BITSUM_MAX_SPLIT * sizeof(G1X)));
     return ws;
 }
