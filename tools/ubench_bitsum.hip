@@ -1,0 +1,76 @@
+// ubench_bitsum.hip — the MSM bit-sum kernel alone on synthetic bucket sums, with wall-clock stamps of workgroup 0
+// (serial loads, wave tree, barrier, cross-wave tree).  Build:
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -DZK_TAIL_TRACE -I webauthn-halo2_amd/csrc tools/ubench_bitsum.hip -o tools/ubench_bitsum
+#include "msm.hip"
+
+#include <stdio.h>
+#include <stdlib.h>
+using namespace zk;
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+int main() {
+    const uint32_t c = 13, nb = 1u << (c - 1), parts = 8, split = 4;
+    const size_t np = (size_t)nb * parts;
+    G1X29S* h = (G1X29S*)calloc(np, sizeof(G1X29S));
+    srand(7);
+    for (size_t b = 0; b < nb; b++)
+        for (int j = 0; j < 36; j++) h[b * parts].w[j] = (j % 9 == 8) ? (rand() & 0xfffff) : (((uint32_t)rand() << 8 ^ rand()) & ((1u << 29) - 1));
+    uint32_t* hs = (uint32_t*)malloc((nb + 1) * 4);
+    for (uint32_t b = 0; b <= nb; b++) hs[b] = b * 40 * PAD;
+    G1X29S* dpart;
+    uint32_t* dstart;
+    G1X* dout;
+    CHK(hipMalloc(&dpart, np * sizeof(G1X29S)));
+    CHK(hipMalloc(&dstart, (nb + 1) * 4));
+    CHK(hipMalloc(&dout, c * split * sizeof(G1X)));
+    CHK(hipMemcpy(dpart, h, np * sizeof(G1X29S), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(dstart, hs, (nb + 1) * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    CHK(hipFree(dout));
+    CHK(hipMalloc(&dout, c * 64 * sizeof(G1X)));
+    for (int cfg = 0; cfg < 7; cfg++) {
+        const uint32_t threads[7] = {512, 256, 256, 128, 128, 64, 64}, splits[7] = {4, 4, 8, 4, 16, 4, 32};
+        for (int rep = 0; rep < 3; rep++) {
+            const uint32_t sp = splits[cfg];
+            CHK(hipEventRecord(e0));
+            if (threads[cfg] == 512) hipLaunchKernelGGL(msm_bitsum_kernel<512>, dim3(c * sp), dim3(512), 0, 0, dpart, parts, nb, c, sp, dstart, 16u, dout);
+            if (threads[cfg] == 256) hipLaunchKernelGGL(msm_bitsum_kernel<256>, dim3(c * sp), dim3(256), 0, 0, dpart, parts, nb, c, sp, dstart, 16u, dout);
+            if (threads[cfg] == 128) hipLaunchKernelGGL(msm_bitsum_kernel<128>, dim3(c * sp), dim3(128), 0, 0, dpart, parts, nb, c, sp, dstart, 16u, dout);
+            if (threads[cfg] == 64) hipLaunchKernelGGL(msm_bitsum_kernel<64>, dim3(c * sp), dim3(64), 0, 0, dpart, parts, nb, c, sp, dstart, 16u, dout);
+            CHK(hipEventRecord(e1));
+            CHK(hipEventSynchronize(e1));
+            float ms;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long tr[16];
+            CHK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(zk_tail_trace), sizeof(tr)));
+            if (rep) printf("threads %3u split %2u: kernel %.1f us | workgroup 0: serial %.1f, wave tree %.1f, barrier %.1f, cross-wave tree %.1f us\n", threads[cfg], sp, ms * 1e3,
+                   (tr[2] - tr[0]) * 0.01, (tr[3] - tr[2]) * 0.01, threads[cfg] > 64 ? (tr[4] - tr[3]) * 0.01 : 0.0, threads[cfg] > 64 ? (tr[5] - tr[4]) * 0.01 : 0.0);
+        }
+    }
+    {
+        // second-level gather: 4096 buckets of 40 first-level partials each, 8 parts (only part 0 used), 16-lane groups
+        const uint32_t per = 40;
+        G1X29S* dpartial;
+        CHK(hipMalloc(&dpartial, (size_t)nb * per * sizeof(G1X29S)));
+        for (uint32_t b = 0; b < per; b++) CHK(hipMemcpy(dpartial + (size_t)b * nb, dpart, 0, hipMemcpyDeviceToDevice));
+        G1X29S* hp = (G1X29S*)malloc((size_t)nb * per * sizeof(G1X29S));
+        for (size_t i = 0; i < (size_t)nb * per; i++) hp[i] = h[(i % nb) * parts];
+        CHK(hipMemcpy(dpartial, hp, (size_t)nb * per * sizeof(G1X29S), hipMemcpyHostToDevice));
+        const uint32_t ngroups = nb * parts;
+        for (int rep = 0; rep < 3; rep++) {
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(msm_gather_kernel<16>, dim3((ngroups * 16 + 255) / 256), dim3(256), 0, 0, dstart, dpartial, parts, ngroups, dpart);
+            CHK(hipEventRecord(e1));
+            CHK(hipEventSynchronize(e1));
+            float ms;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long tr[16];
+            CHK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(zk_tail_trace), sizeof(tr)));
+            printf("gather<16>: kernel %.1f us | workgroup 0: serial %.1f, tree %.1f us\n", ms * 1e3, (tr[9] - tr[8]) * 0.01, (tr[10] - tr[9]) * 0.01);
+        }
+    }
+    return 0;
+}

@@ -631,6 +631,13 @@ __global__ void msm_clear_kernel(G1X29S* __restrict__ p, uint32_t m, uint32_t* _
     if (i < ncols * CBINS_MAX) coarse[(size_t)(i / CBINS_MAX) * coarse_stride + 2 * (CBINS_MAX + 1) + (i % CBINS_MAX)] = 0;  // first-level append cursors
 }
 
+#ifdef ZK_TAIL_TRACE  // tools/ubench_tail.hip: where a bit-sum workgroup spends its time (100 MHz wall clock stamps)
+__device__ unsigned long long zk_tail_trace[16];
+#define ZK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) zk_tail_trace[i] = wall_clock64(); } while (0)
+#else
+#define ZK_STAMP(i) do { } while (0)
+#endif
+
 // ---- reduction tails.  The partial sums stay on the carry-free 29-bit-limb field (ec29.hip.h: 3 300 instructions per
 // general XYZZ addition with the products inlined, against 4 600 through out-of-line 8 x 32-bit products, and no dependent
 // carry chains — these kernels run at one or two waves per SIMD, where a chained product is latency-bound).  Every kernel
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
     if (!__any(active)) return;  // wave-uniform: no group of this wave has work
     // the serial part (lanes stride over the share) and the shuffle tree feed the same addition
     int off = LANES >> 1;
+    ZK_STAMP(8);
 #pragma unroll 1
     for (;;) {
         G1X29 v;
@@ -696,12 +704,14 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
             s += LANES;
         } else {
             if (off == 0) break;
+            if (off == (int)(LANES >> 1)) ZK_STAMP(9);
             v = g1x29_shfl_down(acc, off);  // every lane of the wave takes part in the shuffles
             have = (int)lane < off;
             off >>= 1;
         }
         if (have) g1x29_add(acc, v);
     }
+    ZK_STAMP(10);
     if (active && lane == 0) g1x29_store(part + (size_t)b * parts + p, acc);
 }
 
@@ -714,11 +724,13 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
 // `split` partials of a bit and runs the c-term Horner (on the standard form: the one lane that writes a
 // bit sum converts it).
 static constexpr uint32_t BITSUM_MAX_SPLIT = 4;
+// One wave per workgroup.  Measured on the 4 x 2048 multipliers of a 13-bit window (tools/ubench_bitsum.hip): workgroups of
+// 512 lanes (one multiplier per lane, a cross-wave step through LDS) 205 us, 256 lanes 140, 128 lanes 113, 64 lanes 107 —
+// the hardware packs the waves of a workgroup two or three to a SIMD even on an idle chip, each tree step then costs two or
+// three additions, and the others wait at the barrier; a lone wave per workgroup gets a SIMD to itself.
 static uint32_t bitsum_threads(uint32_t nb) {
-    uint32_t t = nb >> 1;  // multipliers per bit
-    if (t < 64) t = 64;
-    if (t > 512) t = 512;
-    return t;
+    (void)nb;
+    return 64;
 }
 static uint32_t bitsum_split(uint32_t nb) {
     uint32_t s = (nb >> 1) / 512;
@@ -728,7 +740,8 @@ static uint32_t bitsum_split(uint32_t nb) {
 }
 template <uint32_t THREADS>
 __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __restrict__ part, uint32_t parts, uint32_t nb,
-                                                             uint32_t c, uint32_t split, G1X* __restrict__ out) {
+                                                             uint32_t c, uint32_t split, const uint32_t* __restrict__ bucket_start,
+                                                             uint32_t group_lanes, G1X* __restrict__ out) {
     __shared__ G1X29S sh[THREADS / 64];
     const uint32_t q = blockIdx.x % split;
     const uint32_t st = blockIdx.x / split;
@@ -739,6 +752,16 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
     // t < c-1: j = i with a 1 inserted at bit t, i < nb/2;  t = c-1: j = nb only
     const uint32_t items = t + 1 < c ? nb >> 1 : 1;
     uint32_t i = q * THREADS + threadIdx.x, k = 0;
+    // parts of a bucket the gather kernel wrote (the others are identity and not worth a round trip to memory)
+    const auto used_parts = [&](uint32_t b) {
+        const uint32_t len = bucket_start[b + 1] / PAD - bucket_start[b] / PAD;
+        return min(parts, (len + 4 * group_lanes - 1) / (4 * group_lanes));
+    };
+    const auto multiplier = [&](uint32_t ii) { return t + 1 < c ? (((ii >> t) << (t + 1)) | (1u << t) | (ii & ((1u << t) - 1))) : nb; };
+    uint32_t used = 0;
+    ZK_STAMP(0);
+    while (i < items && (used = used_parts(slice * nb + multiplier(i) - 1)) == 0) i += THREADS * split;
+    ZK_STAMP(1);
     // stage 0: the lane's multipliers (serial), then a shuffle tree over the wave; stage 1 (wave 0 only): the
     // per-wave sums from LDS and a shuffle tree over them.  One loop, one addition.
     int off = 32;
@@ -752,24 +775,27 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
             if (stage == 0 && __any(i < items)) {  // wave-uniform
                 have = i < items;
                 if (have) {
-                    const uint32_t j = t + 1 < c ? (((i >> t) << (t + 1)) | (1u << t) | (i & ((1u << t) - 1))) : nb;
-                    v = g1x29_load(part + ((size_t)slice * nb + (j - 1)) * parts + k);
-                    if (++k == parts) {
+                    v = g1x29_load(part + ((size_t)slice * nb + (multiplier(i) - 1)) * parts + k);
+                    if (++k == used) {
                         k = 0;
                         i += THREADS * split;
+                        while (i < items && (used = used_parts(slice * nb + multiplier(i) - 1)) == 0) i += THREADS * split;
                     }
                 }
             } else {
                 if (off == 0) break;
+                if (stage == 0 && off == 32) ZK_STAMP(2);
                 v = g1x29_shfl_down(acc, off);
                 have = (threadIdx.x & (lanes - 1)) < (uint32_t)off;
                 off >>= 1;
             }
             if (have) g1x29_add(acc, v);
         }
+        ZK_STAMP(3 + 2 * stage);
         if (THREADS == 64 || stage == 1) break;
         if ((threadIdx.x & 63) == 0) g1x29_store(sh + wave, acc);
         __syncthreads();
+        ZK_STAMP(4);
         if (wave != 0) return;
         acc = (threadIdx.x < THREADS / 64) ? g1x29_load(sh + threadIdx.x) : g1x29_identity();
         lanes = THREADS / 64;
@@ -784,6 +810,7 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
             r.zzz = internal_to_std_call(acc.zzz);
         }
         g1x_store(out + blockIdx.x, r);
+        ZK_STAMP(6);
     }
 }
 
@@ -1008,13 +1035,17 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     }
     const uint32_t bt = bitsum_threads(nb), bs = bitsum_split(nb);
     if (bt == 512)
-        hipLaunchKernelGGL(msm_bitsum_kernel<512>, dim3(slices * c * bs), dim3(512), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+        hipLaunchKernelGGL(msm_bitsum_kernel<512>, dim3(slices * c * bs), dim3(512), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
+                           fixed ? 16u : 4u, ws->bit_sum);
     else if (bt == 256)
-        hipLaunchKernelGGL(msm_bitsum_kernel<256>, dim3(slices * c * bs), dim3(256), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+        hipLaunchKernelGGL(msm_bitsum_kernel<256>, dim3(slices * c * bs), dim3(256), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
+                           fixed ? 16u : 4u, ws->bit_sum);
     else if (bt == 128)
-        hipLaunchKernelGGL(msm_bitsum_kernel<128>, dim3(slices * c * bs), dim3(128), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+        hipLaunchKernelGGL(msm_bitsum_kernel<128>, dim3(slices * c * bs), dim3(128), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
+                           fixed ? 16u : 4u, ws->bit_sum);
     else
-        hipLaunchKernelGGL(msm_bitsum_kernel<64>, dim3(slices * c * bs), dim3(64), 0, ts, ws->part, parts, nb, c, bs, ws->bit_sum);
+        hipLaunchKernelGGL(msm_bitsum_kernel<64>, dim3(slices * c * bs), dim3(64), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
+                           fixed ? 16u : 4u, ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * bs * sizeof(G1X),
                           hipMemcpyDeviceToHost, ts);
