@@ -52,6 +52,14 @@ static constexpr uint32_t SORT_LDS_BUCKETS = 8192;  // 32 KiB of LDS counters pe
 #endif
 static constexpr uint32_t SEG0 = ZK_SEG0;  // entries per accumulate lane
 static constexpr uint32_t GA = ZK_GA;      // slots per first-level gather lane
+#ifndef ZK_GLANES
+#define ZK_GLANES 16
+#endif
+static constexpr uint32_t GLANES_FIXED = ZK_GLANES;  // lanes per bucket in the second-level gather (fixed-base mode)
+#ifndef ZK_GSHARE
+#define ZK_GSHARE 64
+#endif
+static constexpr uint32_t GSHARE = ZK_GSHARE;         // first-level partials per (bucket, part) group; a bucket uses ceil(partials / GSHARE) parts
 static constexpr uint32_t PAD = SEG0 * GA;  // bucket ranges are padded to multiples of PAD entries
 
 struct MsmBatch {
@@ -633,9 +641,12 @@ __global__ void msm_clear_kernel(G1X29S* __restrict__ p, uint32_t m, uint32_t* _
 
 #ifdef ZK_TAIL_TRACE  // tools/ubench_tail.hip: where a bit-sum workgroup spends its time (100 MHz wall clock stamps)
 __device__ unsigned long long zk_tail_trace[16];
+__device__ unsigned long long zk_wg_trace[3][8192];  // per-workgroup begin / middle / end of the last traced kernel
 #define ZK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) zk_tail_trace[i] = wall_clock64(); } while (0)
+#define ZK_WG_STAMP(i) do { if (blockIdx.x < 8192 && threadIdx.x == 0) zk_wg_trace[i][blockIdx.x] = wall_clock64(); } while (0)
 #else
 #define ZK_STAMP(i) do { } while (0)
+#define ZK_WG_STAMP(i) do { } while (0)
 #endif
 
 // ---- reduction tails.  The partial sums stay on the carry-free 29-bit-limb field (ec29.hip.h: 3 300 instructions per
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
         b = gid - p * nbk;
         const uint32_t s0 = bucket_start[b] / PAD, s1 = bucket_start[b + 1] / PAD;
         const uint32_t len = s1 - s0;
-        const uint32_t used = min(parts, (len + 4 * LANES - 1) / (4 * LANES));
+        const uint32_t used = min(parts, (len + GSHARE - 1) / GSHARE);
         if (p < used) {
             active = true;
             const uint32_t share = (len + used - 1) / used;
@@ -694,6 +705,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
     // the serial part (lanes stride over the share) and the shuffle tree feed the same addition
     int off = LANES >> 1;
     ZK_STAMP(8);
+    ZK_WG_STAMP(0);
 #pragma unroll 1
     for (;;) {
         G1X29 v;
@@ -704,7 +716,10 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
             s += LANES;
         } else {
             if (off == 0) break;
-            if (off == (int)(LANES >> 1)) ZK_STAMP(9);
+            if (off == (int)(LANES >> 1)) {
+                ZK_STAMP(9);
+                ZK_WG_STAMP(1);
+            }
             v = g1x29_shfl_down(acc, off);  // every lane of the wave takes part in the shuffles
             have = (int)lane < off;
             off >>= 1;
@@ -712,6 +727,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
         if (have) g1x29_add(acc, v);
     }
     ZK_STAMP(10);
+    ZK_WG_STAMP(2);
     if (active && lane == 0) g1x29_store(part + (size_t)b * parts + p, acc);
 }
 
@@ -741,7 +757,7 @@ static uint32_t bitsum_split(uint32_t nb) {
 template <uint32_t THREADS>
 __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __restrict__ part, uint32_t parts, uint32_t nb,
                                                              uint32_t c, uint32_t split, const uint32_t* __restrict__ bucket_start,
-                                                             uint32_t group_lanes, G1X* __restrict__ out) {
+                                                             G1X* __restrict__ out) {
     __shared__ G1X29S sh[THREADS / 64];
     const uint32_t q = blockIdx.x % split;
     const uint32_t st = blockIdx.x / split;
@@ -755,7 +771,7 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
     // parts of a bucket the gather kernel wrote (the others are identity and not worth a round trip to memory)
     const auto used_parts = [&](uint32_t b) {
         const uint32_t len = bucket_start[b + 1] / PAD - bucket_start[b] / PAD;
-        return min(parts, (len + 4 * group_lanes - 1) / (4 * group_lanes));
+        return min(parts, (len + GSHARE - 1) / GSHARE);
     };
     const auto multiplier = [&](uint32_t ii) { return t + 1 < c ? (((ii >> t) << (t + 1)) | (1u << t) | (ii & ((1u << t) - 1))) : nb; };
     uint32_t used = 0;
@@ -1027,7 +1043,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
                            ws->partial);
         const uint32_t ngroups = nbt * parts;
         if (fixed)
-            hipLaunchKernelGGL(msm_gather_kernel<16>, dim3((ngroups * 16 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
+            hipLaunchKernelGGL(msm_gather_kernel<GLANES_FIXED>, dim3((ngroups * GLANES_FIXED + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
                                ws->partial, parts, ngroups, ws->part);
         else
             hipLaunchKernelGGL(msm_gather_kernel<4>, dim3((ngroups * 4 + 255) / 256), dim3(256), 0, ts, ws->bucket_start,
@@ -1036,16 +1052,16 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     const uint32_t bt = bitsum_threads(nb), bs = bitsum_split(nb);
     if (bt == 512)
         hipLaunchKernelGGL(msm_bitsum_kernel<512>, dim3(slices * c * bs), dim3(512), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
-                           fixed ? 16u : 4u, ws->bit_sum);
+                           ws->bit_sum);
     else if (bt == 256)
         hipLaunchKernelGGL(msm_bitsum_kernel<256>, dim3(slices * c * bs), dim3(256), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
-                           fixed ? 16u : 4u, ws->bit_sum);
+                           ws->bit_sum);
     else if (bt == 128)
         hipLaunchKernelGGL(msm_bitsum_kernel<128>, dim3(slices * c * bs), dim3(128), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
-                           fixed ? 16u : 4u, ws->bit_sum);
+                           ws->bit_sum);
     else
         hipLaunchKernelGGL(msm_bitsum_kernel<64>, dim3(slices * c * bs), dim3(64), 0, ts, ws->part, parts, nb, c, bs, ws->bucket_start,
-                           fixed ? 16u : 4u, ws->bit_sum);
+                           ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)slices * c * bs * sizeof(G1X),
                           hipMemcpyDeviceToHost, ts);
