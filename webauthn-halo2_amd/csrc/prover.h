@@ -135,7 +135,10 @@ struct EvalItem {
     const Fr* poly;
     uint64_t pad_;
     Fr x;
-    Fr y;  // x^(threads of the launch), filled by launch_eval_batch
+    // filled by launch_eval_batch: x^(2^l), l < 8; y = x^256; z^(2^l), l < 9, with z = x^(coefficients per workgroup)
+    Fr pw[8];
+    Fr y;
+    Fr zpw[9];
 };
 void launch_eval_batch(EvalItem* h_items, EvalItem* d_items, uint32_t count, uint32_t n, Fr* scratch, Fr* out,
                        hipStream_t st);
