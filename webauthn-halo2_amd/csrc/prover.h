@@ -75,11 +75,11 @@ struct QuotientArgs {
     const Fr* lk_in[MAX_LOOKUPS]; // A >= 2: lookup advice coset; A == 1: unused (q_lookup * adv[0])
     const Fr *l0, *l_last, *l_active;
     const Fr* xs;                 // zeta * w_ext^i: the coset points
-    Fr beta, gamma, delta;
-    Fr t_inv[4];                  // 1 / ((zeta w_ext^i)^n - 1), period 4
+    Fr beta, gamma, delta;        // times 32 (the kernel's internal form, quotient.hip)
+    Fr t_inv[4];                  // 1 / ((zeta w_ext^i)^n - 1), period 4, standard form; all 1 when divide == 0
     uint32_t divide, n_terms;     // divide: multiply by t_inv (divide_by_vanishing_poly); 0: the bare numerator of evaluate_h
     Fr* out;
-    Fr ypow[MAX_TERMS];           // y^(T-1-j) for term j of the y-combination, T = n_terms
+    Fr ypow[MAX_TERMS];           // 32 y^(T-1-j) for term j of the y-combination, T = n_terms
 };
 // terms of the y-combination: gates, 2 + (chunks - 1) + chunks permutation terms, 5 per lookup
 static constexpr uint32_t quotient_terms(uint32_t n_gate, uint32_t n_chunks, uint32_t n_lookups) {

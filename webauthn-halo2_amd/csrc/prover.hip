@@ -449,22 +449,24 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
     q.l_last = pk->l_last_coset;
     q.l_active = pk->l_active_coset;
     q.xs = xs;
-    q.beta = beta;
-    q.gamma = gamma;
-    q.delta = fr_delta();
+    // the kernel works in the carry-free field's internal form (x * 2^261): its constants are handed over times 32
+    const Fr k32 = fr_from_u64(32);
+    q.beta = fe_mul(beta, k32);
+    q.gamma = fe_mul(gamma, k32);
+    q.delta = fe_mul(fr_delta(), k32);
     // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
     const Fr zn = fe_pow_u64(c->zeta, lay.n);
     const Fr w4 = fe_pow_u64(fr_omega(lay.ext_k), lay.n);
     Fr cur = zn;
-    for (int i = 0; i < 4; i++) {
-        q.t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
+    for (int i = 0; i < 4; i++) {  // standard form: the product by it also converts the row back (quotient.hip); 1 = no division
+        q.t_inv[i] = divide ? fe_inv(fe_sub(cur, Fr::one())) : Fr::one();
         cur = fe_mul(cur, w4);
     }
     q.divide = divide ? 1 : 0;
     q.n_terms = quotient_terms(lay.n_gate, lay.n_chunks, lay.n_lookups);
     if (q.n_terms > MAX_TERMS) return ZK_EINVAL;
-    Fr yp = Fr::one();
-    for (uint32_t j = q.n_terms; j-- > 0;) {  // ypow[j] = y^(T - 1 - j)
+    Fr yp = k32;
+    for (uint32_t j = q.n_terms; j-- > 0;) {  // ypow[j] = 32 y^(T - 1 - j)
         q.ypow[j] = yp;
         yp = fe_mul(yp, y);
     }
