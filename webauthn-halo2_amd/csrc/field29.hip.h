@@ -206,6 +206,38 @@ __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
     return r;
 }
 
+// sum_{j < K} a[j] * b[j] * 2^-261 mod p with ONE Montgomery reduction (81 (K + 1) instead of 162 K multiply-adds).
+// All operands normalised (limbs < 2^29): a column is at most 9 K + 9 products < 2^58, so K <= 5.  Value bounds:
+// sum_j k_a[j] k_b[j] <= 168 for a result < 2p.
+template <int K, class PRM>
+__device__ __forceinline__ Fe29<PRM> mulKadd29(const Fe29<PRM> (&a)[K], const Fe29<PRM> (&b)[K]) {
+    static_assert(K >= 1 && K <= 5, "a column of 9 K + 9 products of 58 bits must fit 64 bits");
+    uint32_t m[9];
+    Fe29<PRM> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+#pragma unroll
+            for (int i = (k > 8 ? k - 8 : 0); i <= (k < 9 ? k : 8); i++) acc += (uint64_t)a[j].l[i] * b[j].l[k - i];
+        }
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+            m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
+            acc += (uint64_t)m[k] * Lim29<PRM>::P[0];
+        } else {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
+            r.l[k - 9] = (uint32_t)acc & M29;
+        }
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
 // ---- two independent products with their multiply-add chains interleaved.  A column of mul29 is ONE chain of dependent
 // v_mad_u64_u32 (~9.6 cycles each for a lone wave, against ~5 when independent): kernels that run at one wave per SIMD
 // (the MSM reduction tails) take pairs of independent products through these instead.  Same results as mul29 / sqr29.

@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include "prover.h"
+#include "field29.hip.h"
+#include "hostutil.h"
 
 namespace zk {
 
@@ -34,23 +36,50 @@ void launch_mul(Fr* out, const Fr* a, const Fr* b, uint32_t n, hipStream_t st) {
     hipLaunchKernelGGL(mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, a, b, n);
 }
 
-// out[i] = sum_j c[j] * in[j][i]  (+ out[i] if accumulate); in[j] may be shorter than n (zero-padded)
-__global__ void lincomb_kernel(LincombArgs a) {
+// out[i] = sum_j c[j] * in[j][i]  (+ out[i] if accumulate); in[j] may be shorter than n (zero-padded).
+// On the carry-free field (field29.hip.h), lazily: a value is taken as the plain limbs of its standard form (which is the
+// internal form of v / 32), the coefficients arrive times 32, so that a product is the standard form of c v again — nothing
+// to convert — and four products share one Montgomery reduction.  The sum stays below 168 p (at most 40 inputs) and one
+// last product by 2^261 (the identity of this product) brings it below 2p.
+__global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs a) {
+    typedef Fe29<FrParams> Fr29;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    Fr acc = a.accumulate ? fe_load(a.out + i) : Fr::zero();
-    for (uint32_t j = 0; j < a.count; j++) {
-        if (i < a.len[j]) {
-            const Fr v = fe_load(a.in[j] + i);
-            acc = fe_add(acc, a.unit[j] ? v : fe_mul(v, a.c[j]));
+    Fr29 zero;
+#pragma unroll
+    for (int l = 0; l < 9; l++) zero.l[l] = 0;
+    auto get = [&](uint32_t j) { return i < a.len[j] ? to29(fe_load(a.in[j] + i)) : zero; };  // (1 ; 29)
+    Fr29 acc = a.accumulate ? to29(fe_load(a.out + i)) : zero;
+    uint32_t j = 0;
+    // units first come as they are; products in groups of four (the host orders nothing: runs are taken as they come)
+#pragma unroll 1
+    while (j < a.count) {
+        if (a.unit[j]) {
+            acc = norm29(add29(acc, get(j)));
+            j++;
+        } else if (j + 4 <= a.count && !a.unit[j + 1] && !a.unit[j + 2] && !a.unit[j + 3]) {
+            const Fr29 v[4] = {get(j), get(j + 1), get(j + 2), get(j + 3)};
+            const Fr29 c[4] = {to29(a.c[j]), to29(a.c[j + 1]), to29(a.c[j + 2]), to29(a.c[j + 3])};
+            acc = norm29(add29(acc, mulKadd29<4>(v, c)));   // 4 <= 168: < 2p
+            j += 4;
+        } else {
+            acc = norm29(add29(acc, mul29(get(j), to29(a.c[j]))));
+            j++;
         }
     }
-    if (i == 0 && a.sub0) acc = fe_sub(acc, a.sub0_val);
-    if (i < a.sub_low_n) acc = fe_sub(acc, a.sub_low[i]);
-    fe_store(a.out + i, acc);
+    // at most 40 terms of about p each + the old value + 2p per subtraction: below 48 p
+    if (i == 0 && a.sub0) acc = norm29(sub29<2, 29>(acc, to29(a.sub0_val)));
+    if (i < a.sub_low_n) acc = norm29(sub29<2, 29>(acc, to29(a.sub_low[i])));
+    Fr r = from29(mul29(acc, const_pow2_29<261, FrParams>()));  // value bound <= 48
+    reduce_once(r);
+    fe_store(a.out + i, r);
 }
 void launch_lincomb(const LincombArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(lincomb_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    LincombArgs b = a;
+    const Fr k32 = fr_from_u64(32);
+    for (uint32_t j = 0; j < b.count; j++)
+        if (!b.unit[j]) b.c[j] = fe_mul(b.c[j], k32);  // the kernel's products divide by 32 (see above)
+    hipLaunchKernelGGL(lincomb_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b);
 }
 
 __global__ void scale_kernel(Fr* a, Fr c, uint32_t n) {
