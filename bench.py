@@ -326,7 +326,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,  # BASELINE.json "published" is {}: the only reference number (14.846 s/proof, M1 Pro, README.md:38) is other hardware
             "host_setup": {"synthesize_s_per_job": round(wl.synth_s, 3), "keygen_s": round(wl.keygen_s, 3)},
-            "dtype": "u256-montgomery (8x32-bit limbs; 9x29-bit carry-free limbs in the bucket accumulation)",
+            "dtype": "u256-montgomery (9x29-bit carry-free limbs in the hot kernels: bucket accumulation, NTT, reduction tails, quotient; 8x32-bit limbs elsewhere and in memory)",
             "data": "synthetic",
             "config": {"workload": WORKLOAD, "k": K, "transcript": "blake2b", "multiopen": "shplonk", "proof_bytes": 960,
                        "parallelism": "replicas:%d (one independent proof stream per GPU, no collective)" % world},
