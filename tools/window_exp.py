@@ -1,0 +1,45 @@
+"""MSM window bits (ZK_OPT_MSM_WINDOW, 0 = automatic) against single-proof time and two-pipeline throughput at k=19."""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import webauthn_halo2_amd as zk
+from webauthn_halo2_amd import batch, circuit, engine as E
+
+p = circuit.K19
+jobs = list(range(4))
+wit = batch.synthesize_jobs(p, jobs)
+fixed, copies = batch.structure(p)
+
+
+def mk(b):
+    def factory(dev):
+        e = zk.Engine(dev)
+        e.set_option(E.ZK_OPT_MSM_WINDOW, b)
+        return e
+    return factory
+
+
+for b in [int(x) for x in (sys.argv[1:] or ["0", "14"])]:
+    pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=mk(b)) for _ in range(2)]
+    for pl in pipes:
+        for j in jobs:
+            pl.load(j, wit[j])
+    for pl in pipes:
+        pl.prove(0, keep=True)
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter(); pipes[0].prove(1, keep=True); ts.append((time.perf_counter() - t0) * 1e3)
+    te = []
+    for _ in range(4):
+        t0 = time.perf_counter(); pipes[0].prove(1, E.ZK_TRANSCRIPT_EVM, keep=True); te.append((time.perf_counter() - t0) * 1e3)
+    reps = 40
+
+    def work(pl):
+        for i in range(reps):
+            pl.prove(jobs[i % 4], keep=True)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(pl,)) for pl in pipes]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    print("msm window %d: single %.2f ms  evm %.2f ms  two pipelines %.1f proofs/s" % (b, min(ts), min(te), 2 * reps / dt), flush=True)
+    for pl in pipes:
+        pl.close()
