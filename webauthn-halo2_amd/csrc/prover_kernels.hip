@@ -694,7 +694,10 @@ void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t 
 // over chunks carry_t = c_{t+1} + z^L carry_{t+1}, (3) replay each chunk from its carry.
 // Up to KD_MAX_BATCH independent divisions per launch (blockIdx.y): SHPLONK divides every rotation
 // set's polynomial by that set's next point in the same step.  q may be p (in place).
-static constexpr uint32_t KD_L = 32;
+#ifndef ZK_KD_L
+#define ZK_KD_L 8
+#endif
+static constexpr uint32_t KD_L = ZK_KD_L;  // power of two; 8: 4x the lanes of 32 (a 2^19 division is 65 536 Horner chains of 8 instead of 16 384 of 32: -0.1 ms per k=19 proof, -0.3 ms at k=15..17), top level still <= 1024 blocks up to 2^21
 static constexpr uint32_t KD_BLK = 256;
 
 struct KdPtrs {
