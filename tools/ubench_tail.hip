@@ -1,6 +1,6 @@
 // ubench_tail.hip — what one general XYZZ addition on the carry-free field costs a LONE wave (the MSM reduction tails run
 // at one or two waves per SIMD): pure register loop, with and without the 37-word shuffle of a tree step.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I webauthn-halo2_amd/csrc [-DZK_TAIL_ILP=0] tools/ubench_tail.hip -o tools/ubench_tail
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I webauthn-halo2_amd/csrc tools/ubench_tail.hip -o tools/ubench_tail
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -205,75 +205,34 @@ __device__ __forceinline__ void g1x29_dbl_rare(G1X29& p) {
 
 // acc += b, both XYZZ partial sums in internal form (add-2008-s), all special cases handled; the products are inlined,
 // so a kernel should have ONE call site (3 300 instructions).  Bounds in and out as in the header (X < 9p, Y < 5p).
-// ZK_TAIL_ILP: independent products go in interleaved pairs (field29.hip.h mul29x2): the tails run at one wave per SIMD,
-// where a single chain of dependent multiply-adds is latency-bound.  ZK_TAIL_CALLS: products out of line (small code).
-#ifndef ZK_TAIL_ILP
-#define ZK_TAIL_ILP 1
-#endif
-#ifndef ZK_TAIL_CALLS
-#define ZK_TAIL_CALLS 0
-#endif
-#if ZK_TAIL_CALLS
-#define ZK_TMUL(a, b) mul29_call(a, b)
-#define ZK_TSQR(a) mul29_call(a, a)
-#else
-#define ZK_TMUL(a, b) mul29(a, b)
-#define ZK_TSQR(a) sqr29(a)
-#endif
 __device__ __forceinline__ void g1x29_add(G1X29& acc, const G1X29& b) {
     if (b.inf) return;
     if (acc.inf) {
         acc = b;
         return;
     }
-#if ZK_TAIL_ILP
-    Fq29 u1, u2, s1, s2, zt, zzt, pp, rr, ppp, q;
-    mul29x2(acc.x, b.zz, b.x, acc.zz, u1, u2);                             // 18
-    mul29x2(acc.y, b.zzz, b.y, acc.zzz, s1, s2);                           // 10
+    const Fq29 u1 = mul29(acc.x, b.zz);                                    // 18
+    const Fq29 u2 = mul29(b.x, acc.zz);
+    const Fq29 s1 = mul29(acc.y, b.zzz);                                   // 10
+    const Fq29 s2 = mul29(b.y, acc.zzz);
     const Fq29 p = norm29(sub29<3, 29>(u2, u1));                           // (5 ; 29)
     const Fq29 r = norm29(sub29<3, 29>(s2, s1));                           // (5 ; 29)
-    sqr29x2(p, r, pp, rr);                                                 // 25
+    const Fq29 pp = sqr29(p);                                              // 25
+    const Fq29 rr = sqr29(r);                                              // 25
     if (is_zero29(pp)) {                                                   // same x: doubling or cancellation
         if (is_zero29(rr)) g1x29_dbl_rare(acc);
         else acc = g1x29_identity();
         return;
     }
-    mul29x2(acc.zz, b.zz, acc.zzz, b.zzz, zt, zzt);                        // 4
-    mul29x2(p, pp, u1, pp, ppp, q);                                        // 10, 4
+    const Fq29 ppp = mul29(p, pp);                                         // 10
+    const Fq29 q = mul29(u1, pp);                                          // 4
     const Fq29 t = add29(ppp, add29(q, q));                                // (6 ; < 3 * 2^29)
     const Fq29 x3 = norm29(sub29<7, 31>(rr, t));                           // (9 ; 29)
     const Fq29 v = sub29<10, 29>(q, x3);                                   // (12 ; 30.6)
-    acc.y = mul2add29_ilp(r, v, s1, sub29<3, 29>(zero29(), ppp));          // 5 * 12 + 2 * 3 = 66: (2 ; 29)
-    acc.x = x3;
-    mul29x2(zt, pp, zzt, ppp, acc.zz, acc.zzz);
-#else
-    const Fq29 u1 = ZK_TMUL(acc.x, b.zz);                                  // 18
-    const Fq29 u2 = ZK_TMUL(b.x, acc.zz);
-    const Fq29 s1 = ZK_TMUL(acc.y, b.zzz);                                 // 10
-    const Fq29 s2 = ZK_TMUL(b.y, acc.zzz);
-    const Fq29 p = norm29(sub29<3, 29>(u2, u1));                           // (5 ; 29)
-    const Fq29 r = norm29(sub29<3, 29>(s2, s1));                           // (5 ; 29)
-    const Fq29 pp = ZK_TSQR(p);                                            // 25
-    if (is_zero29(pp)) {                                                   // same x: doubling or cancellation
-        if (is_zero29(mul29_call(r, r))) g1x29_dbl_rare(acc);
-        else acc = g1x29_identity();
-        return;
-    }
-    const Fq29 ppp = ZK_TMUL(p, pp);                                       // 10
-    const Fq29 q = ZK_TMUL(u1, pp);                                        // 4
-    const Fq29 rr = ZK_TSQR(r);                                            // 25
-    const Fq29 t = add29(ppp, add29(q, q));                                // (6 ; < 3 * 2^29)
-    const Fq29 x3 = norm29(sub29<7, 31>(rr, t));                           // (9 ; 29)
-    const Fq29 v = sub29<10, 29>(q, x3);                                   // (12 ; 30.6)
-#if ZK_TAIL_CALLS
-    acc.y = norm29(sub29<3, 29>(mul29_call(r, v), mul29_call(s1, ppp)));   // (5 ; 29)
-#else
     acc.y = mul2add29(r, v, s1, sub29<3, 29>(zero29(), ppp));              // 5 * 12 + 2 * 3 = 66: (2 ; 29)
-#endif
     acc.x = x3;
-    acc.zz = ZK_TMUL(ZK_TMUL(acc.zz, b.zz), pp);
-    acc.zzz = ZK_TMUL(ZK_TMUL(acc.zzz, b.zzz), ppp);
-#endif
+    acc.zz = mul29(mul29(acc.zz, b.zz), pp);
+    acc.zzz = mul29(mul29(acc.zzz, b.zzz), ppp);
 }
 
 // The point held by lane (lane + off) mod 64.  One source address for all 37 words and raw ds_bpermute, so that the

@@ -238,132 +238,6 @@ __device__ __forceinline__ Fe29<PRM> mulKadd29(const Fe29<PRM> (&a)[K], const Fe
     return r;
 }
 
-// ---- two independent products with their multiply-add chains interleaved.  A column of mul29 is ONE chain of dependent
-// v_mad_u64_u32 (~9.6 cycles each for a lone wave, against ~5 when independent): kernels that run at one wave per SIMD
-// (the MSM reduction tails) take pairs of independent products through these instead.  Same results as mul29 / sqr29.
-template <class PRM>
-__device__ __forceinline__ void mul29x2(const Fe29<PRM>& a, const Fe29<PRM>& b, const Fe29<PRM>& c, const Fe29<PRM>& d,
-                                        Fe29<PRM>& r0, Fe29<PRM>& r1) {
-    uint32_t m0[9], m1[9];
-    uint64_t acc0 = 0, acc1 = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) {
-            acc0 += (uint64_t)a.l[i] * b.l[k - i];
-            acc1 += (uint64_t)c.l[i] * d.l[k - i];
-        }
-#pragma unroll
-        for (int i = 0; i < k; i++) {
-            acc0 += (uint64_t)m0[i] * Lim29<PRM>::P[k - i];
-            acc1 += (uint64_t)m1[i] * Lim29<PRM>::P[k - i];
-        }
-        m0[k] = ((uint32_t)acc0 * Lim29<PRM>::INV) & M29;
-        m1[k] = ((uint32_t)acc1 * Lim29<PRM>::INV) & M29;
-        acc0 += (uint64_t)m0[k] * Lim29<PRM>::P[0];
-        acc1 += (uint64_t)m1[k] * Lim29<PRM>::P[0];
-        acc0 >>= 29;
-        acc1 >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc0 += (uint64_t)a.l[i] * b.l[k - i];
-            acc1 += (uint64_t)c.l[i] * d.l[k - i];
-        }
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc0 += (uint64_t)m0[i] * Lim29<PRM>::P[k - i];
-            acc1 += (uint64_t)m1[i] * Lim29<PRM>::P[k - i];
-        }
-        r0.l[k - 9] = (uint32_t)acc0 & M29;
-        r1.l[k - 9] = (uint32_t)acc1 & M29;
-        acc0 >>= 29;
-        acc1 >>= 29;
-    }
-    r0.l[8] = (uint32_t)acc0;
-    r1.l[8] = (uint32_t)acc1;
-}
-
-template <class PRM>
-__device__ __forceinline__ void sqr29x2(const Fe29<PRM>& a, const Fe29<PRM>& c, Fe29<PRM>& r0, Fe29<PRM>& r1) {
-    uint32_t m0[9], m1[9], a2[9], c2[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        a2[i] = a.l[i] << 1;
-        c2[i] = c.l[i] << 1;
-    }
-    uint64_t acc0 = 0, acc1 = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-#pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) {
-            acc0 += (uint64_t)a2[i] * a.l[k - i];
-            acc1 += (uint64_t)c2[i] * c.l[k - i];
-        }
-        if ((k & 1) == 0) {
-            acc0 += (uint64_t)a.l[k / 2] * a.l[k / 2];
-            acc1 += (uint64_t)c.l[k / 2] * c.l[k / 2];
-        }
-        if (k < 9) {
-#pragma unroll
-            for (int i = 0; i < k; i++) {
-                acc0 += (uint64_t)m0[i] * Lim29<PRM>::P[k - i];
-                acc1 += (uint64_t)m1[i] * Lim29<PRM>::P[k - i];
-            }
-            m0[k] = ((uint32_t)acc0 * Lim29<PRM>::INV) & M29;
-            m1[k] = ((uint32_t)acc1 * Lim29<PRM>::INV) & M29;
-            acc0 += (uint64_t)m0[k] * Lim29<PRM>::P[0];
-            acc1 += (uint64_t)m1[k] * Lim29<PRM>::P[0];
-        } else {
-#pragma unroll
-            for (int i = k - 8; i < 9; i++) {
-                acc0 += (uint64_t)m0[i] * Lim29<PRM>::P[k - i];
-                acc1 += (uint64_t)m1[i] * Lim29<PRM>::P[k - i];
-            }
-            r0.l[k - 9] = (uint32_t)acc0 & M29;
-            r1.l[k - 9] = (uint32_t)acc1 & M29;
-        }
-        acc0 >>= 29;
-        acc1 >>= 29;
-    }
-    r0.l[8] = (uint32_t)acc0;
-    r1.l[8] = (uint32_t)acc1;
-}
-
-// mul2add29 with the two products on separate accumulators (joined once per column)
-template <class PRM>
-__device__ __forceinline__ Fe29<PRM> mul2add29_ilp(const Fe29<PRM>& a, const Fe29<PRM>& b, const Fe29<PRM>& c, const Fe29<PRM>& d) {
-    uint32_t m[9];
-    Fe29<PRM> r;
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-        uint64_t side = 0;
-#pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 9 ? k : 8); i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            side += (uint64_t)c.l[i] * d.l[k - i];
-        }
-        if (k < 9) {
-#pragma unroll
-            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
-            acc += side;
-            m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
-            acc += (uint64_t)m[k] * Lim29<PRM>::P[0];
-        } else {
-#pragma unroll
-            for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * Lim29<PRM>::P[k - i];
-            acc += side;
-            r.l[k - 9] = (uint32_t)acc & M29;
-        }
-        acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
-    return r;
-}
-
 template <class PRM>
 __device__ __forceinline__ Fe29<PRM> add29(const Fe29<PRM>& a, const Fe29<PRM>& b) {
     Fe29<PRM> r;
