@@ -295,6 +295,31 @@ def _pp(arrs):
     return t
 
 
+def evaluate_h(pk, adv_e, z_e, lk_e, beta, gamma, y, divide=True):
+    """Evaluator::evaluate_h followed by divide_by_vanishing_poly over the extended coset (oracle.c orc_quotient).
+    adv_e / z_e: extended-coset arrays (N, 4) in Montgomery form; lk_e: [(a'_e, s'_e, z_e)] per lookup; challenges as ints.
+    The arrays need not come from a satisfied circuit: the row expression is evaluated as it stands."""
+    sh = pk.shape
+    k, n, ext_k = sh.k, sh.n, sh.ext_k
+    N = 1 << ext_k
+    fx_sel = (ctypes.c_int32 * sh.n_gate)(*[-1 if s is None else s for s in sh.fx_sel])
+    perm_val = [(pk.fix_e[c[1]] if c[0] == "fixed" else adv_e[c[1]]) for c in sh.perm_cols]
+    delta_pow = arr([pow(DELTA, p, R) for p in range(len(sh.perm_cols))])
+    step = 1 << (ext_k - k)
+    xs0 = [ZETA * pow(omega(ext_k), i, R) % R for i in range(step)]
+    tinv = arr([inv((pow(x, n, R) - 1) % R, R) if divide else 1 for x in xs0])
+    hvals = np.empty((N, 4), dtype=np.uint64)
+    keep = [_pp(adv_e), _pp(pk.fix_e), _pp(pk.sig_e), _pp(perm_val), _pp(z_e), _pp([t[2] for t in lk_e]), _pp([t[0] for t in lk_e]),
+            _pp([t[1] for t in lk_e]), _pp([None if sh.single else adv_e[sh.n_gate + l] for l in range(sh.n_lookups)])]
+    rc = _lib().orc_quotient(ext_k, sh.n_gate, sh.n_chunks, sh.chunk_len, len(sh.perm_cols), sh.n_lookups, 1 if sh.single else 0,
+                             sh.fx_table, sh.fx_qlookup or 0, sh.last_rot,
+                             keep[0], keep[1], fx_sel, keep[2], keep[3], keep[4], keep[5], keep[6], keep[7], keep[8],
+                             P(pk.l0_e), P(pk.llast_e), P(pk.lblind_e), P(pk.xs), P(m1(beta)), P(m1(gamma)), P(m1(y)), P(delta_pow), P(tinv),
+                             P(hvals), NT)
+    assert rc == 0
+    return hvals
+
+
 def create_proof(pk, advice, rng, kind="evm", scheme=None, committer=None, timings=None):
     """advice: [n_adv] of (n, 4) Montgomery arrays (rows >= usable are overwritten by blinding in a copy) or lists of
     ints.  `rng` is a zkoracle.hashes.ChaCha20Rng (one block per Fr::random).  Returns the proof bytes."""
@@ -405,21 +430,7 @@ def create_proof(pk, advice, rng, kind="evm", scheme=None, committer=None, timin
         d["ap_e"], d["sp_e"], d["z_e"] = coeff_to_extended(d["ap_c"], ext_k), coeff_to_extended(d["sp_c"], ext_k), coeff_to_extended(d["z_c"], ext_k)
     lap("fft", t0)
     t0 = time.time()
-    fx_sel = (ctypes.c_int32 * sh.n_gate)(*[-1 if s is None else s for s in sh.fx_sel])
-    perm_val = [(pk.fix_e[c[1]] if c[0] == "fixed" else adv_e[c[1]]) for c in sh.perm_cols]
-    delta_pow = arr([pow(DELTA, p, R) for p in range(len(sh.perm_cols))])
-    step = 1 << (ext_k - k)
-    xs0 = [ZETA * pow(omega(ext_k), i, R) % R for i in range(step)]
-    tinv = arr([inv((pow(x, n, R) - 1) % R, R) for x in xs0])
-    hvals = np.empty((N, 4), dtype=np.uint64)
-    keep = [_pp(adv_e), _pp(pk.fix_e), _pp(pk.sig_e), _pp(perm_val), _pp(z_e), _pp([d["z_e"] for d in lk]), _pp([d["ap_e"] for d in lk]),
-            _pp([d["sp_e"] for d in lk]), _pp([None if sh.single else adv_e[sh.n_gate + l] for l in range(sh.n_lookups)])]
-    rc = _lib().orc_quotient(ext_k, sh.n_gate, sh.n_chunks, sh.chunk_len, len(sh.perm_cols), sh.n_lookups, 1 if sh.single else 0,
-                             sh.fx_table, sh.fx_qlookup or 0, sh.last_rot,
-                             keep[0], keep[1], fx_sel, keep[2], keep[3], keep[4], keep[5], keep[6], keep[7], keep[8],
-                             P(pk.l0_e), P(pk.llast_e), P(pk.lblind_e), P(pk.xs), P(m1(beta)), P(m1(gamma)), P(m1(y)), P(delta_pow), P(tinv),
-                             P(hvals), NT)
-    assert rc == 0
+    hvals = evaluate_h(pk, adv_e, z_e, [(d["ap_e"], d["sp_e"], d["z_e"]) for d in lk], beta, gamma, y)
     lap("evaluate_h", t0)
     t0 = time.time()
     h_coeff = extended_to_coeff(hvals, ext_k)

@@ -39,6 +39,20 @@ def test_ntt_matches_oracle(engine, log_n):
     del rng
 
 
+@pytest.mark.parametrize("log_n", [9, 14, 17, 19])
+def test_ntt_largest_stored_words(engine, log_n):
+    """The butterflies run lazily on 29-bit limbs (value bounds grow by stage, ntt.hip): the worst operands are the largest
+    stored words.  Every element p - 1 (as stored), and p - 1 alternating with 0, through one, two and three passes."""
+    n = 1 << log_n
+    pm1 = np.array([(F.R - 1) >> (64 * i) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    w = F.omega(log_n)
+    for pattern in ("all", "alt"):
+        a = np.tile(pm1, (n, 1))
+        if pattern == "alt":
+            a[1::2] = 0
+        assert np.array_equal(engine.ntt(a, mont1(w), log_n), cops.ntt(a, w, log_n)), (log_n, pattern)
+
+
 def test_ntt_nonstandard_omega(engine):
     # a 2^6-th root used on a 2^6 domain but not the canonical one (odd power): own twiddle table
     log_n = 6

@@ -400,3 +400,56 @@ def test_quotient_entry_point_matches_oracle_h(engine, name):
     for h in adv + zs + [x for t in lks for x in t] + [out, hx, he] + polys:
         h.free()
     engine.pk_free(pk)
+
+
+@pytest.mark.parametrize("name", ["k17like", "manycols"])
+def test_quotient_rows_on_adversarial_cosets(engine, name):
+    """The quotient kernel computes lazily on 29-bit limbs (value bounds tracked per expression, quotient.hip): its rows must
+    equal the oracle's for ANY operand values, not only those of a satisfied circuit — cosets made of the largest stored
+    words (p - 1), zeros, ones, alternations and random elements, with and without the division by X^n - 1."""
+    from zkoracle import fastprover as fp, field as F
+    A, L, Fx, k, lb = SHAPES[name][:5]
+    p, asg, pk, polys = setup(engine, A, L, Fx, k, lb)
+    sh = plonk.Shape(k, A, L, Fx, lb, 0)
+    opk = fp.keygen(sh, asg.fixed, asg.copies)
+    N = 4 * sh.n
+    rng = np.random.default_rng(7)
+    pm1 = np.array([(F.R - 1) >> (64 * i) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)  # stored words of the largest element
+
+    def make(kind):
+        if kind == "max":
+            return np.tile(pm1, (N, 1))
+        if kind == "zero":
+            return np.zeros((N, 4), dtype=np.uint64)
+        if kind == "one":
+            return cops.fr_mont([1] * N)
+        if kind == "alt":
+            a = np.tile(pm1, (N, 1))
+            a[::2] = 0
+            return a
+        v = np.frombuffer(rng.bytes(N * 32), dtype=np.uint64).reshape(N, 4).copy()
+        v[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return cops.fr_mont(cops.fr_ints(v))  # canonical random elements
+
+    kinds = ["max", "zero", "one", "alt", "rand"]
+    n_adv, n_z, n_lk = sh.n_adv, sh.n_chunks, sh.n_lookups
+    for round_ in range(3):
+        pick = lambda: make(kinds[int(rng.integers(len(kinds)))] if round_ else "max")
+        adv_e = [pick() for _ in range(n_adv)]
+        z_e = [pick() for _ in range(n_z)]
+        lk_e = [(pick(), pick(), pick()) for _ in range(n_lk)]
+        ch = [F.R - 1, F.R - 1, F.R - 1] if round_ == 0 else [int.from_bytes(rng.bytes(31), "little") for _ in range(3)]
+        adv = [engine.poly(N, a) for a in adv_e]
+        zs = [engine.poly(N, a) for a in z_e]
+        lks = [tuple(engine.poly(N, a) for a in t) for t in lk_e]
+        out = engine.poly(N)
+        chm = [cops.fr_mont([c])[0] for c in ch]
+        for divide in (True, False):
+            engine.quotient(pk, adv, zs, lks, *chm, out, divide=divide)
+            want = fp.evaluate_h(opk, adv_e, z_e, lk_e, *ch, divide=divide)
+            assert np.array_equal(engine.download(out), want), (name, round_, divide)
+        for h in adv + zs + [x for t in lks for x in t] + [out]:
+            h.free()
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
