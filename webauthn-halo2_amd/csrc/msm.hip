@@ -35,6 +35,11 @@
 #include <string.h>
 #include <vector>
 
+// This file's products on the carry-free field keep the source order of their multiply-adds (field29.hip.h ZK_MUL29_ASM):
+// the accumulation runs four waves per SIMD (below), enough to hide a serial column, and saves the 64-bit join per column
+#ifndef ZK_MUL29_ASM
+#define ZK_MUL29_ASM 1
+#endif
 #include "ec29.hip.h"
 #include "engine.h"
 
@@ -599,6 +604,14 @@ __global__ void msm_pad_kernel(const uint32_t* __restrict__ totals, const uint32
 
 // Every lane sums one aligned segment of SEG0 entries; bucket ranges are padded to multiples
 // of SEG0, so a segment lies inside ONE bucket and yields one partial sum ("slot").
+// four waves per SIMD (128 registers; the few values that do not fit live in 33 scratch words of the rare paths): needed by the
+// serial multiply-add columns, neutral otherwise
+#ifndef ZK_ACC_WAVES
+#define ZK_ACC_WAVES 4
+#endif
+#if ZK_ACC_WAVES
+__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
                                                             const uint32_t* __restrict__ counts,
