@@ -153,6 +153,12 @@ __device__ __forceinline__ void round0(Fr29& e0, Fr29& e1, Fr29& e2, Fr29& e3, c
 }
 
 template <uint32_t KIN>
+#ifndef ZK_NTT_WAVES
+#define ZK_NTT_WAVES 0
+#endif
+#if ZK_NTT_WAVES
+__attribute__((amdgpu_waves_per_eu(ZK_NTT_WAVES, ZK_NTT_WAVES)))
+#endif
 __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(const NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Fr* __restrict__ vin = a.in[blockIdx.y];
