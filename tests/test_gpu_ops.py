@@ -137,6 +137,44 @@ def test_msm_edge_bases(engine):
     assert cops.jac_to_affine_ints(engine.msm(ones, g)) == cops.jac_to_affine_ints(cops.msm(ones, g))
 
 
+@pytest.mark.parametrize("with_identity", [False, True])
+def test_fixed_base_commit_over_degenerate_srs(engine, with_identity):
+    """The fixed-base (window-table) path over an SRS that holds the same point several times and a P / -P pair: equal
+    scalars put them in one bucket (doubling, cancellation).  A basis without the identity takes the unchecked accumulation
+    loop, which must notice the exceptional step (ZZ = 0 at the end of the segment) and redo the segment on the general
+    formulas; a basis with an identity point takes the checked loop.  Both bases (coefficient and Lagrange) are loaded."""
+    k = 10
+    n = 1 << k
+    rng = random.Random(1234)
+    g = small_srs(n)
+    g[20] = g[21]
+    g[22] = g[21]
+    g[23] = g[21]
+    for i in range(40, 60):   # a run of equal points: many doublings in one segment
+        g[i] = g[40]
+    neg = cops.affine_arr_to_ints(g[30:31])[0]
+    g[31] = cops.to_mont_arr(cops.ints_to_arr([neg[0], (-neg[1]) % F.P]), 1).reshape(8)
+    if with_identity:
+        g[10] = 0
+        g[700] = 0
+    gl = g[::-1].copy()
+    engine.srs_load(k, g, gl)
+    s = rand_fr(rng, n)
+    s[20] = s[21] = s[22] = s[23] = 5
+    for i in range(40, 60):
+        s[i] = 9
+    s[30] = s[31] = 7
+    sm = cops.fr_mont(s)
+    p = engine.poly(n, sm)
+    for basis, arr_ in ((0, g), (1, gl)):
+        got = cops.affine_arr_to_ints(engine.commit(p, basis))[0]
+        assert got == cops.jac_to_affine_ints(cops.msm(sm, arr_)), (with_identity, basis)
+    ones = engine.poly(n, cops.fr_mont([1] * n))
+    assert cops.affine_arr_to_ints(engine.commit(ones, 0))[0] == cops.jac_to_affine_ints(cops.msm(cops.fr_mont([1] * n), g))
+    p.free()
+    ones.free()
+
+
 def test_msm_witness_like_distribution(engine):
     """Hot low buckets: the mix SURVEY.md §8d prescribes for advice columns."""
     rng = random.Random(0x5EED0019)

@@ -34,6 +34,7 @@ struct zk_ctx {
     G1Affine* g_table = nullptr;           // window multiples of g / g_lagrange (fixed-base MSM)
     G1Affine* g_lagrange_table = nullptr;
     uint32_t table_c = 0;
+    bool g_has_identity = true, g_lagrange_has_identity = true;  // set with the tables (msm_bases_have_identity)
     // G2 half of ParamsKZG (g2, s_g2 = [s]G2) as raw Montgomery images x.c0 || x.c1 || y.c0 || y.c1: the engine never
     // computes with it, it only travels through the SRS file (zk_srs_write / zk_srs_read)
     bool g2_valid = false;

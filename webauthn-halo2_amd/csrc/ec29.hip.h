@@ -38,7 +38,9 @@ __device__ __forceinline__ G1X29 g1x29_from_std(const G1X& a) {
 
 // acc += (x, y): an affine point in the standard memory form (canonical words), not the identity.
 // madd-2008-s.  Returns false when the addition is one of the exceptional cases (same x: a doubling
-// or a cancellation), which the caller redoes on the general path; acc is then unchanged.
+// or a cancellation), which the caller redoes on the general path; acc is then unchanged.  CHECK = false skips the test
+// (and always returns true): the caller detects an exceptional step by ZZ = 0 at the end and redoes the whole run.
+template <bool CHECK = true>
 __device__ __forceinline__ bool g1x29_add_affine(G1X29& acc, const Fq& x, const Fq& y) {
     if (acc.inf) {
         acc.x = std_to_internal(x);  // (2 ; 29)
@@ -64,7 +66,9 @@ __device__ __forceinline__ bool g1x29_add_affine(G1X29& acc, const Fq& x, const 
 #else
     const Fq29 pp = mul29(p, p);                                  // 144
 #endif
-    if (is_zero29(pp)) return false;                              // p prime: P = 0 (mod p) <=> P^2 = 0
+    // p prime: P = 0 (mod p) <=> P^2 = 0.  Without CHECK the caller looks at ZZ afterwards: it is a product of the P^2's, zero
+    // from the first exceptional step on
+    if (CHECK && is_zero29(pp)) return false;
     const Fq29 ppp = mul29(p, pp);                                // 24
     const Fq29 q = mul29(acc.x, pp);                              // 18
 #if ZK_EC29_SQR

@@ -53,7 +53,9 @@ hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affi
 hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t batch, const G1Affine* bases, size_t n,
                    hipStream_t st, G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out,
                    hipEvent_t* accum_events = nullptr, const G1Affine* table = nullptr, uint32_t table_stride = 0,
-                   hipStream_t tail_st = nullptr, hipEvent_t head_done = nullptr);
+                   hipStream_t tail_st = nullptr, hipEvent_t head_done = nullptr, bool bases_may_be_identity = true);
+// whether any of the n points is the identity (synchronises `st`): a basis without one takes the unchecked accumulation loop
+hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, bool* out);
 // G1X entries per result in host_window_sums (fixed-base mode)
 uint32_t msm_sums_per_result(uint32_t c);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).

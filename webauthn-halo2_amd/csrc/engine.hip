@@ -171,9 +171,15 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     // commits against the resident SRS use the precomputed window tables
     const G1Affine* table = nullptr;
     uint32_t stride = 0;
+    bool ident = true;  // arbitrary bases: the accumulation tests every operand
     if (c->srs_k >= 0 && c->table_c) {
-        if (d_bases == c->g) table = c->g_table;
-        else if (d_bases == c->g_lagrange) table = c->g_lagrange_table;
+        if (d_bases == c->g) {
+            table = c->g_table;
+            ident = c->g_has_identity;
+        } else if (d_bases == c->g_lagrange) {
+            table = c->g_lagrange_table;
+            ident = c->g_lagrange_has_identity;
+        }
         stride = 1u << c->srs_k;
     }
     int rc = get_msm_ws(c, lane, table ? (size_t)stride : n, &ws);
@@ -182,7 +188,7 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     if (batch > 1 && (!table || batch > msm_ws_max_batch(ws))) return ZK_EINVAL;
     HIPCHK(c, hipEventRecord(L.t_head[0], c->stream));
     HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
-                      L.head_done));
+                      L.head_done, !table || ident));
     HIPCHK(c, hipEventRecord(L.tail_done, L.tail));
     HIPCHK(c, hipEventRecord(L.t_head[1], c->stream));
     c->msm_launches++;
@@ -539,6 +545,8 @@ int srs_build_tables(zk_ctx* c, uint32_t k) {
         return ZK_ENOMEM;
     hipError_t e = msm_build_table(c->g, n, cw, c->g_table, c->stream);
     if (e == hipSuccess) e = msm_build_table(c->g_lagrange, n, cw, c->g_lagrange_table, c->stream);
+    if (e == hipSuccess) e = msm_bases_have_identity(c->g, n, c->stream, &c->g_has_identity);
+    if (e == hipSuccess) e = msm_bases_have_identity(c->g_lagrange, n, c->stream, &c->g_lagrange_has_identity);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         c->last_hip = (int)e;

@@ -88,6 +88,7 @@ struct MsmWorkspace {
     uint32_t coarse_stride;     // words per column in `coarse`
     uint32_t* cursor;           // [max_batch * nb] per-bucket write cursors of the second level
     size_t inter_stride;        // entries per column in `inter`
+    uint32_t* redo;             // [entries / SEG0] segments the unchecked accumulation hands to the checked one
     G1X29S* slot_pt;            // [entries / SEG0]  partial sums stay in the accumulation's internal form (ec29.hip.h)
     G1X29S* partial;            // [entries / PAD]
     G1X29S* part;                  // [nbt * parts]
@@ -604,11 +605,36 @@ __global__ void msm_pad_kernel(const uint32_t* __restrict__ totals, const uint32
 
 // Every lane sums one aligned segment of SEG0 entries; bucket ranges are padded to multiples
 // of SEG0, so a segment lies inside ONE bucket and yields one partial sum ("slot").
-// four waves per SIMD (128 registers; the few values that do not fit live in 33 scratch words of the rare paths): needed by the
-// serial multiply-add columns, neutral otherwise
+// four waves per SIMD (128 registers; the few values that do not fit live in scratch words of the rare paths): needed by the
+// serial multiply-add columns of the addition (field29.hip.h mul29s), neutral otherwise
 #ifndef ZK_ACC_WAVES
 #define ZK_ACC_WAVES 4
 #endif
+// One segment.  SAFE: every addition tests for the identity as an operand and for the exceptional cases (same x as the running
+// sum: a doubling or a cancellation), which are redone on the general formulas — exact for any input.  Otherwise no test at
+// all (4 % faster: it is the branches around the fallback more than the instructions): the caller vouches that no base is the
+// identity and checks the segment's ZZ afterwards.
+template <bool SAFE>
+__device__ __forceinline__ G1X29 accumulate_segment(const uint32_t* __restrict__ e, const G1Affine* __restrict__ bases) {
+    G1X29 acc;
+    acc.inf = true;
+    for (uint32_t k = 0; k < SEG0; k++) {
+        const uint32_t y = e[k];
+        if (y == SKIP_ENTRY) continue;  // padding at the end of a bucket
+        G1Affine p = affine_load(bases + (y & ~SIGN_BIT));
+        if (SAFE && affine_is_identity(p)) continue;
+        if (y & SIGN_BIT) p.y = fe_neg(p.y);
+        if (!g1x29_add_affine<SAFE>(acc, p.x, p.y)) {
+            // same x as the running sum (doubling or cancellation): the general formulas, rarely
+            G1X s = g1x29_to_std(acc);
+            g1x_add_affine(s, p.x, p.y);
+            acc = g1x29_from_std(s);
+        }
+    }
+    return acc;
+}
+
+// Checked kernel: exact for any bases (arbitrary bases of the fine-grained seam; an SRS that holds the identity).
 #if ZK_ACC_WAVES
 __attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
 #endif
@@ -619,25 +645,38 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __re
     const uint32_t total = counts[0];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
-    const uint32_t* e = entries + (size_t)t * SEG0;
     // the running sum lives on the carry-free 29-bit-limb field (ec29.hip.h); bases are read in
     // their standard memory form, the slot is written in the internal one (the reduction tails stay on that field)
-    G1X29 acc;
-    acc.inf = true;
-    for (uint32_t k = 0; k < SEG0; k++) {
-        const uint32_t y = e[k];
-        if (y == SKIP_ENTRY) continue;  // padding at the end of a bucket
-        G1Affine p = affine_load(bases + (y & ~SIGN_BIT));
-        if (affine_is_identity(p)) continue;
-        if (y & SIGN_BIT) p.y = fe_neg(p.y);
-        if (!g1x29_add_affine(acc, p.x, p.y)) {
-            // same x as the running sum (doubling or cancellation): the general formulas, rarely
-            G1X s = g1x29_to_std(acc);
-            g1x_add_affine(s, p.x, p.y);
-            acc = g1x29_from_std(s);
-        }
-    }
+    g1x29_store(slot_pt + t, accumulate_segment<true>(entries + (size_t)t * SEG0, bases));
+}
+
+// Unchecked kernel for a basis without the identity (the resident SRS): no test at all in the loop, and none of the
+// fallback code in the kernel.  An exceptional step leaves ZZ = 0 (ZZ is the product of the squared x-differences and p is
+// prime): such segments are listed (counts[1], redo[]) and msm_accumulate_redo_kernel, which always follows, redoes them with
+// the checked loop — with distinct bases a handful of segments per MSM, if any.
+#if ZK_ACC_WAVES
+__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
+#endif
+__global__ __launch_bounds__(64) void msm_accumulate_fast_kernel(const uint32_t* __restrict__ entries,
+                                                                 const G1Affine* __restrict__ bases,
+                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ redo,
+                                                                 G1X29S* __restrict__ slot_pt) {
+    const uint32_t total = counts[0];  // multiple of SEG0
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * SEG0 >= total) return;
+    const G1X29 acc = accumulate_segment<false>(entries + (size_t)t * SEG0, bases);
+    if (!acc.inf && is_zero29(acc.zz)) redo[atomicAdd(&counts[1], 1u)] = t;  // at most one entry per segment: redo[] has one word each
     g1x29_store(slot_pt + t, acc);
+}
+__global__ __launch_bounds__(64) void msm_accumulate_redo_kernel(const uint32_t* __restrict__ entries,
+                                                                 const G1Affine* __restrict__ bases,
+                                                                 const uint32_t* __restrict__ counts, const uint32_t* __restrict__ redo,
+                                                                 G1X29S* __restrict__ slot_pt) {
+    const uint32_t m = counts[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t t = redo[i];
+        g1x29_store(slot_pt + t, accumulate_segment<true>(entries + (size_t)t * SEG0, bases));
+    }
 }
 
 // start-of-MSM reset in one launch: bucket parts = identity, bucket totals = 0, counts = 0
@@ -871,6 +910,27 @@ __global__ __launch_bounds__(64) void msm_table_step_kernel(const G1Affine* __re
     fe_store(&next[i].y, r.y);
 }
 
+// does any of the n points equal the identity (0, 0)?  Decides which accumulation loop a basis gets (msm_accumulate_kernel).
+__global__ void msm_identity_flag_kernel(const G1Affine* __restrict__ b, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && affine_is_identity(affine_load(b + i))) atomicOr(flag, 1u);
+}
+hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, bool* out) {
+    uint32_t* d = nullptr;
+    hipError_t e = hipMalloc(&d, 4);
+    if (e != hipSuccess) return e;
+    uint32_t h = 0;
+    e = hipMemsetAsync(d, 0, 4, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(msm_identity_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bases, n, d);
+        e = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    *out = h != 0;
+    return e;
+}
+
 hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st) {
     const uint32_t nwin = nwin_for(c);
     hipError_t e = hipMemcpyAsync(table, bases, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToDevice, st);
@@ -936,6 +996,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
         MSM_TRY(hipMalloc(&ws->coarse, (size_t)max_batch * ws->coarse_stride * sizeof(uint32_t)));
         MSM_TRY(hipMalloc(&ws->cursor, (size_t)max_batch * ws->nb * sizeof(uint32_t)));
     }
+    MSM_TRY(hipMalloc(&ws->redo, threads * sizeof(uint32_t)));
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X29S)));
@@ -954,6 +1015,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->inter);
     hipFree(ws->coarse);
     hipFree(ws->cursor);
+    hipFree(ws->redo);
     hipFree(ws->slot_pt);
     hipFree(ws->partial);
     hipFree(ws->part);
@@ -967,7 +1029,8 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
 // any other kernels) on `st` right away.  tail_st == st gives the plain sequential order.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t batch, const G1Affine* bases, size_t n,
                    hipStream_t st, G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events,
-                   const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done) {
+                   const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done,
+                   bool bases_may_be_identity) {
     if (n > ws->max_n || batch == 0 || batch > ws->max_batch) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const bool fixed = table != nullptr;
@@ -1039,8 +1102,15 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
         const size_t worst = (size_t)(fixed ? batch : 1) * n * nwin + (size_t)nbt * (PAD - 1);  // worst-case padded entry count
         const size_t threads = (worst + SEG0 - 1) / SEG0;
         if (accum_events) hipEventRecord(accum_events[0], st);
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                           fixed ? table : bases, ws->counts, ws->slot_pt);
+        if (bases_may_be_identity) {
+            hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
+                               fixed ? table : bases, ws->counts, ws->slot_pt);
+        } else {
+            hipLaunchKernelGGL(msm_accumulate_fast_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
+                               fixed ? table : bases, ws->counts, ws->redo, ws->slot_pt);
+            hipLaunchKernelGGL(msm_accumulate_redo_kernel, dim3(1024), dim3(64), 0, st, ws->entries, fixed ? table : bases,
+                               ws->counts, ws->redo, ws->slot_pt);
+        }
         if (accum_events) hipEventRecord(accum_events[1], st);
     }
     hipStream_t ts = st;
