@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 [ -n "$tag" ] && export ZKMI355_LIB=$R/webauthn-halo2_amd/build/libzkmi355_$tag.so
 mkdir -p $R/$out
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $R/$out/a --output-format csv -- python $R/tools/prof_ops.py 19 3 > $R/$out/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_SALU -d $R/$out/b --output-format csv -- python $R/tools/prof_ops.py 19 3 > $R/$out/b.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $R/$out/a --output-format csv -- python $R/tools/prof_ops.py 19 3 > $R/$out/a.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_SALU -d $R/$out/b --output-format csv -- python $R/tools/prof_ops.py 19 3 > $R/$out/b.log 2>&1
 python - <<PY
 import csv, glob, collections
 for sub in "ab":

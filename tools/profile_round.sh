@@ -6,13 +6,13 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$tag
 mkdir -p $O
 BENCH="python $R/bench.py --no-cpu-baseline --steps 20"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BENCH > $O/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- $BENCH > $O/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bench_write -- $BENCH > $O/bench_write.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BENCH > $O/bench_stats.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- $BENCH > $O/bench_fetch.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bench_write -- $BENCH > $O/bench_write.log 2>&1
 K21="python $R/tools/stress_k21.py 5"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/k21_stats -- $K21 > $O/k21_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/k21_fetch -- $K21 --no-check > $O/k21_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/k21_write -- $K21 --no-check > $O/k21_write.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k21_stats -- $K21 > $O/k21_stats.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/k21_fetch -- $K21 --no-check > $O/k21_fetch.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/k21_write -- $K21 --no-check > $O/k21_write.log 2>&1
 cd $R
 python tools/summarize_prof.py ${tag}_proof_k19 $(dirname $(find $O/bench_stats -name "*kernel_stats.csv" | head -1)) $(dirname $(find $O/bench_fetch -name "*counter_collection.csv" | head -1)) $(dirname $(find $O/bench_write -name "*counter_collection.csv" | head -1))
 python tools/summarize_prof.py ${tag}_k21_stress $(dirname $(find $O/k21_stats -name "*kernel_stats.csv" | head -1)) $(dirname $(find $O/k21_fetch -name "*counter_collection.csv" | head -1)) $(dirname $(find $O/k21_write -name "*counter_collection.csv" | head -1))
