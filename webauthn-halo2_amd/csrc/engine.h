@@ -54,8 +54,9 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
                    hipStream_t st, G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out,
                    hipEvent_t* accum_events = nullptr, const G1Affine* table = nullptr, uint32_t table_stride = 0,
                    hipStream_t tail_st = nullptr, hipEvent_t head_done = nullptr, bool bases_may_be_identity = true);
-// whether any of the n points is the identity (synchronises `st`): a basis without one takes the unchecked accumulation loop
-hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, bool* out);
+// whether any of the n points is the identity (synchronises `st`; d_word / h_word: one device word and one pinned host word of
+// scratch): a basis without one takes the unchecked accumulation loop
+hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, uint32_t* d_word, uint32_t* h_word, bool* out);
 // G1X entries per result in host_window_sums (fixed-base mode)
 uint32_t msm_sums_per_result(uint32_t c);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).

@@ -545,8 +545,9 @@ int srs_build_tables(zk_ctx* c, uint32_t k) {
         return ZK_ENOMEM;
     hipError_t e = msm_build_table(c->g, n, cw, c->g_table, c->stream);
     if (e == hipSuccess) e = msm_build_table(c->g_lagrange, n, cw, c->g_lagrange_table, c->stream);
-    if (e == hipSuccess) e = msm_bases_have_identity(c->g, n, c->stream, &c->g_has_identity);
-    if (e == hipSuccess) e = msm_bases_have_identity(c->g_lagrange, n, c->stream, &c->g_lagrange_has_identity);
+    if (e == hipSuccess) e = msm_bases_have_identity(c->g, n, c->stream, (uint32_t*)c->small, (uint32_t*)c->host_small, &c->g_has_identity);
+    if (e == hipSuccess)
+        e = msm_bases_have_identity(c->g_lagrange, n, c->stream, (uint32_t*)c->small, (uint32_t*)c->host_small, &c->g_lagrange_has_identity);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         c->last_hip = (int)e;

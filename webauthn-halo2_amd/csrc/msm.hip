@@ -915,20 +915,14 @@ __global__ void msm_identity_flag_kernel(const G1Affine* __restrict__ b, uint32_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && affine_is_identity(affine_load(b + i))) atomicOr(flag, 1u);
 }
-hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, bool* out) {
-    uint32_t* d = nullptr;
-    hipError_t e = hipMalloc(&d, 4);
+hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, uint32_t* d_word, uint32_t* h_word, bool* out) {
+    hipError_t e = hipMemsetAsync(d_word, 0, 4, st);
     if (e != hipSuccess) return e;
-    uint32_t h = 0;
-    e = hipMemsetAsync(d, 0, 4, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(msm_identity_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bases, n, d);
-        e = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d);
-    *out = h != 0;
-    return e;
+    hipLaunchKernelGGL(msm_identity_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bases, n, d_word);
+    if ((e = hipMemcpyAsync(h_word, d_word, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    *out = *h_word != 0;
+    return hipSuccess;
 }
 
 hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st) {
