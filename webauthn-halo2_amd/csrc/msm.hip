@@ -1038,9 +1038,14 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     *c_out = c;
     hipError_t e;
     {
-        const uint32_t m = nbt * parts > nbt + 1 ? nbt * parts : nbt + 1;
+        // the bucket parts need no reset: the bit sums read only the parts the gather wrote (msm_bitsum_kernel used_parts);
+        // an empty MSM runs no gather, so its parts are set to the identity here
+        const uint32_t clear_parts = n > 0 ? 0u : nbt * parts;
+        uint32_t m = nbt + 1;
+        if (clear_parts > m) m = clear_parts;
+        if (batch * CBINS_MAX > m) m = batch * CBINS_MAX;
         const bool sort2 = sort2_applies(fused, n, nb, nwin, table_stride);
-        hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, nbt * parts, ws->totals, nbt + 1,
+        hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, clear_parts, ws->totals, nbt + 1,
                            ws->counts, ws->cursor, sort2 ? nbt : 0u, ws->coarse, ws->coarse_stride, sort2 ? batch : 0u);
     }
     if (n > 0) {
