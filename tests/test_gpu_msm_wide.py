@@ -1,0 +1,139 @@
+"""GPU parity for the wide MSM path (15 / 16-bit windows over the resident SRS: msm.hip "wide path"): every commitment
+equals the oracle's (tau-oracle / C Pippenger), bit-exact after affine normalisation.  The path is selected with
+ZK_OPT_MSM_WINDOW before the SRS (and its window tables) is loaded; 16 bits is the default at k = 19."""
+import random
+
+import numpy as np
+import pytest
+
+from zkoracle import cops, curve as C, field as F, srs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def windowed(engine):
+    from webauthn_halo2_amd import engine as E
+
+    def select(bits):
+        engine.set_option(E.ZK_OPT_MSM_WINDOW, bits)
+        return engine
+
+    yield select
+    engine.set_option(E.ZK_OPT_MSM_WINDOW, 0)
+    engine.srs_setup(10)  # tables of the default plan for whoever comes next
+
+
+def rand_col(rng, n):
+    a = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return a
+
+
+def tau_commit(a):
+    return srs.g1_of_scalar(srs.commit_scalar_monomial(cops.fr_ints(a)))
+
+
+@pytest.mark.parametrize("bits", [15, 16])
+@pytest.mark.parametrize("k", [10, 13, 16])
+def test_wide_commit_matches_tau_oracle(windowed, bits, k):
+    eng = windowed(bits)
+    n = 1 << k
+    eng.srs_setup(k)
+    assert eng.srs_msm_plan()[0] == bits
+    rng = np.random.default_rng(1000 * bits + k)
+    cols = [rand_col(rng, n) for _ in range(5)]
+    cols[1][:] = 0                                   # the zero column: the identity
+    cols[2][:, 1:] = 0                               # 16-bit values: one window, a few hot buckets
+    cols[2][:, 0] &= 0xFFFF
+    cols[2][::3] = 0
+    pr = random.Random(k)
+    mix = []                                         # the advice-column mix of SURVEY.md 8d
+    for _ in range(n):
+        u = pr.random()
+        mix.append(pr.randrange(1 << 18) if u < 0.4 else pr.randrange(1 << 88) if u < 0.75 else pr.randrange(F.R) if u < 0.9 else 0)
+    mixm = cops.fr_mont(mix)
+    boolc = cops.fr_mont([pr.randrange(2) for _ in range(n)])   # one giant bucket
+    top = cops.fr_mont([F.R - 1 - pr.randrange(3) for _ in range(n)])  # largest scalars: every window's top digits, carries
+    polys = [eng.poly(n, c) for c in cols[:3]] + [eng.poly(n, mixm), eng.poly(n, boolc), eng.poly(n, top)]
+    data = cols[:3] + [mixm, boolc, top]
+    want = [tau_commit(d) for d in data]
+    for j, p in enumerate(polys):
+        got = cops.affine_arr_to_ints(eng.commit(p, 0))[0]
+        assert got == want[j], (bits, k, j)
+    # the same columns through ONE batched pass, both bases
+    got = eng.commit_batch(polys, 0)
+    for j in range(len(polys)):
+        assert cops.affine_arr_to_ints(got[j:j + 1])[0] == want[j], (bits, k, "batch", j)
+    gl = eng.commit_batch(polys, 1)
+    for j, p in enumerate(polys):
+        assert (gl[j] == eng.commit(p, 1)).all()
+    # commit_lagrange(v) == commit(iNTT(v))
+    eng.lagrange_to_coeff(polys[0])
+    assert (eng.commit(polys[0], 0) == gl[0]).all()
+    for p in polys:
+        p.free()
+
+
+@pytest.mark.parametrize("with_identity", [False, True])
+def test_wide_commit_over_degenerate_srs(windowed, with_identity):
+    """Equal points with equal scalars (doublings inside a segment), P / -P (cancellation), an SRS with the identity:
+    the unchecked accumulation + redo kernel and the checked one, on the wide path's column regions."""
+    eng = windowed(16)
+    k = 10
+    n = 1 << k
+    rng = random.Random(4321)
+    g = cops.fixed_base_g1(cops.fr_powers(srs.TAU, n))
+    g[20] = g[21]
+    g[22] = g[21]
+    for i in range(40, 60):
+        g[i] = g[40]
+    neg = cops.affine_arr_to_ints(g[30:31])[0]
+    g[31] = cops.to_mont_arr(cops.ints_to_arr([neg[0], (-neg[1]) % F.P]), 1).reshape(8)
+    if with_identity:
+        g[10] = 0
+        g[700] = 0
+    gl = g[::-1].copy()
+    eng.srs_load(k, g, gl)
+    assert eng.srs_msm_plan()[0] == 16
+    s = [rng.randrange(F.R) for _ in range(n)]
+    s[20] = s[21] = s[22] = 5
+    for i in range(40, 60):
+        s[i] = 9
+    s[30] = s[31] = 7
+    sm = cops.fr_mont(s)
+    p = eng.poly(n, sm)
+    q = eng.poly(n, cops.fr_mont([1] * n))
+    for basis, arr_ in ((0, g), (1, gl)):
+        assert cops.affine_arr_to_ints(eng.commit(p, basis))[0] == cops.jac_to_affine_ints(cops.msm(sm, arr_))
+        both = eng.commit_batch([p, q], basis)
+        assert cops.affine_arr_to_ints(both[0:1])[0] == cops.jac_to_affine_ints(cops.msm(sm, arr_))
+        assert cops.affine_arr_to_ints(both[1:2])[0] == cops.jac_to_affine_ints(cops.msm(cops.fr_mont([1] * n), arr_))
+    p.free()
+    q.free()
+
+
+@pytest.mark.parametrize("bits", [15, 16])
+def test_wide_commit_tau_oracle_k19(windowed, bits):
+    """BASELINE size: MSM(s, SRS) == [sum s_i tau^i] G1 at 2^19, one column and a three-column pass."""
+    eng = windowed(bits)
+    k = 19
+    n = 1 << k
+    eng.srs_setup(k)
+    rng = np.random.default_rng(0x5EED0019 + bits)
+    cols = [rand_col(rng, n) for _ in range(3)]
+    cols[2][:, 1:] = 0
+    cols[2][:, 0] &= 0x3FFFF   # lookup-table-like: 18-bit values
+    polys = [eng.poly(n, c) for c in cols]
+    want = [tau_commit(c) for c in cols]
+    assert cops.affine_arr_to_ints(eng.commit(polys[0], 0))[0] == want[0]
+    got = eng.commit_batch(polys, 0)
+    for j in range(3):
+        assert cops.affine_arr_to_ints(got[j:j + 1])[0] == want[j], (bits, j)
+    # linearity (size-independent): commit(2 a) == 2 commit(a)
+    twice = cops.fr_mont([2 * x % F.R for x in cops.fr_ints(cols[0])])
+    p2 = eng.poly(n, twice)
+    assert cops.affine_arr_to_ints(eng.commit(p2, 0))[0] == C.add(want[0], want[0])
+    p2.free()
+    for p in polys:
+        p.free()

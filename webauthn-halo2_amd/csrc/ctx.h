@@ -54,6 +54,7 @@ struct zk_ctx {
         bool busy = false;
         uint32_t nwin = 0, cw = 0;
         uint32_t batch = 1;       // columns of the MSM in flight (fixed-base mode), results collected together
+        bool fixed = false;       // the MSM in flight runs over the resident SRS's window tables
     } lanes[MSM_LANES];
     // scratch
     Fr* scratch = nullptr;

@@ -59,6 +59,9 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
 hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, uint32_t* d_word, uint32_t* h_word, bool* out);
 // G1X entries per result in host_window_sums (fixed-base mode)
 uint32_t msm_sums_per_result(uint32_t c);
+// fixed-base mode, by workspace (the wide path of 15 / 16-bit windows hands over 16 sums per column)
+uint32_t msm_ws_sums_per_result(const MsmWorkspace* ws);
+G1Jac msm_ws_finish_fixed(const MsmWorkspace* ws, const G1X* sums);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).
 G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
 

@@ -143,18 +143,22 @@ static int seam_buffer(zk_ctx* c, int which, size_t bytes, void** out) {
     return ZK_OK;
 }
 
-static int get_msm_ws(zk_ctx* c, int lane, size_t n, MsmWorkspace** out) {
+// `table_window` != 0: the workspace serves the fixed-base mode over the resident SRS (window = the tables'); otherwise
+// arbitrary bases, whose windows stop at 15 bits
+static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmWorkspace** out) {
     size_t want = 1;
     while (want < n) want <<= 1;
     if (want < 1024) want = 1024;
+    uint32_t cw = table_window ? table_window : msm_auto_window(want, c->opt_msm_window);
+    if (!table_window && cw > 15) cw = 15;
     zk_ctx::MsmLane& L = c->lanes[lane];
-    if (L.ws && msm_ws_max_n(L.ws) != want) {
+    if (L.ws && (msm_ws_max_n(L.ws) != want || msm_ws_window(L.ws) != cw)) {
         msm_workspace_destroy(L.ws);
         L.ws = nullptr;
     }
     if (!L.ws) {
         hipError_t e;
-        L.ws = msm_workspace_create(want, msm_auto_window(want, c->opt_msm_window), &e, batch_for(c, want));
+        L.ws = msm_workspace_create(want, cw, &e, batch_for(c, want));
         if (!L.ws) {
             c->last_hip = (int)e;
             return e == hipErrorInvalidValue ? ZK_EINVAL : ZK_ENOMEM;
@@ -182,9 +186,8 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
         }
         stride = 1u << c->srs_k;
     }
-    int rc = get_msm_ws(c, lane, table ? (size_t)stride : n, &ws);
+    int rc = get_msm_ws(c, lane, table ? (size_t)stride : n, table ? c->table_c : 0u, &ws);
     if (rc) return rc;
-    if (table && msm_ws_window(ws) != c->table_c) table = nullptr;
     if (batch > 1 && (!table || batch > msm_ws_max_batch(ws))) return ZK_EINVAL;
     HIPCHK(c, hipEventRecord(L.t_head[0], c->stream));
     HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
@@ -194,6 +197,7 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     c->msm_launches++;
     L.n = n;
     L.batch = batch;
+    L.fixed = table != nullptr;
     L.busy = true;
     return ZK_OK;
 }
@@ -207,9 +211,10 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
     zk_ctx::MsmLane& L = c->lanes[lane];
     L.busy = false;
     HIPCHK(c, hipEventSynchronize(L.tail_done));
-    if (L.batch > 1 || L.nwin == L.batch) {
+    if (L.fixed) {
         // fixed-base mode: one independent result per column
-        for (uint32_t q = 0; q < L.batch; q++) out[q] = msm_finish_host(L.host_buf + (size_t)q * msm_sums_per_result(L.cw), 1, L.cw);
+        const uint32_t per = msm_ws_sums_per_result(L.ws);
+        for (uint32_t q = 0; q < L.batch; q++) out[q] = msm_ws_finish_fixed(L.ws, L.host_buf + (size_t)q * per);
     } else {
         out[0] = msm_finish_host(L.host_buf, L.nwin, L.cw);  // generic mode: Horner over the windows
     }
@@ -397,7 +402,7 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
     std::lock_guard<std::mutex> lk(c->mu);
     switch (option) {
         case ZK_OPT_MSM_WINDOW:
-            if (value && (value < 9 || value > 15)) return ZK_EINVAL;
+            if (value && (value < 9 || value > 16)) return ZK_EINVAL;
             c->opt_msm_window = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_MSM_BATCH:

@@ -93,21 +93,37 @@ struct MsmWorkspace {
     G1X29S* partial;            // [entries / PAD]
     G1X29S* part;                  // [nbt * parts]
     G1X* bit_sum;               // [nwin * c]
+    // wide path (15 / 16-bit windows, fixed-base mode): per-column regions
+    bool wide;
+    size_t w_ent_stride;        // entries per column region (multiple of 64)
+    uint32_t w_slot_stride;     // = w_ent_stride / SEG0
+    uint32_t w_part_stride;     // parts per column region
+    uint32_t* w_bstart;         // [max_batch][nb] places of the buckets in their column's entry region
+    uint32_t* w_pstart;         // [max_batch][nb] first part of every bucket
+    uint32_t* w_pbucket;        // [max_batch][w_part_stride] bucket of every part
+    G1X29S* w_part;             // [max_batch][w_part_stride]
+    G1X29S* w_rc;               // [max_batch][nb / 256 + 256] row and column sums of the bucket matrix
 };
 
+static inline uint32_t nwin_for(uint32_t c) { return 254 / c + 1; }
+// the wide path (below): 15 / 16-bit windows over a resident basis whose window table indexes fit 24 bits
+static bool msm_wide_applies(uint32_t c, size_t table_stride) {
+    return c >= 15 && c <= 16 && (uint64_t)nwin_for(c) * table_stride <= (1u << 24);
+}
 uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    // measured on MI355X with whole proofs (tools/k17_timing.py, bench.py): 13 at 2^19, 12 at 2^16..2^18
-    int c = lg >= 19 ? (int)lg - 6 : (lg >= 16 ? 12 : (int)lg - 5);
-    if (c > 14) c = lg >= 21 ? 15 : 14;  // 15-bit windows (two LDS sweeps per sort, 4x the bucket tail) pay from 2^21 up
+    // measured on MI355X (tools/msm_window_ab.py, whole proofs): the wide path's 16-bit windows from 2^17 to 2^20 (16 bucket
+    // additions per scalar instead of 20 / 22: -13...-26 % per commitment); below, 12 bits at 2^16, then lg - 5; 2^21 and up
+    // (window table indexes beyond 24 bits) 15 bits on the swept sort
+    int c = lg >= 21 ? 15 : (lg >= 17 ? 16 : (lg >= 16 ? 12 : (int)lg - 5));
     if (override_c) c = (int)override_c;  // zk_ctx_set_option(ZK_OPT_MSM_WINDOW)
     if (c < 9) c = 9;
-    if (c > 15) c = 15;  // digits are int16
+    if (c > 16) c = 16;  // digits are int16
+    if (c == 16 && !msm_wide_applies(c, n)) c = 15;  // 16-bit digits exist on the wide path only
     return (uint32_t)c;
 }
 
-static inline uint32_t nwin_for(uint32_t c) { return 254 / c + 1; }
 uint32_t msm_num_windows(uint32_t c) { return nwin_for(c); }
 size_t msm_ws_max_n(const MsmWorkspace* ws) { return ws->max_n; }
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws) { return ws->max_batch; }
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256) void msm_recode_hist_kernel(MsmBatch batch, ui
 #ifndef ZK_SORT2
 #define ZK_SORT2 1
 #endif
-static constexpr uint32_t CBINS_MAX = 128;   // coarse bins = buckets / 64 (64 at 13-bit windows, 128 at 14)
+static constexpr uint32_t CBINS_MAX = 256;   // coarse bins: buckets / 64 (64 at 13-bit windows, 128 at 14); buckets / 128 on the wide path (256 at 16)
 #ifndef ZK_SORT_SUB
 #define ZK_SORT_SUB 4096
 #endif
@@ -286,7 +302,7 @@ static bool sort2_applies(bool fused, size_t n, uint32_t nb, uint32_t nwin, size
 }
 
 static constexpr uint32_t SUB = ZK_SORT_SUB;  // entries sorted in LDS at a time
-static constexpr uint32_t COARSE_WORDS = 3 * (CBINS_MAX + 1);  // per column: bin starts, chunk prefix, append cursors
+static constexpr uint32_t COARSE_WORDS = 5 * (CBINS_MAX + 1);  // per column: bin starts, chunk prefix, append cursors; wide path: the bins' entry / part regions
 
 // digits + fine histogram: the global bucket totals (the workgroup's counts are added with one atomic per non-empty bucket)
 __global__ __launch_bounds__(256) void msm_recode_hist2_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c, uint32_t nwin,
@@ -327,14 +343,15 @@ __global__ __launch_bounds__(256) void msm_recode_hist2_kernel(MsmBatch batch, u
 
 // per column: coarse-bin totals (sums of 64 bucket totals), their exclusive scan (the bins' places in `inter`), the chunk
 // prefix of the second level (ceil(total / SUB) chunks per bin), and the first level's append cursors (zero)
-__global__ __launch_bounds__(128) void msm_scan_coarse_kernel(const uint32_t* __restrict__ totals_all, uint32_t nb,
-                                                              uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t bins) {
+__global__ __launch_bounds__(CBINS_MAX) void msm_scan_coarse_kernel(const uint32_t* __restrict__ totals_all, uint32_t nb,
+                                                                    uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t bins,
+                                                                    uint32_t fb) {
     __shared__ uint32_t tot[CBINS_MAX];
     const uint32_t* totals = totals_all + (size_t)blockIdx.x * nb;
     uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
     if (threadIdx.x < bins) {
         uint32_t sum = 0;
-        for (uint32_t q = 0; q < 64; q++) sum += totals[threadIdx.x * 64 + q];
+        for (uint32_t q = 0; q < (1u << fb); q++) sum += totals[(threadIdx.x << fb) + q];
         tot[threadIdx.x] = sum;
     }
     __syncthreads();
@@ -360,24 +377,24 @@ struct SortLds {
 };
 
 __device__ __forceinline__ void sort_scan(SortLds& S, uint32_t bins) {
-    // exclusive scan of S.cnt over `bins` <= 128 keys by the first wave
+    // exclusive scan of S.cnt over `bins` <= 256 keys by the first wave (four consecutive keys per lane);
+    // S.lstart[CBINS_MAX] = the total
     if (threadIdx.x < 64) {
-        uint32_t a = threadIdx.x < bins ? S.cnt[threadIdx.x] : 0;
-        uint32_t b = threadIdx.x + 64 < bins ? S.cnt[threadIdx.x + 64] : 0;
-        uint32_t x = a;
+        const uint32_t k0 = threadIdx.x * 4;
+        const uint32_t a0 = k0 < bins ? S.cnt[k0] : 0, a1 = k0 + 1 < bins ? S.cnt[k0 + 1] : 0;
+        const uint32_t a2 = k0 + 2 < bins ? S.cnt[k0 + 2] : 0, a3 = k0 + 3 < bins ? S.cnt[k0 + 3] : 0;
+        const uint32_t s = a0 + a1 + a2 + a3;
+        uint32_t x = s;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t y = __shfl_up(x, off);
             if ((int)threadIdx.x >= off) x += y;
         }
-        const uint32_t tot_a = __shfl(x, 63);
-        uint32_t z = b;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t y = __shfl_up(z, off);
-            if ((int)threadIdx.x >= off) z += y;
-        }
-        S.lstart[threadIdx.x] = x - a;
-        S.lstart[threadIdx.x + 64] = tot_a + z - b;
-        if (threadIdx.x == 63) S.lstart[128] = tot_a + z;
+        const uint32_t base = x - s;
+        S.lstart[k0] = base;
+        S.lstart[k0 + 1] = base + a0;
+        S.lstart[k0 + 2] = base + a0 + a1;
+        S.lstart[k0 + 3] = base + a0 + a1 + a2;
+        if (threadIdx.x == 63) S.lstart[CBINS_MAX] = x;
     }
 }
 
@@ -385,14 +402,15 @@ __device__ __forceinline__ void sort_scan(SortLds& S, uint32_t bins) {
 // coarse bin and appended to the workgroup's range of every bin of `inter` (reserved by msm_recode_hist2_kernel)
 __global__ __launch_bounds__(256) void msm_scatter1_kernel(const int16_t* __restrict__ digits_all, uint32_t n, uint32_t stride, uint32_t nwin,
                                                            uint32_t nb, uint32_t table_stride, const uint32_t* __restrict__ coarse_all,
-                                                           uint32_t coarse_stride, uint32_t* __restrict__ inter_all, size_t inter_stride) {
+                                                           uint32_t coarse_stride, uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                           uint32_t fb) {
     __shared__ SortLds S;
     const uint32_t col = blockIdx.y;
     const int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     const uint32_t* __restrict__ cbase = chdr + COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX;
     uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
-    const uint32_t bins = nb >> 6;
+    const uint32_t bins = nb >> fb, fmask = (1u << fb) - 1;
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
     if (threadIdx.x < bins) S.gbase[threadIdx.x] = chdr[threadIdx.x] + cbase[threadIdx.x];
     constexpr uint32_t WPS = SUB / FCHUNK;      // windows per sub-round
@@ -410,8 +428,8 @@ __global__ __launch_bounds__(256) void msm_scatter1_kernel(const int16_t* __rest
                 const int32_t d = digits[(size_t)w * stride + i];
                 if (d != 0) {
                     const uint32_t bkt = (uint32_t)(d < 0 ? -d : d) - 1;
-                    const uint32_t key = bkt >> 6;
-                    ent[q] = (w * table_stride + i) | ((bkt & 63u) << 24) | (d < 0 ? SIGN_BIT : 0);
+                    const uint32_t key = bkt >> fb;
+                    ent[q] = (w * table_stride + i) | ((bkt & fmask) << 24) | (d < 0 ? SIGN_BIT : 0);
                     meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
                 }
             }
@@ -427,7 +445,7 @@ __global__ __launch_bounds__(256) void msm_scatter1_kernel(const int16_t* __rest
                 S.kid[pos] = (uint8_t)key;
             }
         __syncthreads();
-        const uint32_t total = S.lstart[128];
+        const uint32_t total = S.lstart[CBINS_MAX];
         for (uint32_t q = threadIdx.x; q < total; q += 256) {
             const uint32_t key = S.kid[q];
             inter[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
@@ -442,7 +460,10 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
                                                            const uint32_t* __restrict__ totals_all,
                                                            const uint32_t* __restrict__ bucket_start_all, uint32_t* __restrict__ cursor_all,
-                                                           uint32_t* __restrict__ entries) {
+                                                           uint32_t* __restrict__ entries_all, uint32_t fb, uint32_t pad,
+                                                           size_t ent_stride) {
+    // 13 / 14-bit plan: the bucket starts of all columns index one dense entry list (ent_stride = 0), ranges padded to
+    // PAD entries; wide path: column-local starts, one entry region per column, ranges padded to one segment
     __shared__ SortLds S;
     __shared__ uint32_t s_bin, s_chunk;
     const uint32_t col = blockIdx.y;
@@ -451,10 +472,11 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
     const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
     const uint32_t* __restrict__ bucket_start = bucket_start_all + (size_t)col * nb;
     uint32_t* __restrict__ cursor = cursor_all + (size_t)col * nb;
-    const uint32_t bins = nb >> 6;
-    // this workgroup's share of the bucket padding (skip markers up to the next multiple of PAD)
+    uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
+    const uint32_t bins = nb >> fb, keys = 1u << fb;
+    // this workgroup's share of the bucket padding (skip markers up to the next multiple of `pad`)
     for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
-        const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
+        const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b] + ((totals[b] + pad - 1) & ~(pad - 1));
         for (uint32_t q = beg; q < end; q++) entries[q] = SKIP_ENTRY;
     }
     const uint32_t* cpre = chdr + (CBINS_MAX + 1);
@@ -465,7 +487,7 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
         s_bin = b;
         s_chunk = blockIdx.x - cpre[b];
     }
-    if (threadIdx.x < 64) S.cnt[threadIdx.x] = 0;
+    if (threadIdx.x < keys) S.cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t bin = s_bin;
     const uint32_t beg = chdr[bin] + s_chunk * SUB;
@@ -478,15 +500,15 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
         meta[q] = 0xffffffffu;
         if (p < end) {
             const uint32_t e = inter[p];
-            const uint32_t key = (e >> 24) & 63u;
-            ent[q] = e & ~(63u << 24);
+            const uint32_t key = (e >> 24) & (keys - 1);
+            ent[q] = e & ~((keys - 1) << 24);
             meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
         }
     }
     __syncthreads();
-    sort_scan(S, 64);
-    if (threadIdx.x < 64) {
-        const uint32_t cnt = S.cnt[threadIdx.x], b = bin * 64 + threadIdx.x;
+    sort_scan(S, keys);
+    if (threadIdx.x < keys) {
+        const uint32_t cnt = S.cnt[threadIdx.x], b = bin * keys + threadIdx.x;
         S.gbase[threadIdx.x] = bucket_start[b] + (cnt ? atomicAdd(&cursor[b], cnt) : 0);
     }
     __syncthreads();
@@ -641,13 +663,16 @@ __attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
                                                             const uint32_t* __restrict__ counts,
-                                                            G1X29S* __restrict__ slot_pt) {
-    const uint32_t total = counts[0];  // multiple of SEG0
+                                                            G1X29S* __restrict__ slot_pt, uint32_t slot_stride) {
+    // blockIdx.y = column region of the wide path (slot_stride slots each, counts[4 col] entries in use); the dense
+    // layout is one region
+    const uint32_t total = counts[4 * blockIdx.y];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
+    const size_t gs = (size_t)blockIdx.y * slot_stride + t;
     // the running sum lives on the carry-free 29-bit-limb field (ec29.hip.h); bases are read in
     // their standard memory form, the slot is written in the internal one (the reduction tails stay on that field)
-    g1x29_store(slot_pt + t, accumulate_segment<true>(entries + (size_t)t * SEG0, bases));
+    g1x29_store(slot_pt + gs, accumulate_segment<true>(entries + gs * SEG0, bases));
 }
 
 // Unchecked kernel for a basis without the identity (the resident SRS): no test at all in the loop, and none of the
@@ -660,13 +685,14 @@ __attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
 __global__ __launch_bounds__(64) void msm_accumulate_fast_kernel(const uint32_t* __restrict__ entries,
                                                                  const G1Affine* __restrict__ bases,
                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ redo,
-                                                                 G1X29S* __restrict__ slot_pt) {
-    const uint32_t total = counts[0];  // multiple of SEG0
+                                                                 G1X29S* __restrict__ slot_pt, uint32_t slot_stride) {
+    const uint32_t total = counts[4 * blockIdx.y];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
-    const G1X29 acc = accumulate_segment<false>(entries + (size_t)t * SEG0, bases);
-    if (!acc.inf && is_zero29(acc.zz)) redo[atomicAdd(&counts[1], 1u)] = t;  // at most one entry per segment: redo[] has one word each
-    g1x29_store(slot_pt + t, acc);
+    const size_t gs = (size_t)blockIdx.y * slot_stride + t;
+    const G1X29 acc = accumulate_segment<false>(entries + gs * SEG0, bases);
+    if (!acc.inf && is_zero29(acc.zz)) redo[atomicAdd(&counts[1], 1u)] = (uint32_t)gs;  // at most one entry per segment: redo[] has one word each
+    g1x29_store(slot_pt + gs, acc);
 }
 __global__ __launch_bounds__(64) void msm_accumulate_redo_kernel(const uint32_t* __restrict__ entries,
                                                                  const G1Affine* __restrict__ bases,
@@ -686,7 +712,7 @@ __global__ void msm_clear_kernel(G1X29S* __restrict__ p, uint32_t m, uint32_t* _
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) g1x29_store(p + i, g1x29_identity());
     if (i < nt) totals[i] = 0;
-    if (i < 4) counts[i] = 0;
+    if (i < 4 * (ncols + 1)) counts[i] = 0;
     if (i < ncur) cursor[i] = 0;  // second-level write cursors (two-level sort)
     if (i < ncols * CBINS_MAX) coarse[(size_t)(i / CBINS_MAX) * coarse_stride + 2 * (CBINS_MAX + 1) + (i % CBINS_MAX)] = 0;  // first-level append cursors
 }
@@ -882,6 +908,342 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
     }
 }
 
+// ================================================================== wide path ==
+// Windows of 15 / 16 bits (fixed-base mode): 17 / 16 bucket additions per scalar instead of 20 at 13 bits, paid for with
+// 16384 / 32768 buckets per column.  What changes against the 13-bit plan above:
+//   * the digits / histogram kernel counts in 16-bit LDS counters (two buckets per word: a workgroup's 1024 scalars
+//     put at most 17 x 1024 entries into one bucket), so that the 32768 counters of a column take 64 KB;
+//   * the two-level sort splits a bucket index into an 8-bit coarse bin and a 7-bit fine key (128 buckets per bin);
+//   * every column owns a region of the entry / slot lists (column-local bucket starts), bucket ranges are padded to
+//     ONE accumulate segment (16 entries: 3 % padding at 256 entries per bucket, 64 would be 12 %);
+//   * the reduction tail is shaped for many small buckets: (T1) one lane per "part" of at most WCAP slots sums it
+//     serially, lanes of the same bucket inside a wave are joined by a segmented shuffle tree; (T2) the bucket matrix
+//     [rows = nb / 256][256] is summed along its rows and along its columns, one wave each —
+//     sum_b (b + 1) B_b = 256 sum_h h R_h + sum_l (l + 1) C_l — and (T3) the short weighted sums over h and l + 1 are
+//     taken bit by bit (log2(rows) + 9 tree reductions per column); the host runs the 16-step Horner.
+static constexpr uint32_t WIDE_FB = 7;    // fine key bits: 128 buckets per coarse bin
+static constexpr uint32_t WIDE_KEYS = 1u << WIDE_FB;
+static constexpr uint32_t WCAP = 8;       // slots per part (T1's serial run)
+static constexpr uint32_t WIDE_SUMS = 16; // bit sums per column handed to the host: 9 column bits, then up to 7 row bits
+
+// signed digits in [-half, half): the 16-bit window's digits fit int16 (the last window never carries: a scalar is < 2^254)
+__device__ __forceinline__ void msm_digits_wide(const uint32_t* L, uint32_t c, uint32_t nwin, uint32_t i, uint32_t stride,
+                                                int16_t* __restrict__ digits, uint32_t* hist) {
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < nwin; w++) {
+        const uint32_t bit = w * c, word = bit >> 5, off = bit & 31;
+        uint32_t raw = 0;
+        if (word < 8) {
+            const uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
+            raw = (uint32_t)(two >> off) & mask;
+        }
+        raw += carry;
+        int32_t d;
+        if (raw >= half) {
+            d = (int32_t)raw - (int32_t)(1u << c);
+            carry = 1;
+        } else {
+            d = (int32_t)raw;
+            carry = 0;
+        }
+        digits[(size_t)w * stride + i] = (int16_t)d;
+        if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1) >> WIDE_FB], 1u);
+    }
+}
+
+// digits + the workgroup's coarse histogram (bucket >> 7): its range inside every coarse bin of `inter` is reserved with one
+// returning atomic per bin on the append cursors, which end up holding the bins' totals.  The per-bucket totals are counted
+// later, bin by bin, from the sorted intermediate list (msm_binscan_kernel): 32768 counters per workgroup here would cost
+// 6.7 M global atomics per 2^19 column (measured: 117 us for this kernel against 31 us at 4096 buckets).
+__global__ __launch_bounds__(256) void msm_recode_coarse_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c, uint32_t nwin,
+                                                                uint32_t nb, int16_t* __restrict__ digits_all,
+                                                                uint32_t* __restrict__ coarse_all, uint32_t coarse_stride) {
+    __shared__ uint32_t hist[CBINS_MAX];
+    __shared__ uint32_t limbs[256 * 9];
+    const uint32_t col = blockIdx.y;
+    const Fr* __restrict__ scalars = batch.s[col];
+    int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
+    uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    uint32_t* L = limbs + threadIdx.x * 9;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const Fr s = fe_from_mont(fe_load(scalars + i));
+#pragma unroll
+        for (int k = 0; k < 8; k++) L[k] = s.v[k];
+        L[8] = 0;
+        msm_digits_wide(L, c, nwin, i, stride, digits, hist);
+    }
+    __syncthreads();
+    if (threadIdx.x < (nb >> WIDE_FB)) {
+        const uint32_t sum = hist[threadIdx.x];
+        chdr[COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX + threadIdx.x] = sum ? atomicAdd(&chdr[2 * (CBINS_MAX + 1) + threadIdx.x], sum) : 0;
+    }
+}
+
+// per column (blockIdx.x), from the bins' totals (the append cursors): the bins' places in `inter` (dense), the chunk prefix
+// of the second sort level, and the bins' REGIONS of the entry list and of the part list, sized for the worst case of the
+// padding (every bucket of a bin padded by SEG0 - 1) — the bucket starts inside a region are set by msm_binscan_kernel once
+// the per-bucket totals are known.  counts[4 col] / [4 col + 2] = the end of the last entry / part region.
+__global__ __launch_bounds__(64) void msm_scan_coarse_wide_kernel(uint32_t* __restrict__ coarse_all, uint32_t coarse_stride,
+                                                                  uint32_t bins, uint32_t* __restrict__ counts) {
+    constexpr uint32_t CB = CBINS_MAX + 1;
+    uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
+    // one wave, four consecutive bins per lane: exclusive scans of four quantities
+    const uint32_t k0 = threadIdx.x * 4;
+    uint32_t v[4][4];  // [bin][inter entries, chunks, entry region, part region]
+    uint32_t s4[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t t = k0 + j < bins ? c[2 * CB + k0 + j] : 0;
+        const uint32_t e = t ? (t + WIDE_KEYS * (SEG0 - 1) + SEG0 - 1) & ~(SEG0 - 1) : 0;
+        v[j][0] = t;
+        v[j][1] = (t + SUB - 1) / SUB;
+        v[j][2] = e;
+        v[j][3] = t ? (e / SEG0 + WCAP - 1) / WCAP + WIDE_KEYS : 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) s4[q] += v[j][q];
+    }
+    uint32_t x[4] = {s4[0], s4[1], s4[2], s4[3]};
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t y = __shfl_up(x[q], off);
+            if ((int)threadIdx.x >= off) x[q] += y;
+        }
+    }
+    uint32_t run[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) run[q] = x[q] - s4[q];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (k0 + j < bins) {
+            c[k0 + j] = run[0];
+            c[CB + k0 + j] = run[1];
+            c[3 * CB + k0 + j] = run[2];
+            c[4 * CB + k0 + j] = run[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) run[q] += v[j][q];
+    }
+    if (threadIdx.x == 63) {
+        c[bins] = x[0];
+        c[CB + bins] = x[1];
+        c[3 * CB + bins] = x[2];
+        c[4 * CB + bins] = x[3];
+        counts[4 * blockIdx.x] = x[2];
+        counts[4 * blockIdx.x + 2] = x[3];
+    }
+}
+
+// one workgroup per (coarse bin, column): counts the bin's entries per fine key from `inter`, then the bin-local scans:
+// totals[b], bstart[b] (place of bucket b in the column's entry region; its range is padded to a multiple of SEG0),
+// pstart[b] and pbucket[] (the bucket's parts of at most WCAP slots, T1), and the fills of what the region holds beyond
+// the buckets (skip markers / no-part markers).
+__global__ __launch_bounds__(1024) void msm_binscan_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                          const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
+                                                          uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
+                                                          uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket_all,
+                                                          uint32_t part_stride, uint32_t* __restrict__ entries_all, size_t ent_stride) {
+    __shared__ uint32_t hist[WIDE_KEYS];
+    __shared__ uint32_t wsum[4];
+    constexpr uint32_t CB = CBINS_MAX + 1;
+    const uint32_t col = blockIdx.y, bin = blockIdx.x;
+    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
+    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    uint32_t* __restrict__ pbucket = pbucket_all + (size_t)col * part_stride;
+    uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
+    if (threadIdx.x < WIDE_KEYS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t beg = chdr[bin], end = chdr[bin + 1];
+    for (uint32_t p = beg + threadIdx.x; p < end; p += 1024) atomicAdd(&hist[(inter[p] >> 24) & (WIDE_KEYS - 1)], 1u);
+    __syncthreads();
+    // threads 0..127 = the bin's buckets (two waves): exclusive scans of the padded sizes and of the part counts
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t cnt = 0, h = 0, np = 0;
+    if (threadIdx.x < WIDE_KEYS) {
+        cnt = hist[threadIdx.x];
+        h = (cnt + SEG0 - 1) & ~(SEG0 - 1);
+        np = (h / SEG0 + WCAP - 1) / WCAP;
+    }
+    uint32_t xe = h, xp = np;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ye = __shfl_up(xe, off), yp = __shfl_up(xp, off);
+        if ((int)lane >= off) {
+            xe += ye;
+            xp += yp;
+        }
+    }
+    if (lane == 63 && wave < 2) {
+        wsum[2 * wave] = xe;
+        wsum[2 * wave + 1] = xp;
+    }
+    __syncthreads();
+    const uint32_t ebase = chdr[3 * CB + bin], pbase = chdr[4 * CB + bin];
+    const uint32_t eend = chdr[3 * CB + bin + 1], pend = chdr[4 * CB + bin + 1];
+    const uint32_t e_used = wsum[0] + wsum[2], p_used = wsum[1] + wsum[3];
+    if (threadIdx.x < WIDE_KEYS) {
+        const uint32_t b = bin * WIDE_KEYS + threadIdx.x;
+        const uint32_t e0 = ebase + xe - h + (wave ? wsum[0] : 0), p0 = pbase + xp - np + (wave ? wsum[1] : 0);
+        totals_all[(size_t)col * nb + b] = cnt;
+        bstart_all[(size_t)col * nb + b] = e0;
+        pstart_all[(size_t)col * nb + b] = p0;
+        for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
+    }
+    for (uint32_t q = ebase + e_used + threadIdx.x; q < eend; q += 1024) entries[q] = SKIP_ENTRY;
+    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 1024) pbucket[q] = 0xffffffffu;
+}
+
+// T1: part g of a column = up to WCAP consecutive slots of one bucket, summed serially by one lane; then the lanes of a wave
+// that hold parts of the same bucket (a bucket's parts are consecutive) are joined by a segmented shuffle tree — the first
+// lane of every run stores.  part[g] is therefore valid at the "heads": g = pstart[b] and the multiples of 64 inside
+// (pstart[b], pstart[b + 1]).
+__global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict__ slot_all, uint32_t slot_stride,
+                                                        const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
+                                                        const uint32_t* __restrict__ pstart_all, const uint32_t* __restrict__ pbucket_all,
+                                                        uint32_t part_stride, uint32_t nb, const uint32_t* __restrict__ counts,
+                                                        G1X29S* __restrict__ part_all) {
+    const uint32_t col = blockIdx.y;
+    const uint32_t nparts = counts[4 * col + 2];
+    if (blockIdx.x * 64 >= nparts) return;  // wave-uniform
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = blockIdx.x * 64 + lane;
+    const G1X29S* __restrict__ slots = slot_all + (size_t)col * slot_stride;
+    uint32_t b = g < nparts ? pbucket_all[(size_t)col * part_stride + g] : 0xffffffffu;  // 0xffffffff: the unused end of a bin's part region
+    const bool active = b != 0xffffffffu;
+    uint32_t s = 0, s_end = 0;
+    if (active) {
+        const uint32_t s0 = bstart_all[(size_t)col * nb + b] / SEG0;
+        const uint32_t len = (totals_all[(size_t)col * nb + b] + SEG0 - 1) / SEG0;
+        const uint32_t np = (len + WCAP - 1) / WCAP;
+        const uint32_t p = g - pstart_all[(size_t)col * nb + b];
+        // balanced shares: part p of np takes slots [s0 + p len / np, s0 + (p + 1) len / np)
+        s = s0 + (uint32_t)(((uint64_t)p * len) / np);
+        s_end = s0 + (uint32_t)(((uint64_t)(p + 1) * len) / np);
+    }
+    G1X29 acc = g1x29_identity();
+    int off = 1;
+#pragma unroll 1
+    for (;;) {
+        G1X29 v;
+        bool have;
+        if (__any(s < s_end)) {  // wave-uniform: the serial runs
+            have = s < s_end;
+            if (have) v = g1x29_load(slots + s);
+            s++;
+        } else {
+            // segmented tree: lane i takes lane i + off's sum when both hold parts of the same bucket (a bucket's parts are
+            // consecutive lanes: a level without any such pair ends the tree)
+            if (off >= 64) break;
+            const uint32_t kb = (uint32_t)__shfl_down((int)b, off);
+            have = active && lane + off < 64 && kb == b;
+            if (!__any(have)) break;
+            v = g1x29_shfl_down(acc, off);
+            off <<= 1;
+        }
+        if (have) g1x29_add(acc, v);
+    }
+    const uint32_t prev = (uint32_t)__shfl_up((int)b, 1);
+    if (active && (lane == 0 || prev != b)) g1x29_store(part_all + (size_t)col * part_stride + g, acc);
+}
+
+// T2: one wave per row (blockIdx.x < rows) or column (blockIdx.x - rows) of the column's bucket matrix [rows][256]: lanes walk
+// their buckets' heads serially, then a shuffle tree.  rc[col][rows + 256]
+__global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restrict__ part_all, uint32_t part_stride,
+                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ pstart_all,
+                                                         uint32_t nb, G1X29S* __restrict__ rc_all) {
+    const uint32_t col = blockIdx.y, rows = nb >> 8, r = blockIdx.x, lane = threadIdx.x;
+    const uint32_t* __restrict__ pstart = pstart_all + (size_t)col * nb;
+    const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
+    const G1X29S* __restrict__ part = part_all + (size_t)col * part_stride;
+    const bool is_row = r < rows;
+    // lane's j-th bucket: rows: 256 r + lane + 64 j (j < 4); columns: 256 (lane + 64 j) + (r - rows) (j < rows / 64)
+    const uint32_t nj = is_row ? 4u : rows / 64;
+    uint32_t j = 0, g = 0, g_end = 0;
+    const auto bucket_of = [&](uint32_t jj) { return is_row ? 256 * r + lane + 64 * jj : 256 * (lane + 64 * jj) + (r - rows); };
+    const auto open_bucket = [&]() {
+        while (j < nj) {
+            const uint32_t b = bucket_of(j);
+            g = pstart[b];
+            g_end = g + ((totals[b] + SEG0 - 1) / SEG0 + WCAP - 1) / WCAP;
+            if (g < g_end) return;
+            j++;
+        }
+    };
+    open_bucket();
+    G1X29 acc = g1x29_identity();
+    int off = 32;
+#pragma unroll 1
+    for (;;) {
+        G1X29 v;
+        bool have;
+        if (__any(j < nj)) {  // wave-uniform
+            have = j < nj;
+            if (have) {
+                v = g1x29_load(part + g);
+                g = (g | 63u) + 1;  // the next head of this bucket, if any
+                if (g >= g_end) {
+                    j++;
+                    open_bucket();
+                }
+            }
+        } else {
+            if (off == 0) break;
+            v = g1x29_shfl_down(acc, off);
+            have = (int)lane < off;
+            off >>= 1;
+        }
+        if (have) g1x29_add(acc, v);
+    }
+    if (lane == 0) g1x29_store(rc_all + (size_t)col * (rows + 256) + r, acc);
+}
+
+// T3: blockIdx.x = t < 9: sum of the column sums C_l with bit t of (l + 1) set; t >= 9: sum of the row sums R_h with bit
+// t - 9 of h set.  One wave each; lane 0 hands the sum over in the standard form.  out[col][WIDE_SUMS]
+__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out) {
+    const uint32_t col = blockIdx.y, rows = nb >> 8, t = blockIdx.x, lane = threadIdx.x;
+    const G1X29S* __restrict__ rc = rc_all + (size_t)col * (rows + 256);
+    const bool cols = t < 9;
+    const uint32_t items = cols ? 256u : rows;
+    uint32_t i = lane;
+    const auto wanted = [&](uint32_t ii) { return cols ? (((ii + 1) >> t) & 1u) != 0 : ((ii >> (t - 9)) & 1u) != 0; };
+    while (i < items && !wanted(i)) i += 64;
+    G1X29 acc = g1x29_identity();
+    int off = 32;
+#pragma unroll 1
+    for (;;) {
+        G1X29 v;
+        bool have;
+        if (__any(i < items)) {  // wave-uniform
+            have = i < items;
+            if (have) {
+                v = g1x29_load(rc + (cols ? rows + i : i));
+                i += 64;
+                while (i < items && !wanted(i)) i += 64;
+            }
+        } else {
+            if (off == 0) break;
+            v = g1x29_shfl_down(acc, off);
+            have = (int)lane < off;
+            off >>= 1;
+        }
+        if (have) g1x29_add(acc, v);
+    }
+    if (lane == 0) {
+        G1X r = G1X::identity();
+        if (!acc.inf) {
+            r.x = internal_to_std_call(acc.x);
+            r.y = internal_to_std_call(acc.y);
+            r.zz = internal_to_std_call(acc.zz);
+            r.zzz = internal_to_std_call(acc.zzz);
+        }
+        g1x_store(out + (size_t)col * WIDE_SUMS + t, r);
+    }
+}
+
 // ------------------------------------------------------ fixed-base tables ---
 // table[w][i] = 2^(c w) * P_i (affine).  One launch per window: c doublings + one inversion.
 __global__ __launch_bounds__(64) void msm_table_step_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next,
@@ -951,7 +1313,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     if (err) *err = hipSuccess;
     if (c == 0) c = msm_auto_window(max_n);
     if (max_batch == 0) max_batch = 1;
-    if (c < 9 || c > 15 || max_n == 0 || max_n > ((size_t)1 << 26) || max_batch > MSM_MAX_BATCH) {
+    if (c < 9 || c > 16 || (c == 16 && !msm_wide_applies(c, max_n)) || max_n == 0 || max_n > ((size_t)1 << 26) || max_batch > MSM_MAX_BATCH) {
         if (err) *err = hipErrorInvalidValue;
         return nullptr;
     }
@@ -980,7 +1342,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
         const size_t generic_blocks = nchunks * ws->nwin, fixed_blocks = (size_t)max_batch * ((max_n + FCHUNK - 1) / FCHUNK);
         MSM_TRY(hipMalloc(&ws->blockbase, (generic_blocks > fixed_blocks ? generic_blocks : fixed_blocks) * ws->nb * 4));
     }
-    MSM_TRY(hipMalloc(&ws->counts, 4 * 4));
+    MSM_TRY(hipMalloc(&ws->counts, 4 * 4 * (MSM_MAX_BATCH + 1)));
     MSM_TRY(hipMalloc(&ws->entries, ent * sizeof(uint32_t)));
     {
         const size_t nblk_max = (max_n + FCHUNK - 1) / FCHUNK;
@@ -995,6 +1357,22 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->bit_sum, slices * c * BITSUM_MAX_SPLIT * sizeof(G1X)));
+    ws->wide = msm_wide_applies(c, max_n);
+    if (ws->wide) {
+        ws->w_ent_stride = (max_n * ws->nwin + (size_t)(ws->nb >> WIDE_FB) * (WIDE_KEYS * (SEG0 - 1) + SEG0) + 63) & ~(size_t)63;
+        if (ws->w_ent_stride * max_batch > ent) {  // cannot happen: the dense list is padded to 64 per bucket
+            if (err) *err = hipErrorInvalidValue;
+            msm_workspace_destroy(ws);
+            return nullptr;
+        }
+        ws->w_slot_stride = (uint32_t)(ws->w_ent_stride / SEG0);
+        ws->w_part_stride = (ws->w_slot_stride / WCAP + ws->nb + 2 * (ws->nb >> WIDE_FB) + 63) & ~63u;
+        MSM_TRY(hipMalloc(&ws->w_bstart, (size_t)max_batch * ws->nb * 4));
+        MSM_TRY(hipMalloc(&ws->w_pstart, (size_t)max_batch * ws->nb * 4));
+        MSM_TRY(hipMalloc(&ws->w_pbucket, (size_t)max_batch * ws->w_part_stride * 4));
+        MSM_TRY(hipMalloc(&ws->w_part, (size_t)max_batch * ws->w_part_stride * sizeof(G1X29S)));
+        MSM_TRY(hipMalloc(&ws->w_rc, (size_t)max_batch * ((ws->nb >> 8) + 256) * sizeof(G1X29S)));
+    }
     return ws;
 }
 
@@ -1014,7 +1392,82 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->partial);
     hipFree(ws->part);
     hipFree(ws->bit_sum);
+    hipFree(ws->w_bstart);
+    hipFree(ws->w_pstart);
+    hipFree(ws->w_pbucket);
+    hipFree(ws->w_part);
+    hipFree(ws->w_rc);
     delete ws;
+}
+
+// The wide path's pipeline (see "wide path" above): `batch` columns against the resident basis whose window table is `table`.
+static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t batch, size_t n, hipStream_t st,
+                               G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events,
+                               const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done,
+                               bool bases_may_be_identity) {
+    const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
+    const uint32_t nbt = batch * nb, rows = nb >> 8;
+    uint32_t row_bits = 0;
+    while ((1u << row_bits) < rows) row_bits++;
+    *nwin_out = batch;
+    *c_out = c;
+    hipError_t e;
+    {
+        uint32_t m = nbt + 1;
+        if (batch * CBINS_MAX > m) m = batch * CBINS_MAX;
+        hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, 0u, ws->totals, nbt + 1, ws->counts,
+                           ws->cursor, nbt, ws->coarse, ws->coarse_stride, batch);
+    }
+    const uint32_t n32 = (uint32_t)n;
+    const uint32_t stride = (uint32_t)ws->max_n;
+    // worst-case extent of one column's entry region at this n (every bin's region is sized for full padding) -> grid sizes
+    const size_t worst = (size_t)n * nwin + (size_t)(nb >> WIDE_FB) * (WIDE_KEYS * (SEG0 - 1) + SEG0);
+    const uint32_t slots = (uint32_t)((worst + SEG0 - 1) / SEG0);
+    if (n > 0) {
+        const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
+        MsmBatch mb;
+        memset(&mb, 0, sizeof(mb));
+        for (uint32_t q = 0; q < batch; q++) mb.s[q] = scalars_list[q];
+        hipLaunchKernelGGL(msm_recode_coarse_kernel, dim3(nblk, batch), dim3(256), 0, st, mb, n32, stride, c, nwin, nb, ws->digits,
+                           ws->coarse, ws->coarse_stride);
+        hipLaunchKernelGGL(msm_scan_coarse_wide_kernel, dim3(batch), dim3(64), 0, st, ws->coarse, ws->coarse_stride, nb >> WIDE_FB,
+                           ws->counts);
+        hipLaunchKernelGGL(msm_scatter1_kernel, dim3(nblk, batch), dim3(256), 0, st, ws->digits, n32, stride, nwin, nb, table_stride,
+                           ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride, WIDE_FB);
+        hipLaunchKernelGGL(msm_binscan_kernel, dim3(nb >> WIDE_FB, batch), dim3(1024), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, ws->entries,
+                           ws->w_ent_stride);
+        const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> WIDE_FB);
+        hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->cursor, ws->entries, WIDE_FB, SEG0, ws->w_ent_stride);
+        if (accum_events) hipEventRecord(accum_events[0], st);
+        if (bases_may_be_identity) {
+            hipLaunchKernelGGL(msm_accumulate_kernel, dim3((slots + 63) / 64, batch), dim3(64), 0, st, ws->entries, table, ws->counts,
+                               ws->slot_pt, ws->w_slot_stride);
+        } else {
+            hipLaunchKernelGGL(msm_accumulate_fast_kernel, dim3((slots + 63) / 64, batch), dim3(64), 0, st, ws->entries, table, ws->counts,
+                               ws->redo, ws->slot_pt, ws->w_slot_stride);
+        }
+        if (accum_events) hipEventRecord(accum_events[1], st);
+        if (!bases_may_be_identity)
+            hipLaunchKernelGGL(msm_accumulate_redo_kernel, dim3(1024), dim3(64), 0, st, ws->entries, table, ws->counts, ws->redo, ws->slot_pt);
+    }
+    hipStream_t ts = st;
+    if (tail_st && tail_st != st) {
+        if ((e = hipEventRecord(head_done, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(tail_st, head_done, 0)) != hipSuccess) return e;
+        ts = tail_st;
+    }
+    if (n > 0) {
+        const uint32_t max_parts = slots / WCAP + nb + (nb >> WIDE_FB) + 1;
+        hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, ws->totals,
+                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part);
+    }
+    hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, ws->totals, ws->w_pstart, nb,
+                       ws->w_rc);
+    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts);
 }
 
 // `table` != nullptr selects the fixed-base mode: table[w * table_stride + i] = 2^(c w) P_i.
@@ -1028,6 +1481,10 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     if (n > ws->max_n || batch == 0 || batch > ws->max_batch) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const bool fixed = table != nullptr;
+    if (fixed && ws->wide && table_stride == ws->max_n)
+        return msm_run_wide(ws, scalars_list, batch, n, st, host_window_sums, nwin_out, c_out, accum_events, table, table_stride, tail_st,
+                            head_done, bases_may_be_identity);
+    if (c > 15) return hipErrorInvalidValue;  // 16-bit digits exist on the wide path only
     const bool fused = fixed && nb <= SORT_LDS_BUCKETS;  // one-kernel digits + histogram; 15-bit windows take the swept sort
     if (!fused && batch != 1) return hipErrorInvalidValue;  // columns are batched on the fused fixed-base path only
     const Fr* scalars = scalars_list[0];
@@ -1062,12 +1519,12 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
             hipLaunchKernelGGL(msm_recode_hist2_kernel, dim3(nblk, batch), dim3(256), (nb + 256 * 9) * 4, st, mb, n32, stride, c, nwin, nb,
                                ws->digits, ws->totals, ws->coarse, ws->coarse_stride);
             hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ws->totals, ws->bucket_start, nbt, ws->counts);
-            hipLaunchKernelGGL(msm_scan_coarse_kernel, dim3(batch), dim3(128), 0, st, ws->totals, nb, ws->coarse, ws->coarse_stride, nb >> 6);
+            hipLaunchKernelGGL(msm_scan_coarse_kernel, dim3(batch), dim3(CBINS_MAX), 0, st, ws->totals, nb, ws->coarse, ws->coarse_stride, nb >> 6, 6u);
             hipLaunchKernelGGL(msm_scatter1_kernel, dim3(nblk, batch), dim3(256), 0, st, ws->digits, n32, stride, nwin, nb, table_stride,
-                               ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride);
+                               ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride, 6u);
             const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> 6);
             hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                               ws->coarse_stride, nb, ws->totals, ws->bucket_start, ws->cursor, ws->entries);
+                               ws->coarse_stride, nb, ws->totals, ws->bucket_start, ws->cursor, ws->entries, 6u, PAD, (size_t)0);
         } else if (fused) {
             const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
             MsmBatch mb;
@@ -1103,10 +1560,10 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
         if (accum_events) hipEventRecord(accum_events[0], st);
         if (bases_may_be_identity) {
             hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                               fixed ? table : bases, ws->counts, ws->slot_pt);
+                               fixed ? table : bases, ws->counts, ws->slot_pt, 0u);
         } else {
             hipLaunchKernelGGL(msm_accumulate_fast_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                               fixed ? table : bases, ws->counts, ws->redo, ws->slot_pt);
+                               fixed ? table : bases, ws->counts, ws->redo, ws->slot_pt, 0u);
         }
         if (accum_events) hipEventRecord(accum_events[1], st);  // the dominant kernel alone (bench.py's roofline)
         if (!bases_may_be_identity)
@@ -1153,6 +1610,23 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
 // bit_sums[(w * c + t) * split + q]: partials of G_{w,t}, split = bitsum_split(2^(c-1));
 // result = sum_w 2^(c w) sum_t 2^t G_{w,t}  (Horner over all bit positions)
 uint32_t msm_sums_per_result(uint32_t c) { return c * bitsum_split(1u << (c - 1)); }
+
+uint32_t msm_ws_sums_per_result(const MsmWorkspace* ws) { return ws->wide ? WIDE_SUMS : msm_sums_per_result(ws->c); }
+
+// fixed-base mode: one column's result from its bit sums
+G1Jac msm_ws_finish_fixed(const MsmWorkspace* ws, const G1X* sums) {
+    if (!ws->wide) return msm_finish_host(sums, 1, ws->c);
+    // sum_{t < 9} 2^t S_t (columns of the bucket matrix, weight l + 1) + sum_u 2^(8 + u) S_{9 + u} (rows, weight 256 h)
+    uint32_t row_bits = 0;
+    while ((1u << row_bits) < (ws->nb >> 8)) row_bits++;
+    G1X acc = G1X::identity();
+    for (int pos = (int)(8 + row_bits) - 1; pos >= 0; pos--) {
+        if (!acc.is_identity()) acc = g1x_dbl(acc);
+        if (pos >= 8) g1x_add(acc, sums[9 + (pos - 8)]);
+        if (pos <= 8) g1x_add(acc, sums[pos]);
+    }
+    return g1x_to_jac(acc);
+}
 
 G1Jac msm_finish_host(const G1X* bit_sums, uint32_t nwin, uint32_t c) {
     const uint32_t split = bitsum_split(1u << (c - 1));
