@@ -31,7 +31,7 @@ for k, (d, c) in agg.items():
     tot += d
 print("sum", tot / 1e6)
 def is_tail(k):
-    return k.startswith("msm_gather") or k.startswith("msm_bitsum")
+    return k.startswith("msm_gather") or k.startswith("msm_bitsum") or k.startswith("msm_wparts") or k.startswith("msm_wrowcol") or k.startswith("msm_wbits")
 
 
 main = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, nm(r)) for r in seg if not is_tail(nm(r))]

@@ -482,10 +482,14 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
     const uint32_t* cpre = chdr + (CBINS_MAX + 1);
     if (blockIdx.x >= cpre[bins]) return;  // the grid is sized for the worst case
     if (threadIdx.x == 0) {
-        uint32_t b = 0;
-        while (cpre[b + 1] <= blockIdx.x) b++;
-        s_bin = b;
-        s_chunk = blockIdx.x - cpre[b];
+        uint32_t lo = 0, hi = bins;  // the bin whose chunk range holds blockIdx.x
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cpre[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        s_bin = lo;
+        s_chunk = blockIdx.x - cpre[lo];
     }
     if (threadIdx.x < keys) S.cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -1039,36 +1043,63 @@ __global__ __launch_bounds__(64) void msm_scan_coarse_wide_kernel(uint32_t* __re
     }
 }
 
-// one workgroup per (coarse bin, column): counts the bin's entries per fine key from `inter`, then the bin-local scans:
-// totals[b], bstart[b] (place of bucket b in the column's entry region; its range is padded to a multiple of SEG0),
-// pstart[b] and pbucket[] (the bucket's parts of at most WCAP slots, T1), and the fills of what the region holds beyond
-// the buckets (skip markers / no-part markers).
-__global__ __launch_bounds__(1024) void msm_binscan_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                          const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
-                                                          uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
+// per-bucket totals from the sorted intermediate list: one workgroup per chunk (<= SUB entries) of a coarse bin — the
+// decomposition of the second sort level — counts its entries per fine key in LDS and adds the 128 counts to totals[]
+// (zeroed by the clear kernel).  Chunks, not whole bins: witness-like columns put most of their entries into a few bins
+// (a permuted lookup column at k = 19: 400 K entries in bin 0 — one workgroup needed 200 us for them).
+__global__ __launch_bounds__(256) void msm_finehist_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                           const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
+                                                           uint32_t* __restrict__ totals_all) {
+    __shared__ uint32_t hist[WIDE_KEYS];
+    __shared__ uint32_t s_bin, s_chunk;
+    const uint32_t col = blockIdx.y;
+    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
+    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    const uint32_t bins = nb >> WIDE_FB;
+    const uint32_t* cpre = chdr + (CBINS_MAX + 1);
+    if (blockIdx.x >= cpre[bins]) return;  // the grid is sized for the worst case
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = bins;  // the bin whose chunk range holds blockIdx.x
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cpre[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        s_bin = lo;
+        s_chunk = blockIdx.x - cpre[lo];
+    }
+    if (threadIdx.x < WIDE_KEYS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    const uint32_t beg = chdr[bin] + s_chunk * SUB;
+    const uint32_t end = min(chdr[bin + 1], beg + SUB);
+    for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&hist[(inter[p] >> 24) & (WIDE_KEYS - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < WIDE_KEYS) {
+        const uint32_t cnt = hist[threadIdx.x];
+        if (cnt) atomicAdd(&totals_all[(size_t)col * nb + bin * WIDE_KEYS + threadIdx.x], cnt);
+    }
+}
+
+// one workgroup (two waves: a lane per bucket) per (coarse bin, column): the bin-local scans of the per-bucket totals:
+// bstart[b] (place of bucket b in the column's entry region; its range is padded to a multiple of SEG0), pstart[b] and
+// pbucket[] (the bucket's parts of at most WCAP slots, T1), and the fills of what the bin's regions hold beyond the buckets
+// (skip markers / no-part markers).
+__global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
+                                                          const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
                                                           uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket_all,
                                                           uint32_t part_stride, uint32_t* __restrict__ entries_all, size_t ent_stride) {
-    __shared__ uint32_t hist[WIDE_KEYS];
     __shared__ uint32_t wsum[4];
     constexpr uint32_t CB = CBINS_MAX + 1;
     const uint32_t col = blockIdx.y, bin = blockIdx.x;
-    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     uint32_t* __restrict__ pbucket = pbucket_all + (size_t)col * part_stride;
     uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
-    if (threadIdx.x < WIDE_KEYS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t beg = chdr[bin], end = chdr[bin + 1];
-    for (uint32_t p = beg + threadIdx.x; p < end; p += 1024) atomicAdd(&hist[(inter[p] >> 24) & (WIDE_KEYS - 1)], 1u);
-    __syncthreads();
-    // threads 0..127 = the bin's buckets (two waves): exclusive scans of the padded sizes and of the part counts
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t cnt = 0, h = 0, np = 0;
-    if (threadIdx.x < WIDE_KEYS) {
-        cnt = hist[threadIdx.x];
-        h = (cnt + SEG0 - 1) & ~(SEG0 - 1);
-        np = (h / SEG0 + WCAP - 1) / WCAP;
-    }
+    const uint32_t b = bin * WIDE_KEYS + threadIdx.x;
+    const uint32_t cnt = totals_all[(size_t)col * nb + b];
+    const uint32_t h = (cnt + SEG0 - 1) & ~(SEG0 - 1);
+    const uint32_t np = (h / SEG0 + WCAP - 1) / WCAP;
     uint32_t xe = h, xp = np;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t ye = __shfl_up(xe, off), yp = __shfl_up(xp, off);
@@ -1077,7 +1108,7 @@ __global__ __launch_bounds__(1024) void msm_binscan_kernel(const uint32_t* __res
             xp += yp;
         }
     }
-    if (lane == 63 && wave < 2) {
+    if (lane == 63) {
         wsum[2 * wave] = xe;
         wsum[2 * wave + 1] = xp;
     }
@@ -1085,16 +1116,12 @@ __global__ __launch_bounds__(1024) void msm_binscan_kernel(const uint32_t* __res
     const uint32_t ebase = chdr[3 * CB + bin], pbase = chdr[4 * CB + bin];
     const uint32_t eend = chdr[3 * CB + bin + 1], pend = chdr[4 * CB + bin + 1];
     const uint32_t e_used = wsum[0] + wsum[2], p_used = wsum[1] + wsum[3];
-    if (threadIdx.x < WIDE_KEYS) {
-        const uint32_t b = bin * WIDE_KEYS + threadIdx.x;
-        const uint32_t e0 = ebase + xe - h + (wave ? wsum[0] : 0), p0 = pbase + xp - np + (wave ? wsum[1] : 0);
-        totals_all[(size_t)col * nb + b] = cnt;
-        bstart_all[(size_t)col * nb + b] = e0;
-        pstart_all[(size_t)col * nb + b] = p0;
-        for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
-    }
-    for (uint32_t q = ebase + e_used + threadIdx.x; q < eend; q += 1024) entries[q] = SKIP_ENTRY;
-    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 1024) pbucket[q] = 0xffffffffu;
+    const uint32_t e0 = ebase + xe - h + (wave ? wsum[0] : 0), p0 = pbase + xp - np + (wave ? wsum[1] : 0);
+    bstart_all[(size_t)col * nb + b] = e0;
+    pstart_all[(size_t)col * nb + b] = p0;
+    for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
+    for (uint32_t q = ebase + e_used + threadIdx.x; q < eend; q += 128) entries[q] = SKIP_ENTRY;
+    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 128) pbucket[q] = 0xffffffffu;
 }
 
 // T1: part g of a column = up to WCAP consecutive slots of one bucket, summed serially by one lane; then the lanes of a wave
@@ -1434,10 +1461,11 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
                            ws->counts);
         hipLaunchKernelGGL(msm_scatter1_kernel, dim3(nblk, batch), dim3(256), 0, st, ws->digits, n32, stride, nwin, nb, table_stride,
                            ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride, WIDE_FB);
-        hipLaunchKernelGGL(msm_binscan_kernel, dim3(nb >> WIDE_FB, batch), dim3(1024), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, ws->entries,
-                           ws->w_ent_stride);
         const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> WIDE_FB);
+        hipLaunchKernelGGL(msm_finehist_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, nb, ws->totals);
+        hipLaunchKernelGGL(msm_binscan_kernel, dim3(nb >> WIDE_FB, batch), dim3(128), 0, st, ws->coarse, ws->coarse_stride, nb, ws->totals,
+                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, ws->entries, ws->w_ent_stride);
         hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
                            ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->cursor, ws->entries, WIDE_FB, SEG0, ws->w_ent_stride);
         if (accum_events) hipEventRecord(accum_events[0], st);
