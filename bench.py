@@ -56,7 +56,7 @@ class ProofWorkload:
         self.synth_s = (time.time() - t0) / len(self.jobs)
         fixed, copies = batch.structure(p)
         t0 = time.time()
-        self.pipes = [batch.Pipeline(device, p, fixed, copies) for _ in range(inflight)]
+        self.pipes = [batch.Pipeline(device, p, fixed, copies, deterministic_seeds=True) for _ in range(inflight)]
         self.keygen_s = (time.time() - t0) / inflight
         for q, pl in enumerate(self.pipes):
             for j in self.jobs[q::inflight]:

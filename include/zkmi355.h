@@ -23,8 +23,10 @@
  *     device is ZK_ENODEV;
  *   - a zk_ctx is bound to one HIP device and one stream and serialises its
  *     callers internally; use one context per worker thread / GPU;
- *   - the engine consumes no randomness: blinding values are
- *     supplied by the caller.
+ *   - the engine has no entropy source of its own: the seam and phase-level entry points are
+ *     deterministic maps, and the one entry point that needs blinding values, zk_prove, expands the 32-byte seed the
+ *     CALLER supplies with ChaCha20 (halo2's ChaCha20Rng stream and draw order) — the host draws that seed from its
+ *     own RNG (the reference uses OsRng, ecdsa_p256.rs:362,412,550); a fixed or predictable seed forfeits zero-knowledge.
  */
 #ifndef ZKMI355_H
 #define ZKMI355_H
@@ -139,6 +141,9 @@ int zk_coeff_to_extended(zk_ctx* ctx, zk_poly src, zk_poly dst_ext);
 int zk_extended_to_coeff(zk_ctx* ctx, zk_poly ext, size_t n_out);
 /* replaces arithmetic::eval_polynomial(poly, x) */
 int zk_eval(zk_ctx* ctx, zk_poly p, const uint64_t x_mont[4], uint64_t out_mont[4]);
+/* replaces arithmetic::kate_division(p, z): q = (p - p(z)) / (X - z).  q has p's length (its top coefficient is 0: the
+ * quotient is one coefficient shorter); q may be p (in place).  The multi-open provers (GWC / SHPLONK) divide with it. */
+int zk_kate_division(zk_ctx* ctx, zk_poly p, const uint64_t z_mont[4], zk_poly q);
 
 /* ---- keygen / create_proof ---------------------------------------------------
  * The config row that selects the column shape: reference CircuitParams

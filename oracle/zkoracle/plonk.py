@@ -56,8 +56,10 @@ class Shape:
         self.fx_const = list(range(F))
         self.fx_table = F
         if self.single:
-            self.fx_sel = [F + 1]          # q_enable
-            self.fx_qlookup = F + 2
+            # compress_selectors gives the selectors that occur in no gate (the complex q_lookup) their fixed columns
+            # first, then the simple ones [RECALLED plonk/circuit/compress_selectors.rs `process`; zkoracle/vkrepr.py]
+            self.fx_qlookup = F + 1
+            self.fx_sel = [F + 2]          # q_enable
             self.n_fix = F + 3
         else:
             self.fx_sel = [F + 1 + j for j in range(A - U)] + [None] * U

@@ -140,10 +140,12 @@ def build_sigma(shape: Shape, copies):
 
 
 def transcript_repr(shape: Shape, fixed_commitments, permutation_commitments):
-    """Stand-in for halo2's vk.transcript_repr (a Blake2b hash of the vk's pinned
-    Debug string — not reproducible without the Rust types): blake2b-512 over the
-    shape and the vk commitments, reduced mod r.  Only used for circuits built
-    here; the reference's own k=17 value is a fixture."""
+    """halo2's vk.transcript_repr: the Blake2b hash of the pinned verifying key's Debug rendering (zkoracle/vkrepr.py,
+    pinned by the reference's k = 17 value, P256Verifier.yul:34).  Shapes with never-enabled gate columns (whose
+    selector compression is not restated) keep a stand-in: blake2b-512 over the shape and the vk commitments."""
+    from . import vkrepr
+    if vkrepr.supported(shape):
+        return vkrepr.transcript_repr(shape, fixed_commitments, permutation_commitments)
     h = hashlib.blake2b(digest_size=64, person=b"zkmi355-vk-repr")
     for v in (shape.k, shape.num_advice, shape.num_lookup_advice, shape.num_fixed, shape.lookup_bits,
               shape.idle_gate_columns):

@@ -141,8 +141,11 @@ def pack_bits(bits):
 
 
 def vk_bytes(shape, fixed_commitments, permutation_commitments, selectors, fmt):
+    """`fixed_commitments` in the oracle's (query) order; the file lists them in halo2's column order (table first)."""
+    from .vkrepr import halo2_fixed_order
+
     out = be32(shape.k) + be32(len(fixed_commitments))
-    out += b"".join(g1_bytes(p, fmt) for p in fixed_commitments)
+    out += b"".join(g1_bytes(fixed_commitments[i], fmt) for i in halo2_fixed_order(shape))
     out += b"".join(g1_bytes(p, fmt) for p in permutation_commitments)
     out += b"".join(pack_bits(s) for s in selectors)
     return out
@@ -166,7 +169,12 @@ def vk_parse(shape, b, fmt):
         raw = b[pos:pos + shape.n // 8]
         sels.append([(raw[i >> 3] >> (i & 7)) & 1 for i in range(shape.n)])
         pos += shape.n // 8
-    return pts[:shape.n_fix], pts[shape.n_fix:], sels
+    from .vkrepr import halo2_fixed_order
+
+    fixed = [None] * shape.n_fix
+    for pos, i in enumerate(halo2_fixed_order(shape)):
+        fixed[i] = pts[pos]
+    return fixed, pts[shape.n_fix:], sels
 
 
 def poly_bytes(a_mont, fmt):
@@ -186,6 +194,9 @@ def pk_bytes(fpk, fixed_ints, fmt):
     l_active = fp.lin(fp.lin(one, 1, fpk.llast_e, R - 1), 1, fpk.lblind_e, R - 1)  # 1 - l_last - l_blind
     out = vk_bytes(sh, fpk.vk.fixed_commitments, fpk.vk.permutation_commitments, selectors_of(sh, fixed_ints), fmt)
     out += poly_bytes(fpk.l0_e, fmt) + poly_bytes(fpk.llast_e, fmt) + poly_bytes(l_active, fmt)
-    out += slice_bytes(fpk.fixed, fmt) + slice_bytes(fpk.fix_c, fmt) + slice_bytes(fpk.fix_e, fmt)
+    from .vkrepr import halo2_fixed_order
+
+    order = halo2_fixed_order(sh)  # fixed columns in halo2's column order (table first)
+    out += slice_bytes([fpk.fixed[i] for i in order], fmt) + slice_bytes([fpk.fix_c[i] for i in order], fmt) + slice_bytes([fpk.fix_e[i] for i in order], fmt)
     out += slice_bytes(fpk.sigma, fmt) + slice_bytes(fpk.sig_c, fmt) + slice_bytes(fpk.sig_e, fmt)
     return out

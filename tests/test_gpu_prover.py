@@ -260,7 +260,16 @@ def test_reference_api_mirror(engine, tmp_path):
     p, pk = api._STATE[0]["keys"][pkp]
     vk = product_vk(eng, pk, sh)
     assert plonk.verify(vk, pf, "blake2b") and plonk.verify(vk, pe, "evm")
-    assert os.path.getsize(vkp) == 12 + (6 + 6) * 64 + 32
+    # the verifying-key file is the VerifyingKey::write image (RawBytes, ecdsa_p256.rs:266-270): header, 6 + 6 commitments
+    # (fixed columns in halo2's column order), the 4 selector bit vectors — what the oracle's serialiser gives for this key
+    from zkoracle import serde as oserde
+    asg0 = zk.circuit.synthesize(p, 0)
+    want_vk = oserde.vk_bytes(sh, vk.fixed_commitments, vk.permutation_commitments, oserde.selectors_of(sh, asg0.fixed), oserde.RAW_BYTES)
+    assert os.path.getsize(vkp) == 8 + (6 + 6) * 64 + 4 * (1 << 17) // 8 and open(vkp, "rb").read() == want_vk
+    # /setup again under the same name: the resident key is replaced (the old one freed), not leaked
+    api.download_keys(17, pkp, None)
+    assert len(api._STATE[0]["keys"]) == 1
+    p, pk = api._STATE[0]["keys"][pkp]
     # the engine's real input: advice columns handed over by the host
     asg = zk.circuit.synthesize(p, api._witness_seed(*req))
     assert api.create_proof_from_advice([asg.to_limbs(c) for c in asg.advice], pkp, 17, E.ZK_TRANSCRIPT_EVM, rng_seed=bytes(32)) == pe
@@ -288,13 +297,13 @@ def test_batch_of_jobs_equals_lone_proofs():
     jobs = list(range(10))
     wit = batch.synthesize_jobs(p, jobs, processes=2)
     fixed, copies = batch.structure(p)
-    pipes = [batch.Pipeline(0, p, fixed, copies) for _ in range(2)]
+    pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True) for _ in range(2)]
     for q, pl in enumerate(pipes):
         for j in jobs[q::2]:
             pl.load(j, wit[j])
     got = batch.run(pipes, jobs, E.ZK_TRANSCRIPT_EVM)
     assert sorted(got) == jobs and len(set(got.values())) == len(jobs)
-    lone = batch.Pipeline(0, p, fixed, copies)
+    lone = batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)
     for j in jobs:
         lone.load(j, wit[j])
         assert lone.prove(j, E.ZK_TRANSCRIPT_EVM) == got[j]
@@ -453,3 +462,94 @@ def test_quotient_rows_on_adversarial_cosets(engine, name):
     for h in polys:
         h.free()
     engine.pk_free(pk)
+
+
+def _limbs(col):
+    """ints -> (n, 4) uint64 canonical little-endian limbs"""
+    a = np.zeros((len(col), 4), dtype=np.uint64)
+    for i, v in enumerate(col):
+        for q in range(4):
+            a[i, q] = (v >> (64 * q)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+@pytest.mark.parametrize("shape,seed", [((8, 3, 2, 2, 5), 1234), ((8, 3, 2, 2, 5), 99), ((8, 1, 1, 1, 5), 1234), ((8, 1, 1, 1, 5), 7),
+                                        ((9, 4, 1, 1, 6), 1234), ((10, 4, 1, 1, 7), 5)])
+def test_adversarial_layout_matches_plain_python_oracle(engine, shape, seed):
+    """zk_keygen / zk_prove on a column layout this repo's own generator (webauthn-halo2_amd/circuit.py) never
+    produces — tests/adversarial_layout.py: overlapping gates on irregular rows, copy cycles of up to 40 cells over all
+    permutation columns, constants on every row, lookup rows in one block, an all-zero gate column — byte-compared
+    with the plain-Python oracle prover (both transcripts), verifying-key commitments included."""
+    import adversarial_layout as adv
+
+    k, A, L, F, lb = shape
+    sh = plonk.Shape(k, A, L, F, lb)
+    fixed, copies, advice = adv.build(sh, seed)
+    adv.check(sh, fixed, copies, advice)
+    opk = prover.keygen(prover.Circuit(sh, fixed, copies, advice))
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    engine.srs_setup(k)
+    pk = engine.keygen(p, np.stack([_limbs(c) for c in fixed]), copies)
+    vk = product_vk(engine, pk, sh)
+    assert vk.fixed_commitments == opk.vk.fixed_commitments and vk.permutation_commitments == opk.vk.permutation_commitments
+    assert vk.transcript_repr == opk.vk.transcript_repr
+    polys = []
+    for col in advice:
+        h = engine.poly(1 << k)
+        engine.upload_canonical(h, _limbs(col))
+        polys.append(h)
+    rseed = bytes([seed & 0xFF]) * 32
+    for kind in ("evm", "blake2b"):
+        got = engine.prove(pk, polys, rseed, KIND[kind])
+        assert got == prover.create_proof(opk, advice, ChaCha20Rng(rseed), kind), (shape, seed, kind)
+        assert plonk.verify(opk.vk, got, kind)
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
+
+
+@pytest.mark.parametrize("name", ["k17like", "k19like", "wide", "k10batched"])
+def test_transcript_repr_is_halo2s_pinned_vk_hash(engine, name):
+    """zk_keygen stamps `transcript_repr` as halo2 does: the Blake2b hash of the pinned verifying key's Debug rendering
+    (csrc/vkrepr.h).  The oracle's restatement of that rendering (zkoracle/vkrepr.py) reproduces the reference's k = 17
+    literal (tests/test_oracle_kat.py, P256Verifier.yul:34); here the device-side rendering gives the same digest as the
+    oracle's for the key it has just made."""
+    from zkoracle import vkrepr
+
+    A, L, F, k, lb = SHAPES[name][:5]
+    p, asg, pk, polys = setup(engine, A, L, F, k, lb)
+    sh = plonk.Shape(k, A, L, F, lb)
+    vk = product_vk(engine, pk, sh)
+    assert vk.transcript_repr == vkrepr.transcript_repr(sh, vk.fixed_commitments, vk.permutation_commitments)
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
+
+
+def test_k19_batch_of_8_jobs_equals_committed_oracle_proofs():
+    """BASELINE configs[3] at its size: the first 8 jobs of the k = 19 batch workload (bench.py's timed steps) drained
+    by two resident pipelines through batch.run — 960-byte Blake2b + SHPLONK proofs, byte for byte the proofs the
+    oracle's CPU prover made for the same witness seeds and blinding streams (tests/golden/batch_k19_proofs.json)."""
+    import hashlib
+    import json
+
+    from webauthn_halo2_amd import batch
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch_k19_proofs.json")))
+    jobs = sorted(int(j) for j in fx["jobs"])
+    assert len(jobs) >= 8 and fx["degree"] == 19
+    p = zk.circuit.K19
+    wit = batch.synthesize_jobs(p, jobs)
+    fixed, copies = batch.structure(p)
+    pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True) for _ in range(2)]
+    for q, pl in enumerate(pipes):
+        for j in jobs[q::2]:
+            pl.load(j, wit[j])
+    got = batch.run(pipes, jobs, E.ZK_TRANSCRIPT_BLAKE2B)
+    for pl in pipes:
+        pl.close()
+    assert sorted(got) == jobs
+    for j in jobs:
+        assert len(got[j]) == 960
+        assert hashlib.sha256(got[j]).hexdigest() == fx["jobs"][str(j)]["sha256"], j
+        assert got[j].hex() == fx["jobs"][str(j)]["proof"], j

@@ -86,6 +86,10 @@ def test_engine_proof_fixture_verifies():
     vk, proof = load_engine_fixture()
     assert len(proof) == 2720
     assert plonk.verify(vk, proof, "evm")
+    # the digest the device stamped on its key is halo2's own: the hash of the pinned verifying key's Debug rendering
+    # (zkoracle/vkrepr.py, pinned by the reference's k = 17 literal in tests/test_oracle_kat.py)
+    from zkoracle import vkrepr
+    assert vk.transcript_repr == vkrepr.transcript_repr(vk.shape, vk.fixed_commitments, vk.permutation_commitments)
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/proving-server/P256Verifier.yul"),

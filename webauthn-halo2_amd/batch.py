@@ -12,6 +12,7 @@ exchanged between pipelines (§8e).
     Pipeline(device, params)             resident SRS + key on one device; .load(job, cols) / .prove(job)
     run(pipelines, jobs, transcript)     drains `jobs` over the pipelines (one host thread each) -> {job: proof}
 """
+import os
 import threading
 
 import numpy as np
@@ -27,8 +28,10 @@ def job_seed(i: int) -> int:
 
 
 def job_rng_seed(i: int) -> bytes:
-    """create_proof's RNG stream for job i (the reference draws from OsRng, ecdsa_p256.rs:412; a fixed
-    per-job seed makes a batch reproducible and comparable with lone proofs)."""
+    """A FIXED create_proof RNG stream for job i: makes a batch reproducible and comparable with lone proofs (tests,
+    bench.py).  The blinding of such a proof is predictable from the public job index, i.e. the proof is NOT
+    zero-knowledge — production callers leave Pipeline's default (os.urandom, as the reference draws from OsRng,
+    ecdsa_p256.rs:412)."""
     return (0x9E3779B97F4A7C15 * (i + 1) % (1 << 256)).to_bytes(32, "little")
 
 
@@ -70,8 +73,11 @@ def structure(params):
 class Pipeline:
     """One proof in flight: a zk_ctx on `device` with the SRS of params.degree and the proving key resident."""
 
-    def __init__(self, device, params, fixed=None, copies=None, engine_factory=Engine):
+    def __init__(self, device, params, fixed=None, copies=None, engine_factory=Engine, deterministic_seeds=False):
+        """deterministic_seeds: blinding from job_rng_seed(job) instead of the OS entropy source — reproducible
+        proofs for tests and benchmarks, at the price of zero-knowledge (see job_rng_seed)."""
         self.params = params
+        self.deterministic_seeds = deterministic_seeds
         self.eng = engine_factory(device)
         self.eng.srs_setup(params.degree)
         if fixed is None:
@@ -89,8 +95,10 @@ class Pipeline:
             polys.append(h)
         self.resident[job] = polys
 
-    def prove(self, job, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False):
-        proof = self.eng.prove(self.pk, self.resident[job], job_rng_seed(job), transcript)
+    def prove(self, job, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False, rng_seed=None):
+        if rng_seed is None:
+            rng_seed = job_rng_seed(job) if self.deterministic_seeds else os.urandom(32)
+        proof = self.eng.prove(self.pk, self.resident[job], rng_seed, transcript)
         if not keep:
             self.unload(job)
         return proof

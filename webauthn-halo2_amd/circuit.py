@@ -61,8 +61,9 @@ class Layout:
         self.n_adv = A + self.n_lookup_cols
         self.fx_table = F
         if self.single:
-            self.fx_sel = [F + 1]
-            self.fx_qlookup = F + 2
+            # halo2's selector compression allocates the complex selector's fixed column before the gate selector's
+            self.fx_qlookup = F + 1
+            self.fx_sel = [F + 2]
             self.n_fix = F + 3
         else:
             U = p.idle_gate_columns

@@ -961,3 +961,26 @@ ZK_API(zk_eval, (zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]), (c
     return ZK_OK;
 }
 
+namespace zk {
+uint32_t kate_division_scratch(uint32_t n);  // prover_kernels.hip
+void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* scratch, hipStream_t st);
+}  // namespace zk
+
+ZK_API(zk_kate_division, (zk_ctx* c, zk_poly hp, const uint64_t z[4], zk_poly hq), (c, hp, z, hq)) {
+    if (!c || !z) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* p = find_poly(c, hp);
+    PolyRec* q = find_poly(c, hq);
+    if (!p || !q || p->n != q->n || p->n == 0 || p->n > ((size_t)1 << 26)) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    if ((rc = ctx_ensure_scratch(c, kate_division_scratch((uint32_t)p->n)))) return rc;
+    Fr zz;
+    memcpy(&zz, z, 32);
+    launch_kate_division(p->ptr, q->ptr, (uint32_t)p->n, zz, c->scratch, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+

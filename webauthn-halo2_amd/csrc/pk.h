@@ -35,8 +35,10 @@ struct Layout {
         fx_table = F;
         fx_sel.clear();
         if (single) {
-            fx_sel.push_back(F + 1);
-            fx_qlookup = F + 2;
+            // halo2's compress_selectors gives the selectors that occur in no gate (the complex q_lookup) their fixed columns
+            // first, then the simple ones (vkrepr.h)
+            fx_qlookup = F + 1;
+            fx_sel.push_back(F + 2);
             n_fix = F + 3;
         } else {
             for (uint32_t j = 0; j < A; j++) fx_sel.push_back(j < A - idle ? F + 1 + j : NO_SELECTOR);
@@ -128,5 +130,6 @@ void pk_destroy(zk_pk_rec* pk);
 // the per-proof workspace (advice / z / lookup forms, quotient buffer, scan and evaluation scratch): everything a key
 // needs beyond the key material itself; called at the end of zk_keygen and zk_pk_read
 int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk);
-// stand-in transcript_repr of a key made here (same rule as the oracle's keygen); a host-supplied value replaces it
+// transcript_repr of a key made or read here: halo2.s own hash of the pinned verifying key (vkrepr.h); a stand-in for the shapes
+// that rendering does not cover; a host-supplied value replaces either
 Fr pk_standin_transcript_repr(const zk_pk_rec* pk);

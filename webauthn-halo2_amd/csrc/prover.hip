@@ -21,6 +21,7 @@
 
 #include "pk.h"
 #include "transcript.h"
+#include "vkrepr.h"
 
 using namespace zk;
 
@@ -122,9 +123,12 @@ void pk_destroy_all(zk_ctx* c) {
     c->pks.clear();
 }
 
+// halo2's transcript_repr of a key made (or read) here: the hash of the pinned verifying key's Debug rendering
+// (vkrepr.h).  Shapes with never-enabled gate columns, whose selector compression is not restated, keep a stand-in hash
+// over the shape and the commitments (same rule as the oracle's keygen); a host-supplied value replaces either.
 Fr pk_standin_transcript_repr(const zk_pk_rec* pk) {
     const Layout& lay = pk->lay;
-    // stand-in for halo2's pinned-vk hash (same rule as the oracle's keygen)
+    if (vkrepr::supported(lay)) return vkrepr::transcript_repr(lay, pk->fixed_commit, pk->perm_commit);
     {
         Blake2b h("zkmi355-vk-repr");
         const uint16_t hdr[6] = {(uint16_t)lay.k, (uint16_t)lay.A,           (uint16_t)lay.L,

@@ -697,8 +697,18 @@ void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t 
 #ifndef ZK_KD_L
 #define ZK_KD_L 8
 #endif
-static constexpr uint32_t KD_L = ZK_KD_L;  // power of two; 8: 4x the lanes of 32 (a 2^19 division is 65 536 Horner chains of 8 instead of 16 384 of 32: -0.1 ms per k=19 proof, -0.3 ms at k=15..17), top level still <= 1024 blocks up to 2^21
+// shortest chunk (power of two): 8: 4x the lanes of 32 (a 2^19 division is 65 536 Horner chains of 8 instead of 16 384 of 32:
+// -0.1 ms per k=19 proof, -0.3 ms at k=15..17)
+static constexpr uint32_t KD_L_MIN = ZK_KD_L;
 static constexpr uint32_t KD_BLK = 256;
+static constexpr uint32_t KD_TOP = 1024;  // blocks the one-workgroup top level scans
+// chunk length of an n-coefficient division: the shortest that keeps the top level within ONE workgroup (8 up to 2^21,
+// 16 at 2^22, ...)
+__host__ __device__ inline uint32_t kd_len(uint32_t n) {
+    uint32_t L = KD_L_MIN;
+    while (((n + L - 1) / L + KD_BLK - 1) / KD_BLK > KD_TOP) L <<= 1;
+    return L;
+}
 
 struct KdPtrs {
     const Fr* p[KD_MAX_BATCH];
@@ -717,12 +727,13 @@ struct KdZ {
 
 // per-division scratch: cval[m] | suf[m] | agg[nblk] | G[nblk] | zpow[256]
 __host__ __device__ inline uint32_t kd_scratch_elems(uint32_t n) {
-    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
+    const uint32_t L = kd_len(n), m = (n + L - 1) / L, nblk = (m + KD_BLK - 1) / KD_BLK;
     return 2 * m + 2 * nblk + 256;
 }
 uint32_t kate_division_scratch(uint32_t n) { return kd_scratch_elems(n); }
 
 __global__ void kd_chunk_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
+    const uint32_t KD_L = kd_len(n);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = t * KD_L;
     if (base >= n) return;
@@ -743,6 +754,7 @@ __global__ void kd_chunk_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) 
 //   kd_apply       K_t = suf[t+1] (same block) + Z^(last_in_block - t) G_B
 __global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(KdStep pw, uint32_t n, Fr* __restrict__ scratch) {
     __shared__ Fr sh[KD_BLK];
+    const uint32_t KD_L = kd_len(n);
     const uint32_t m = (n + KD_L - 1) / KD_L;
     Fr* cval = scratch + (size_t)blockIdx.y * kd_scratch_elems(n);
     Fr* suf = cval + m;
@@ -767,9 +779,10 @@ __global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(KdStep pw, uint32
     if (threadIdx.x == 0) fe_store(agg + blockIdx.x, v);
 }
 
-// G[B] = sum_{B' > B} S_{B'} (Z^256)^(B'-B-1); nblk <= 1024.  blockIdx.x = division.
-__global__ __launch_bounds__(1024) void kd_top_kernel(KdTop pw, uint32_t n, Fr* __restrict__ scratch) {
-    __shared__ Fr sh[1024];
+// G[B] = sum_{B' > B} S_{B'} (Z^256)^(B'-B-1); nblk <= KD_TOP by the choice of the chunk length.  blockIdx.x = division.
+__global__ __launch_bounds__(KD_TOP) void kd_top_kernel(KdTop pw, uint32_t n, Fr* __restrict__ scratch) {
+    __shared__ Fr sh[KD_TOP];
+    const uint32_t KD_L = kd_len(n);
     const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
     Fr* agg = scratch + (size_t)blockIdx.x * kd_scratch_elems(n) + 2 * m;
     Fr* G = agg + nblk;
@@ -793,6 +806,7 @@ __global__ __launch_bounds__(1024) void kd_top_kernel(KdTop pw, uint32_t n, Fr* 
 }
 
 __global__ void kd_apply_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
+    const uint32_t KD_L = kd_len(n);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = t * KD_L;
     if (base >= n) return;
@@ -819,6 +833,7 @@ __global__ void kd_apply_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) 
 
 // zpow[i] = Z^i, i < 256 (one workgroup per division)
 __global__ __launch_bounds__(256) void kd_zpow_kernel(KdZ zz, uint32_t n, Fr* __restrict__ scratch) {
+    const uint32_t KD_L = kd_len(n);
     const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
     Fr* zpow = scratch + (size_t)blockIdx.x * kd_scratch_elems(n) + 2 * m + 2 * nblk;
     Fr acc = Fr::one(), base = zz.Z[blockIdx.x];
@@ -832,6 +847,7 @@ __global__ __launch_bounds__(256) void kd_zpow_kernel(KdZ zz, uint32_t n, Fr* __
 // `count` <= KD_MAX_BATCH divisions q[i] = (p[i] - p[i](z[i])) / (X - z[i]); scratch: count * kate_division_scratch(n)
 void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, uint32_t count, uint32_t n, Fr* scratch,
                                 hipStream_t st) {
+    const uint32_t KD_L = kd_len(n);
     const uint32_t m = (n + KD_L - 1) / KD_L;
     const uint32_t nblk = (m + KD_BLK - 1) / KD_BLK;
     KdPtrs pt;
@@ -847,7 +863,7 @@ void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, u
         pt.q[b] = q[b];
         pt.z[b] = z[b];
         Fr Z = z[b];
-        for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^32
+        for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^KD_L
         zz.Z[b] = Z;
         Fr cur = Z;
         for (int j = 0; j < 8; j++) {
@@ -863,7 +879,7 @@ void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, u
     hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st, pt, n, scratch);
     hipLaunchKernelGGL(kd_zpow_kernel, dim3(count), dim3(256), 0, st, zz, n, scratch);
     hipLaunchKernelGGL(kd_block_scan_kernel, dim3(nblk, count), dim3(KD_BLK), 0, st, stp, n, scratch);
-    hipLaunchKernelGGL(kd_top_kernel, dim3(count), dim3(1024), 0, st, tp, n, scratch);
+    hipLaunchKernelGGL(kd_top_kernel, dim3(count), dim3(KD_TOP), 0, st, tp, n, scratch);
     hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st, pt, n, scratch);
 }
 

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include "pk.h"
+#include "vkrepr.h"
 
 namespace zk {
 void launch_to_mont(Fr* a, uint32_t n, hipStream_t st);
@@ -568,8 +569,8 @@ int write_vk(zk_ctx* c, const zk_pk_rec* pk, int format, Out& o) {
     const Layout& lay = pk->lay;
     if (uint8_t* p = o.take(4)) put_be32(p, lay.k);
     if (uint8_t* p = o.take(4)) put_be32(p, lay.n_fix);
-    for (const G1Affine& cm : pk->fixed_commit)
-        if (uint8_t* p = o.take(g1_size(format))) host_g1_write(cm, format, p);
+    for (uint32_t i : vkrepr::halo2_fixed_order(lay))  // halo2's column order: the table column first (vkrepr.h)
+        if (uint8_t* p = o.take(g1_size(format))) host_g1_write(pk->fixed_commit[i], format, p);
     for (const G1Affine& cm : pk->perm_commit)
         if (uint8_t* p = o.take(g1_size(format))) host_g1_write(cm, format, p);
     if (!o.real) {
@@ -593,11 +594,14 @@ int parse_vk(const Layout& lay, In& in, int format, ParsedVk* out) {
     if (!p || get_be32(p) != lay.k || get_be32(p + 4) != lay.n_fix) return ZK_EINVAL;
     out->fixed.resize(lay.n_fix);
     out->perm.resize(lay.perm_cols.size());
-    for (auto* v : {&out->fixed, &out->perm})
-        for (G1Affine& cm : *v) {
-            const uint8_t* b = in.take(g1_size(format));
-            if (!b || !host_g1_read(b, format, &cm)) return ZK_EINVAL;
-        }
+    for (uint32_t i : vkrepr::halo2_fixed_order(lay)) {  // the file lists the fixed columns in halo2's column order
+        const uint8_t* b = in.take(g1_size(format));
+        if (!b || !host_g1_read(b, format, &out->fixed[i])) return ZK_EINVAL;
+    }
+    for (G1Affine& cm : out->perm) {
+        const uint8_t* b = in.take(g1_size(format));
+        if (!b || !host_g1_read(b, format, &cm)) return ZK_EINVAL;
+    }
     out->selectors.assign(n_selectors(lay), std::vector<uint8_t>(lay.n / 8));
     for (auto& s : out->selectors) {
         const uint8_t* b = in.take(s.size());
@@ -697,14 +701,18 @@ ZK_API(zk_pk_write, (zk_ctx* c, zk_pk h, int format, uint8_t* out, size_t cap, s
     if ((rc = write_poly(c, pk->l0_coset, N, format, o, tmp)) || (rc = write_poly(c, pk->l_last_coset, N, format, o, tmp)) ||
         (rc = write_poly(c, pk->l_active_coset, N, format, o, tmp)))
         return rc;
-    auto slice = [&](const std::vector<Fr*>& v, size_t len_each) -> int {
+    // fixed columns in halo2's column order (table first), permutation columns as they are
+    const std::vector<uint32_t> forder = vkrepr::halo2_fixed_order(lay);
+    std::vector<uint32_t> sorder(lay.perm_cols.size());
+    for (uint32_t i = 0; i < sorder.size(); i++) sorder[i] = i;
+    auto slice = [&](const std::vector<Fr*>& v, const std::vector<uint32_t>& order, size_t len_each) -> int {
         if (uint8_t* p = o.take(4)) put_be32(p, (uint32_t)v.size());
-        for (Fr* d : v)
-            if (int r = write_poly(c, d, len_each, format, o, tmp)) return r;
+        for (uint32_t i : order)
+            if (int r = write_poly(c, v[i], len_each, format, o, tmp)) return r;
         return ZK_OK;
     };
-    if ((rc = slice(pk->fixed_val, n)) || (rc = slice(pk->fixed_poly, n)) || (rc = slice(pk->fixed_coset, N)) ||
-        (rc = slice(pk->sigma_val, n)) || (rc = slice(pk->sigma_poly, n)) || (rc = slice(pk->sigma_coset, N)))
+    if ((rc = slice(pk->fixed_val, forder, n)) || (rc = slice(pk->fixed_poly, forder, n)) || (rc = slice(pk->fixed_coset, forder, N)) ||
+        (rc = slice(pk->sigma_val, sorder, n)) || (rc = slice(pk->sigma_poly, sorder, n)) || (rc = slice(pk->sigma_coset, sorder, N)))
         return rc;
     return o.pos == *len && o.real ? ZK_OK : ZK_EINTERNAL;
 }
@@ -748,19 +756,25 @@ ZK_API(zk_pk_read, (zk_ctx* c, const zk_circuit_params* params, const uint8_t* b
         if ((rc = read_poly(c, in, N, format, pk->l0_coset, d_err)) || (rc = read_poly(c, in, N, format, pk->l_last_coset, d_err)) ||
             (rc = read_poly(c, in, N, format, pk->l_active_coset, d_err)))
             return fail(rc);
-        auto slice = [&](std::vector<Fr*>& v, size_t count, size_t len_each) -> int {
+        // the file lists the fixed columns in halo2's column order (table first): column `pos` of a slice is the
+        // engine's column order[pos]
+        const std::vector<uint32_t> forder = vkrepr::halo2_fixed_order(lay);
+        std::vector<uint32_t> sorder(m);
+        for (uint32_t i = 0; i < m; i++) sorder[i] = i;
+        auto slice = [&](std::vector<Fr*>& v, const std::vector<uint32_t>& order, size_t len_each) -> int {
             const uint8_t* hcount = in.take(4);
-            if (!hcount || get_be32(hcount) != count) return ZK_EINVAL;
-            for (size_t i = 0; i < count; i++) {
+            if (!hcount || get_be32(hcount) != order.size()) return ZK_EINVAL;
+            v.assign(order.size(), nullptr);
+            for (uint32_t i : order) {
                 Fr* p = d.alloc(len_each);
                 if (d.rc) return d.rc;
-                v.push_back(p);
+                v[i] = p;
                 if (int r = read_poly(c, in, len_each, format, p, d_err)) return r;
             }
             return ZK_OK;
         };
-        if ((rc = slice(pk->fixed_val, lay.n_fix, n)) || (rc = slice(pk->fixed_poly, lay.n_fix, n)) || (rc = slice(pk->fixed_coset, lay.n_fix, N)) ||
-            (rc = slice(pk->sigma_val, m, n)) || (rc = slice(pk->sigma_poly, m, n)) || (rc = slice(pk->sigma_coset, m, N)))
+        if ((rc = slice(pk->fixed_val, forder, n)) || (rc = slice(pk->fixed_poly, forder, n)) || (rc = slice(pk->fixed_coset, forder, N)) ||
+            (rc = slice(pk->sigma_val, sorder, n)) || (rc = slice(pk->sigma_poly, sorder, n)) || (rc = slice(pk->sigma_coset, sorder, N)))
             return fail(rc);
         if (in.pos != len) return fail(ZK_EINVAL);
         uint32_t herr = 0;

@@ -67,19 +67,22 @@ def gen_srs(degree: int, device: int = 0) -> Engine:
 
 def download_keys(degree: int, proving_key_path=None, verifying_key_path=None, device: int = 0):
     """keygen_vk + keygen_pk for the ECDSA-shape circuit.  The proving key stays on the device
-    (registered under `proving_key_path`); the verifying key (commitments + transcript_repr) is
-    written to `verifying_key_path` if given."""
+    (registered under `proving_key_path`; a key already registered under that name is freed first); the
+    verifying key is written to `verifying_key_path` if given, as the reference writes it
+    (`vk.to_bytes(SerdeFormat::RawBytes)`, ecdsa_p256.rs:266-270: the VerifyingKey::write image of zk_vk_write)."""
     eng = gen_srs(degree, device)
     p = _config_for(degree)
     asg = circuit.synthesize(p, 0)  # structure only: fixed columns and copy constraints
     fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    keys = _STATE[device]["keys"]
+    name = proving_key_path or "<default>"
+    if name in keys:  # /setup called again: the resident key (GBs at k = 17 / 19) is replaced, not leaked
+        eng.pk_free(keys.pop(name)[1])
     pk = eng.keygen(p, fixed, asg.copies)
-    _STATE[device]["keys"][proving_key_path or "<default>"] = (p, pk)
+    keys[name] = (p, pk)
     if verifying_key_path:
-        fc, pc, tr = eng.vk_export(pk)
         with open(verifying_key_path, "wb") as f:
-            f.write(np.uint32([degree, fc.shape[0], pc.shape[0]]).tobytes())
-            f.write(fc.tobytes() + pc.tobytes() + tr.tobytes())
+            f.write(eng.vk_write(pk).tobytes())
     return pk
 
 

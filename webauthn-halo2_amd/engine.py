@@ -85,6 +85,7 @@ def load_library():
         "zk_extended_to_coeff": ([vp, ctypes.c_uint64, sz], ctypes.c_int),
         "zk_eval": ([vp, ctypes.c_uint64, u64p, u64p], ctypes.c_int),
         "zk_last_kernel_ms": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
+        "zk_kate_division": ([vp, ctypes.c_uint64, u64p, ctypes.c_uint64], ctypes.c_int),
         "zk_timer_reset": ([vp], ctypes.c_int),
         "zk_timer_stats": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, sz, ctypes.POINTER(ctypes.c_uint32), sz,
@@ -308,6 +309,11 @@ class Engine:
         out = np.zeros(4, dtype=np.uint64)
         self._chk(self.L.zk_eval(self.ctx, p.h, _p(x), _p(out)), "zk_eval")
         return out
+
+    def kate_division(self, p, z_mont, q=None):
+        """arithmetic::kate_division: q = (p - p(z)) / (X - z), same length as p (top coefficient 0); in place by default."""
+        z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(4)
+        self._chk(self.L.zk_kate_division(self.ctx, p.h, _p(z), (q or p).h), "zk_kate_division")
 
     def upload_canonical(self, p, data):
         d = _arr(data, 4)
