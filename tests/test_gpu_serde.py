@@ -42,6 +42,10 @@ def test_srs_file_equals_the_oracle_image_and_round_trips(fmt):
     for cut in (img[:-1], img + b"\0", img[:3], b"\x40\0\0\0" + img[4:]):
         with pytest.raises(zk.ZkError):
             other.srs_read(cut, fmt)
+    # a refused file leaves the resident SRS (and what was made under it) untouched: the image is decoded and validated
+    # into fresh buffers and swapped in only on success
+    assert other.srs_write(E.ZK_SERDE_RAW_BYTES).tobytes() == serde.srs_bytes(k, E.ZK_SERDE_RAW_BYTES)
+    assert np.array_equal(other.commit(other.poly(1 << k, a), 1), eng.commit(eng.poly(1 << k, a), 1))
     # an SRS adopted from arrays has no G2 half until the host supplies it
     third = zk.Engine(0)
     third.srs_load(k, eng.srs_export(0, 0, 1 << k), eng.srs_export(1, 0, 1 << k))
@@ -117,6 +121,12 @@ def test_key_files_equal_the_oracle_images_and_round_trip(name):
                                          num_fixed=p.num_fixed, lookup_bits=p.lookup_bits)
         with pytest.raises(zk.ZkError):
             other.pk_read(wrong, pk_img, fmt)
+        # a key written under ANOTHER SRS (same size, another secret) is refused: its commitments are not those of the
+        # resident bases (spot check on the table column)
+        other.srs_setup(sh.k, bytes([9]) * 32)
+        with pytest.raises(zk.ZkError) as e:
+            other.pk_read(p, pk_img, fmt)
+        assert e.value.code == -1
         other.close()
     eng.close()
 

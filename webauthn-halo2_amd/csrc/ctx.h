@@ -131,5 +131,8 @@ uint32_t ctx_ntt_max_batch(uint32_t log_n);
 void pk_destroy_all(zk_ctx* c);
 // SRS plumbing shared by engine.hip (setup / load) and serde.hip (read)
 int srs_alloc(zk_ctx* c, uint32_t k);
+// replaces the resident SRS by two decoded, validated bases of 2^k points (device buffers the context takes over);
+// the previous SRS, its window tables and every key made under it are dropped only now
+void srs_adopt(zk_ctx* c, uint32_t k, G1Affine* g, G1Affine* g_lagrange);
 int srs_build_tables(zk_ctx* c, uint32_t k);
 void srs_set_g2_from_secret(zk_ctx* c, const Fr& s_mont);

@@ -562,6 +562,21 @@ int srs_build_tables(zk_ctx* c, uint32_t k) {
     return ZK_OK;
 }
 
+void srs_adopt(zk_ctx* c, uint32_t k, G1Affine* g, G1Affine* g_lagrange) {
+    (void)k;
+    c->g2_valid = false;
+    c->srs_gen++;  // proving keys made under the previous SRS are refused from now on (ZK_ESTATE)
+    if (c->g) hipFree(c->g);
+    if (c->g_lagrange) hipFree(c->g_lagrange);
+    if (c->g_table) hipFree(c->g_table);
+    if (c->g_lagrange_table) hipFree(c->g_lagrange_table);
+    c->g_table = c->g_lagrange_table = nullptr;
+    c->table_c = 0;
+    c->srs_k = -1;
+    c->g = g;
+    c->g_lagrange = g_lagrange;
+}
+
 int srs_alloc(zk_ctx* c, uint32_t k) {
     if (k < 1 || k > 24) return ZK_EINVAL;
     c->g2_valid = false;

@@ -753,6 +753,14 @@ __global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X29S* __restric
     g1x29_store(partial + t, acc);
 }
 
+// Parts of bucket b that the second-level gather writes and the bit sums read — ONE definition for both kernels: the
+// parts are not reset between MSMs (msm_run), so a disagreement would make the bit sums read a previous MSM's sums.
+// -DZK_MSM_POISON fills the parts with a non-point before every MSM to catch exactly that.
+__device__ __forceinline__ uint32_t msm_used_parts(const uint32_t* __restrict__ bucket_start, uint32_t b, uint32_t parts) {
+    const uint32_t len = bucket_start[b + 1] / PAD - bucket_start[b] / PAD;
+    return min(parts, (len + GSHARE - 1) / GSHARE);
+}
+
 // Second level: one LANES-lane group per (bucket b, part p) sums the p-th share of the bucket's
 // first-level partials ([start_b / PAD, start_{b+1} / PAD) — contiguous, all of bucket b): lanes
 // stride over the share, then a shuffle tree.  A bucket uses ceil(partials / (4 * LANES)) parts
@@ -774,7 +782,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
         b = gid - p * nbk;
         const uint32_t s0 = bucket_start[b] / PAD, s1 = bucket_start[b + 1] / PAD;
         const uint32_t len = s1 - s0;
-        const uint32_t used = min(parts, (len + GSHARE - 1) / GSHARE);
+        const uint32_t used = msm_used_parts(bucket_start, b, parts);
         if (p < used) {
             active = true;
             const uint32_t share = (len + used - 1) / used;
@@ -851,10 +859,7 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
     const uint32_t items = t + 1 < c ? nb >> 1 : 1;
     uint32_t i = q * THREADS + threadIdx.x, k = 0;
     // parts of a bucket the gather kernel wrote (the others are identity and not worth a round trip to memory)
-    const auto used_parts = [&](uint32_t b) {
-        const uint32_t len = bucket_start[b + 1] / PAD - bucket_start[b] / PAD;
-        return min(parts, (len + GSHARE - 1) / GSHARE);
-    };
+    const auto used_parts = [&](uint32_t b) { return msm_used_parts(bucket_start, b, parts); };
     const auto multiplier = [&](uint32_t ii) { return t + 1 < c ? (((ii >> t) << (t + 1)) | (1u << t) | (ii & ((1u << t) - 1))) : nb; };
     uint32_t used = 0;
     ZK_STAMP(0);
@@ -1525,6 +1530,9 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     {
         // the bucket parts need no reset: the bit sums read only the parts the gather wrote (msm_bitsum_kernel used_parts);
         // an empty MSM runs no gather, so its parts are set to the identity here
+#ifdef ZK_MSM_POISON
+        hipMemsetAsync(ws->part, 0xA5, (size_t)nbt * parts * sizeof(G1X29S), st);  // debug: any part read without being written shows
+#endif
         const uint32_t clear_parts = n > 0 ? 0u : nbt * parts;
         uint32_t m = nbt + 1;
         if (clear_parts > m) m = clear_parts;

@@ -486,18 +486,30 @@ ZK_API(zk_srs_read, (zk_ctx* c, const uint8_t* bytes, size_t len, int format), (
     if (!host_g2_read(bytes + 4 + 2 * n * gs, format, g2) || !host_g2_read(bytes + 4 + 2 * n * gs + g2_size(format), format, s_g2)) return ZK_EINVAL;
     int rc = ctx_bind(c);
     if (rc) return rc;
-    if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
+    // decode and validate into fresh buffers: a malformed file leaves the resident SRS, its tables and the keys made under
+    // it as they were (they are replaced only once every point has been accepted)
+    G1Affine* fresh[2] = {nullptr, nullptr};
     uint32_t* d_err = nullptr;
     uint8_t* tmp = nullptr;
-    if (hipMalloc(&d_err, 4) != hipSuccess) return ZK_ENOMEM;
+    auto drop = [&]() {
+        hipFree(fresh[0]);
+        hipFree(fresh[1]);
+        hipFree(d_err);
+        hipFree(tmp);
+    };
+    if (hipMalloc(&fresh[0], n * sizeof(G1Affine)) != hipSuccess || hipMalloc(&fresh[1], n * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc(&d_err, 4) != hipSuccess) {
+        drop();
+        return ZK_ENOMEM;
+    }
     hipMemsetAsync(d_err, 0, 4, c->stream);
     hipError_t e = hipSuccess;
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        G1Affine* dst = b ? c->g_lagrange : c->g;
+        G1Affine* dst = fresh[b];
         const uint8_t* src = bytes + 4 + (size_t)b * n * gs;
         if (format == ZK_SERDE_PROCESSED) {
             if (!tmp && hipMalloc(&tmp, n * 32) != hipSuccess) {
-                hipFree(d_err);
+                drop();
                 return ZK_ENOMEM;
             }
             e = hipMemcpyAsync(tmp, src, n * 32, hipMemcpyHostToDevice, c->stream);
@@ -512,13 +524,18 @@ ZK_API(zk_srs_read, (zk_ctx* c, const uint8_t* bytes, size_t len, int format), (
     uint32_t herr = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_err);
-    hipFree(tmp);
     if (e != hipSuccess) {
+        drop();
         c->last_hip = (int)e;
         return ZK_EHIP;
     }
-    if (herr) return ZK_EINVAL;  // a point off the curve / a non-canonical coordinate: halo2's read fails the same way
+    if (herr) {  // a point off the curve / a non-canonical coordinate: halo2's read fails the same way
+        drop();
+        return ZK_EINVAL;
+    }
+    hipFree(d_err);
+    hipFree(tmp);
+    srs_adopt(c, k, fresh[0], fresh[1]);
     if ((rc = srs_build_tables(c, k)) != ZK_OK) return rc;
     c->srs_k = (int)k;
     memcpy(c->g2_raw, g2, 128);
@@ -798,6 +815,18 @@ ZK_API(zk_pk_read, (zk_ctx* c, const zk_circuit_params* params, const uint8_t* b
         }
         hipFree(d_err);
         d_err = nullptr;
+        // the file's commitments must belong to the RESIDENT SRS: a key written under another SRS would be stamped with
+        // this context's SRS generation and yield proofs that do not verify.  Spot check: the table column (never zero)
+        // recommitted in both of its forms
+        {
+            G1Jac j1, j2;
+            if ((rc = ctx_msm_device(c, pk->fixed_val[lay.fx_table], c->g_lagrange, n, &j1)) ||
+                (rc = ctx_msm_device(c, pk->fixed_poly[lay.fx_table], c->g, n, &j2)))
+                return fail(rc);
+            const G1Affine a1 = g1_jac_to_affine_host(j1), a2 = g1_jac_to_affine_host(j2);
+            if (memcmp(&a1, &pk->fixed_commit[lay.fx_table], sizeof(G1Affine)) != 0 || memcmp(&a2, &a1, sizeof(G1Affine)) != 0)
+                return fail(ZK_EINVAL);
+        }
         pk->transcript_repr = pk_standin_transcript_repr(pk);
         if ((rc = pk_alloc_workspace(c, pk))) return fail(rc);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
