@@ -932,7 +932,14 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
 //     taken bit by bit (log2(rows) + 9 tree reductions per column); the host runs the 16-step Horner.
 static constexpr uint32_t WIDE_FB = 7;    // fine key bits: 128 buckets per coarse bin
 static constexpr uint32_t WIDE_KEYS = 1u << WIDE_FB;
-static constexpr uint32_t WCAP = 8;       // slots per part (T1's serial run)
+// slots per part (T1's serial run), a per-pass parameter.  8 everywhere: lane-serial additions are the cheap ones (every lane
+// busy); shorter runs for a lone column — whose tail is exposed latency — were measured (tools/single_ab.py, k = 19 single
+// proof): 8: 12.37-12.41 ms, 4: 12.41-12.49, 2: 12.55-12.60 (more waves and more tree levels cost what the shorter chain saves)
+static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = 8;  // WCAP_MIN sizes the part lists
+#ifndef ZK_WCAP_ONE
+#define ZK_WCAP_ONE 8
+#endif
+static inline uint32_t wcap_for(uint32_t batch) { return batch == 1 ? (uint32_t)ZK_WCAP_ONE : WCAP_BATCH; }
 static constexpr uint32_t WIDE_SUMS = 16; // bit sums per column handed to the host: 9 column bits, then up to 7 row bits
 
 // signed digits in [-half, half): the 16-bit window's digits fit int16 (the last window never carries: a scalar is < 2^254)
@@ -998,7 +1005,7 @@ __global__ __launch_bounds__(256) void msm_recode_coarse_kernel(MsmBatch batch, 
 // padding (every bucket of a bin padded by SEG0 - 1) — the bucket starts inside a region are set by msm_binscan_kernel once
 // the per-bucket totals are known.  counts[4 col] / [4 col + 2] = the end of the last entry / part region.
 __global__ __launch_bounds__(64) void msm_scan_coarse_wide_kernel(uint32_t* __restrict__ coarse_all, uint32_t coarse_stride,
-                                                                  uint32_t bins, uint32_t* __restrict__ counts) {
+                                                                  uint32_t bins, uint32_t* __restrict__ counts, uint32_t WCAP) {
     constexpr uint32_t CB = CBINS_MAX + 1;
     uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
     // one wave, four consecutive bins per lane: exclusive scans of four quantities
@@ -1093,7 +1100,8 @@ __global__ __launch_bounds__(256) void msm_finehist_kernel(const uint32_t* __res
 __global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
                                                           const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
                                                           uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket_all,
-                                                          uint32_t part_stride, uint32_t* __restrict__ entries_all, size_t ent_stride) {
+                                                          uint32_t part_stride, uint32_t* __restrict__ entries_all, size_t ent_stride,
+                                                          uint32_t WCAP) {
     __shared__ uint32_t wsum[4];
     constexpr uint32_t CB = CBINS_MAX + 1;
     const uint32_t col = blockIdx.y, bin = blockIdx.x;
@@ -1137,7 +1145,7 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
                                                         const uint32_t* __restrict__ pstart_all, const uint32_t* __restrict__ pbucket_all,
                                                         uint32_t part_stride, uint32_t nb, const uint32_t* __restrict__ counts,
-                                                        G1X29S* __restrict__ part_all) {
+                                                        G1X29S* __restrict__ part_all, uint32_t WCAP) {
     const uint32_t col = blockIdx.y;
     const uint32_t nparts = counts[4 * col + 2];
     if (blockIdx.x * 64 >= nparts) return;  // wave-uniform
@@ -1186,7 +1194,7 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
 // their buckets' heads serially, then a shuffle tree.  rc[col][rows + 256]
 __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restrict__ part_all, uint32_t part_stride,
                                                          const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ pstart_all,
-                                                         uint32_t nb, G1X29S* __restrict__ rc_all) {
+                                                         uint32_t nb, G1X29S* __restrict__ rc_all, uint32_t WCAP) {
     const uint32_t col = blockIdx.y, rows = nb >> 8, r = blockIdx.x, lane = threadIdx.x;
     const uint32_t* __restrict__ pstart = pstart_all + (size_t)col * nb;
     const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
@@ -1398,7 +1406,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
             return nullptr;
         }
         ws->w_slot_stride = (uint32_t)(ws->w_ent_stride / SEG0);
-        ws->w_part_stride = (ws->w_slot_stride / WCAP + ws->nb + 2 * (ws->nb >> WIDE_FB) + 63) & ~63u;
+        ws->w_part_stride = (ws->w_slot_stride / WCAP_MIN + ws->nb + 2 * (ws->nb >> WIDE_FB) + 63) & ~63u;
         MSM_TRY(hipMalloc(&ws->w_bstart, (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_pstart, (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_pbucket, (size_t)max_batch * ws->w_part_stride * 4));
@@ -1439,6 +1447,7 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
                                bool bases_may_be_identity) {
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const uint32_t nbt = batch * nb, rows = nb >> 8;
+    const uint32_t WCAP = wcap_for(batch);
     uint32_t row_bits = 0;
     while ((1u << row_bits) < rows) row_bits++;
     *nwin_out = batch;
@@ -1463,14 +1472,14 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         hipLaunchKernelGGL(msm_recode_coarse_kernel, dim3(nblk, batch), dim3(256), 0, st, mb, n32, stride, c, nwin, nb, ws->digits,
                            ws->coarse, ws->coarse_stride);
         hipLaunchKernelGGL(msm_scan_coarse_wide_kernel, dim3(batch), dim3(64), 0, st, ws->coarse, ws->coarse_stride, nb >> WIDE_FB,
-                           ws->counts);
+                           ws->counts, WCAP);
         hipLaunchKernelGGL(msm_scatter1_kernel, dim3(nblk, batch), dim3(256), 0, st, ws->digits, n32, stride, nwin, nb, table_stride,
                            ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride, WIDE_FB);
         const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> WIDE_FB);
         hipLaunchKernelGGL(msm_finehist_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
                            ws->coarse_stride, nb, ws->totals);
         hipLaunchKernelGGL(msm_binscan_kernel, dim3(nb >> WIDE_FB, batch), dim3(128), 0, st, ws->coarse, ws->coarse_stride, nb, ws->totals,
-                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, ws->entries, ws->w_ent_stride);
+                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, ws->entries, ws->w_ent_stride, WCAP);
         hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
                            ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->cursor, ws->entries, WIDE_FB, SEG0, ws->w_ent_stride);
         if (accum_events) hipEventRecord(accum_events[0], st);
@@ -1494,10 +1503,10 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     if (n > 0) {
         const uint32_t max_parts = slots / WCAP + nb + (nb >> WIDE_FB) + 1;
         hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, ws->totals,
-                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part);
+                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
     }
     hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, ws->totals, ws->w_pstart, nb,
-                       ws->w_rc);
+                       ws->w_rc, WCAP);
     hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts);

@@ -239,6 +239,11 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
     __syncthreads();
 
     // ---- log_r DIT stages over the position index, two per round in registers
+#ifndef ZK_NTT_EXP_NOLDS
+#define ZK_NTT_EXP_NOLDS 0   // 1: timing experiment — values stay in registers between rounds (WRONG results)
+#endif
+    Fr29 keep[4];
+    (void)keep;
     uint32_t s = 0;
     if (a.log_r >= 2) {
         // stages 0 and 1: groups of four adjacent positions
@@ -249,12 +254,18 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             Fr29 e0 = tile_load(lds, tile, row, b, t, a.log_t), e1 = tile_load(lds, tile, row, b + 1, t, a.log_t),
                  e2 = tile_load(lds, tile, row, b + 2, t, a.log_t), e3 = tile_load(lds, tile, row, b + 3, t, a.log_t);
             round0<KIN>(e0, e1, e2, e3, w4);
+#if ZK_NTT_EXP_NOLDS
+            keep[0] = norm29(e0); keep[1] = norm29(e1); keep[2] = norm29(e2); keep[3] = norm29(e3);
+#else
             tile_store(lds, tile, row, b, t, a.log_t, norm29(e0));
             tile_store(lds, tile, row, b + 1, t, a.log_t, norm29(e1));
             tile_store(lds, tile, row, b + 2, t, a.log_t, norm29(e2));
             tile_store(lds, tile, row, b + 3, t, a.log_t, norm29(e3));
+#endif
         }
+#if !ZK_NTT_EXP_NOLDS
         __syncthreads();
+#endif
         s = 2;
     }
     for (; s + 1 < a.log_r; s += 2) {
@@ -263,8 +274,12 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             const uint32_t t = q & (T - 1), g = q >> a.log_t;
             const uint32_t lo = g & (h - 1);
             const uint32_t base = ((g >> s) << (s + 2)) | lo;
+#if ZK_NTT_EXP_NOLDS
+            Fr29 e0 = keep[0], e1 = keep[1], e2 = keep[2], e3 = keep[3];
+#else
             Fr29 e0 = tile_load(lds, tile, row, base, t, a.log_t), e1 = tile_load(lds, tile, row, base + h, t, a.log_t),
                  e2 = tile_load(lds, tile, row, base + 2 * h, t, a.log_t), e3 = tile_load(lds, tile, row, base + 3 * h, t, a.log_t);
+#endif
             {
                 const Fr29 w1 = lds_load29(wr + (lo << (a.log_r - s - 1)) * 9);   // w_{2h}^lo
                 bfly_mul(e0, e1, w1);
@@ -272,11 +287,21 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             }
             bfly_mul(e0, e2, lds_load29(wr + (lo << (a.log_r - s - 2)) * 9));        // w_{4h}^lo
             bfly_mul(e1, e3, lds_load29(wr + ((lo + h) << (a.log_r - s - 2)) * 9));  // w_{4h}^(lo + h)
+#if ZK_NTT_EXP_NOLDS
+            keep[0] = norm29(e0); keep[1] = norm29(e1); keep[2] = norm29(e2); keep[3] = norm29(e3);
+            if (s + 3 >= a.log_r) {
+#endif
             tile_store(lds, tile, row, base, t, a.log_t, norm29(e0));
             tile_store(lds, tile, row, base + h, t, a.log_t, norm29(e1));
             tile_store(lds, tile, row, base + 2 * h, t, a.log_t, norm29(e2));
             tile_store(lds, tile, row, base + 3 * h, t, a.log_t, norm29(e3));
+#if ZK_NTT_EXP_NOLDS
+            }
+#endif
         }
+#if ZK_NTT_EXP_NOLDS
+        if (s + 3 >= a.log_r)
+#endif
         __syncthreads();
     }
     if (s < a.log_r) {  // one stage left (odd log_r, or log_r == 1): half = R / 2
