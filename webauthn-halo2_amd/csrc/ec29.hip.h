@@ -40,17 +40,20 @@ __device__ __forceinline__ G1X29 g1x29_from_std(const G1X& a) {
 // madd-2008-s.  Returns false when the addition is one of the exceptional cases (same x: a doubling
 // or a cancellation), which the caller redoes on the general path; acc is then unchanged.  CHECK = false skips the test
 // (and always returns true): the caller detects an exceptional step by ZZ = 0 at the end and redoes the whole run.
-template <bool CHECK = true>
+// INTERNAL: (x, y) are already in the internal form (x * 2^261 mod p, canonical words — the wide path's window tables,
+// msm.hip): their plain limbs are the operand (bound 1 instead of 32) and starting a run costs no product, so that a lane
+// can restart its running sum in the middle of its entries (a new bucket) at the price of a few moves.
+template <bool CHECK = true, bool INTERNAL = false>
 __device__ __forceinline__ bool g1x29_add_affine(G1X29& acc, const Fq& x, const Fq& y) {
     if (acc.inf) {
-        acc.x = std_to_internal(x);  // (2 ; 29)
-        acc.y = std_to_internal(y);
+        acc.x = INTERNAL ? to29(x) : std_to_internal(x);  // (2 ; 29)
+        acc.y = INTERNAL ? to29(y) : std_to_internal(y);
         acc.zz = const_pow2_29<261, FqParams>();  // 1 in internal form
         acc.zzz = acc.zz;
         acc.inf = false;
         return true;
     }
-    const Fq29 x2 = to29_x32(x), y2 = to29_x32(y);               // (32 ; 29)
+    const Fq29 x2 = INTERNAL ? to29(x) : to29_x32(x), y2 = INTERNAL ? to29(y) : to29_x32(y);  // (32 ; 29), internal: (1 ; 29)
     const Fq29 u2 = mul29(x2, acc.zz);                            // 32 * 2 = 64 <= 168
     const Fq29 s2 = mul29(y2, acc.zzz);
     const Fq29 p = norm29(sub29<10, 29>(u2, acc.x));              // (12 ; 29)   X < 9p

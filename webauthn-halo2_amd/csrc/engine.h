@@ -44,7 +44,10 @@ size_t msm_ws_max_n(const MsmWorkspace* ws);
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws);
 uint32_t msm_ws_window(const MsmWorkspace* ws);
 // table[w * n + i] = 2^(c w) * bases[i] (affine), w < msm_num_windows(c)
+// (the wide path's tables — 15 / 16-bit windows, msm_table_is_internal — hold the points in the accumulation's internal form,
+// x * 2^261: they are read by the fixed-base MSM only)
 hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st);
+bool msm_table_is_internal(uint32_t c, size_t n);
 // Launches the whole device pipeline on `st`; the bit sums (XYZZ) are copied to `host_window_sums`
 // asynchronously.  `table` != nullptr selects the fixed-base mode: `batch` scalar vectors (columns) against
 // the same bases in ONE pass, one bucket set per column; *nwin_out = batch independent results, each finished

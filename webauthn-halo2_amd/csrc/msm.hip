@@ -47,6 +47,8 @@ namespace zk {
 
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
+// wide path: an entry is sign << 31 | first-of-bucket << 30 | delta << 24 | table index (24 bits)
+static constexpr uint32_t WIDE_FLAG = 0x40000000u, WIDE_IDX = 0x00ffffffu, WIDE_ESC = 63;
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
 static constexpr uint32_t SORT_LDS_BUCKETS = 8192;  // 32 KiB of LDS counters per sort workgroup
 #ifndef ZK_SEG0  // build-time tuning knobs (tools/ab_variants.sh)
@@ -96,8 +98,11 @@ struct MsmWorkspace {
     // wide path (15 / 16-bit windows, fixed-base mode): per-column regions
     bool wide;
     size_t w_ent_stride;        // entries per column region (multiple of 64)
-    uint32_t w_slot_stride;     // = w_ent_stride / SEG0
+    uint32_t w_lane_stride;     // accumulation lanes per column region
+    uint32_t w_slot_stride;     // slots per column region: lanes + buckets
     uint32_t w_part_stride;     // parts per column region
+    uint32_t* w_lane_b;         // [max_batch][w_lane_stride] the bucket every lane starts in
+    uint8_t* w_delta;           // [max_batch][nb] distance of a bucket from the previous non-empty one (first-of-bucket entries carry it)
     uint32_t* w_bstart;         // [max_batch][nb] places of the buckets in their column's entry region
     uint32_t* w_pstart;         // [max_batch][nb] first part of every bucket
     uint32_t* w_pbucket;        // [max_batch][w_part_stride] bucket of every part
@@ -461,11 +466,14 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ totals_all,
                                                            const uint32_t* __restrict__ bucket_start_all, uint32_t* __restrict__ cursor_all,
                                                            uint32_t* __restrict__ entries_all, uint32_t fb, uint32_t pad,
-                                                           size_t ent_stride) {
+                                                           size_t ent_stride, const uint8_t* __restrict__ delta_all) {
     // 13 / 14-bit plan: the bucket starts of all columns index one dense entry list (ent_stride = 0), ranges padded to
-    // PAD entries; wide path: column-local starts, one entry region per column, ranges padded to one segment
+    // PAD entries (skip markers); wide path (delta_all != nullptr): column-local starts, one entry region per column, no
+    // padding (pad = 1) — the first entry of every bucket carries WIDE_FLAG and the bucket's distance from the previous
+    // non-empty one (msm_binscan_kernel) in its spare bits
     __shared__ SortLds S;
     __shared__ uint32_t s_bin, s_chunk;
+    __shared__ uint32_t s_mark[CBINS_MAX];  // wide path: flag bits of a key's first entry when this chunk holds the bucket's first
     const uint32_t col = blockIdx.y;
     const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
@@ -513,7 +521,9 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
     sort_scan(S, keys);
     if (threadIdx.x < keys) {
         const uint32_t cnt = S.cnt[threadIdx.x], b = bin * keys + threadIdx.x;
-        S.gbase[threadIdx.x] = bucket_start[b] + (cnt ? atomicAdd(&cursor[b], cnt) : 0);
+        const uint32_t before = cnt ? atomicAdd(&cursor[b], cnt) : 0;
+        S.gbase[threadIdx.x] = bucket_start[b] + before;
+        s_mark[threadIdx.x] = (delta_all && cnt && before == 0) ? (WIDE_FLAG | ((uint32_t)delta_all[(size_t)col * nb + b] << 24)) : 0;
     }
     __syncthreads();
 #pragma unroll
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __res
     const uint32_t total = end - beg;
     for (uint32_t q = threadIdx.x; q < total; q += 256) {
         const uint32_t key = S.kid[q];
-        entries[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
+        entries[S.gbase[key] + q - S.lstart[key]] = S.sorted[q] | (q == S.lstart[key] ? s_mark[key] : 0u);
     }
 }
 
@@ -920,11 +930,17 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
 // ================================================================== wide path ==
 // Windows of 15 / 16 bits (fixed-base mode): 17 / 16 bucket additions per scalar instead of 20 at 13 bits, paid for with
 // 16384 / 32768 buckets per column.  What changes against the 13-bit plan above:
-//   * the digits / histogram kernel counts in 16-bit LDS counters (two buckets per word: a workgroup's 1024 scalars
-//     put at most 17 x 1024 entries into one bucket), so that the 32768 counters of a column take 64 KB;
-//   * the two-level sort splits a bucket index into an 8-bit coarse bin and a 7-bit fine key (128 buckets per bin);
-//   * every column owns a region of the entry / slot lists (column-local bucket starts), bucket ranges are padded to
-//     ONE accumulate segment (16 entries: 3 % padding at 256 entries per bucket, 64 would be 12 %);
+//   * the two-level sort splits a bucket index into an 8-bit coarse bin and a 7-bit fine key (128 buckets per bin); the
+//     digits kernel counts coarse bins only, the per-bucket totals are counted from the binned intermediate list
+//     (32768 LDS counters per workgroup would cost 6.7 M global atomics per 2^19 column);
+//   * every column owns a region of the entry / slot / part lists, and all scans are local to a coarse bin;
+//   * NO PADDING: the entry list is dense.  A lane of the accumulation sums WL consecutive entries whatever buckets they
+//     fall in: the first entry of every bucket carries a flag, at which the lane stores its running sum (one "slot" per
+//     (lane, bucket) pair: slot index = lane + bucket, unique and ordered along the staircase of the pairs) and restarts.
+//     A restart costs a few moves because the window tables of this path hold the points in the accumulation's internal
+//     form (x * 2^261: g1x29_add_affine<.., INTERNAL>).  Against 16-entry segments padded per bucket: no padding lanes
+//     (3 %), half the slots for the reduction tail to add up (5 % of the bucket additions), and one 2^19 column is exactly
+//     4096 waves = one full round of four waves per SIMD (16-entry segments: 2.07 rounds);
 //   * the reduction tail is shaped for many small buckets: (T1) one lane per "part" of at most WCAP slots sums it
 //     serially, lanes of the same bucket inside a wave are joined by a segmented shuffle tree; (T2) the bucket matrix
 //     [rows = nb / 256][256] is summed along its rows and along its columns, one wave each —
@@ -941,6 +957,12 @@ static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = 8;  // WCAP_MIN sizes the p
 #endif
 static inline uint32_t wcap_for(uint32_t batch) { return batch == 1 ? (uint32_t)ZK_WCAP_ONE : WCAP_BATCH; }
 static constexpr uint32_t WIDE_SUMS = 16; // bit sums per column handed to the host: 9 column bits, then up to 7 row bits
+#ifndef ZK_WL
+#define ZK_WL 32
+#endif
+static constexpr uint32_t WL = ZK_WL;     // entries per accumulation lane (a 2^19 column of 16-bit windows: 2^23 / 32 = 4096 waves)
+// slots of a bucket whose cnt > 0 entries start at position s of the column's entry list: one per lane that holds some of them
+__device__ __forceinline__ uint32_t wide_slot_count(uint32_t s, uint32_t cnt) { return cnt ? (s + cnt - 1) / WL - s / WL + 1 : 0; }
 
 // signed digits in [-half, half): the 16-bit window's digits fit int16 (the last window never carries: a scalar is < 2^254)
 __device__ __forceinline__ void msm_digits_wide(const uint32_t* L, uint32_t c, uint32_t nwin, uint32_t i, uint32_t stride,
@@ -1000,58 +1022,55 @@ __global__ __launch_bounds__(256) void msm_recode_coarse_kernel(MsmBatch batch, 
     }
 }
 
-// per column (blockIdx.x), from the bins' totals (the append cursors): the bins' places in `inter` (dense), the chunk prefix
-// of the second sort level, and the bins' REGIONS of the entry list and of the part list, sized for the worst case of the
-// padding (every bucket of a bin padded by SEG0 - 1) — the bucket starts inside a region are set by msm_binscan_kernel once
-// the per-bucket totals are known.  counts[4 col] / [4 col + 2] = the end of the last entry / part region.
+// per column (blockIdx.x), from the bins' totals (the append cursors): the bins' places in `inter` — and in the final entry
+// list, which is as dense —, the chunk prefix of the second sort level, and the bins' REGIONS of the part list, sized for
+// the worst case (every bucket of a bin one slot and one part more than its share) — the parts inside a region are laid out
+// by msm_binscan_kernel once the per-bucket totals are known.  counts[4 col] = entries, counts[4 col + 2] = the end of the
+// last part region.
 __global__ __launch_bounds__(64) void msm_scan_coarse_wide_kernel(uint32_t* __restrict__ coarse_all, uint32_t coarse_stride,
                                                                   uint32_t bins, uint32_t* __restrict__ counts, uint32_t WCAP) {
     constexpr uint32_t CB = CBINS_MAX + 1;
     uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
-    // one wave, four consecutive bins per lane: exclusive scans of four quantities
+    // one wave, four consecutive bins per lane: exclusive scans of three quantities
     const uint32_t k0 = threadIdx.x * 4;
-    uint32_t v[4][4];  // [bin][inter entries, chunks, entry region, part region]
-    uint32_t s4[4] = {0, 0, 0, 0};
+    uint32_t v[4][3];  // [bin][entries, chunks, part region]
+    uint32_t s3[3] = {0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t t = k0 + j < bins ? c[2 * CB + k0 + j] : 0;
-        const uint32_t e = t ? (t + WIDE_KEYS * (SEG0 - 1) + SEG0 - 1) & ~(SEG0 - 1) : 0;
         v[j][0] = t;
         v[j][1] = (t + SUB - 1) / SUB;
-        v[j][2] = e;
-        v[j][3] = t ? (e / SEG0 + WCAP - 1) / WCAP + WIDE_KEYS : 0;
+        v[j][2] = t ? (t / WL + 2 * WIDE_KEYS + WCAP - 1) / WCAP + WIDE_KEYS : 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) s4[q] += v[j][q];
+        for (int q = 0; q < 3; q++) s3[q] += v[j][q];
     }
-    uint32_t x[4] = {s4[0], s4[1], s4[2], s4[3]};
+    uint32_t x[3] = {s3[0], s3[1], s3[2]};
     for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 3; q++) {
             const uint32_t y = __shfl_up(x[q], off);
             if ((int)threadIdx.x >= off) x[q] += y;
         }
     }
-    uint32_t run[4];
+    uint32_t run[3];
 #pragma unroll
-    for (int q = 0; q < 4; q++) run[q] = x[q] - s4[q];
+    for (int q = 0; q < 3; q++) run[q] = x[q] - s3[q];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (k0 + j < bins) {
             c[k0 + j] = run[0];
             c[CB + k0 + j] = run[1];
-            c[3 * CB + k0 + j] = run[2];
-            c[4 * CB + k0 + j] = run[3];
+            c[4 * CB + k0 + j] = run[2];
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) run[q] += v[j][q];
+        for (int q = 0; q < 3; q++) run[q] += v[j][q];
     }
     if (threadIdx.x == 63) {
         c[bins] = x[0];
         c[CB + bins] = x[1];
-        c[3 * CB + bins] = x[2];
-        c[4 * CB + bins] = x[3];
-        counts[4 * blockIdx.x] = x[2];
-        counts[4 * blockIdx.x + 2] = x[3];
+        c[4 * CB + bins] = x[2];
+        counts[4 * blockIdx.x] = x[0];
+        counts[4 * blockIdx.x + 2] = x[2];
     }
 }
 
@@ -1094,47 +1113,163 @@ __global__ __launch_bounds__(256) void msm_finehist_kernel(const uint32_t* __res
 }
 
 // one workgroup (two waves: a lane per bucket) per (coarse bin, column): the bin-local scans of the per-bucket totals:
-// bstart[b] (place of bucket b in the column's entry region; its range is padded to a multiple of SEG0), pstart[b] and
-// pbucket[] (the bucket's parts of at most WCAP slots, T1), and the fills of what the bin's regions hold beyond the buckets
-// (skip markers / no-part markers).
+// bstart[b] (the bucket's place in the column's dense entry list), delta[b] (distance from the previous non-empty bucket of
+// the bin minus one, WIDE_ESC for a bin's first one or a longer gap: what the bucket's first entry tells the lane that runs
+// into it), lane_b[] (the bucket a lane starts in), pstart[b] / pbucket[] (the bucket's parts of at most WCAP slots, T1) and
+// the no-part markers at the end of the bin's part region.
 __global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
                                                           const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
-                                                          uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket_all,
-                                                          uint32_t part_stride, uint32_t* __restrict__ entries_all, size_t ent_stride,
-                                                          uint32_t WCAP) {
+                                                          uint8_t* __restrict__ delta_all, uint32_t* __restrict__ lane_b_all,
+                                                          uint32_t lane_stride, uint32_t* __restrict__ pstart_all,
+                                                          uint32_t* __restrict__ pbucket_all, uint32_t part_stride, uint32_t WCAP) {
     __shared__ uint32_t wsum[4];
+    __shared__ int wlast[2];
     constexpr uint32_t CB = CBINS_MAX + 1;
     const uint32_t col = blockIdx.y, bin = blockIdx.x;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     uint32_t* __restrict__ pbucket = pbucket_all + (size_t)col * part_stride;
-    uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
+    uint32_t* __restrict__ lane_b = lane_b_all + (size_t)col * lane_stride;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = bin * WIDE_KEYS + threadIdx.x;
     const uint32_t cnt = totals_all[(size_t)col * nb + b];
-    const uint32_t h = (cnt + SEG0 - 1) & ~(SEG0 - 1);
-    const uint32_t np = (h / SEG0 + WCAP - 1) / WCAP;
-    uint32_t xe = h, xp = np;
+    // exclusive scan of the counts -> place in the entry list
+    uint32_t xe = cnt;
+    int last = cnt ? (int)threadIdx.x : -1;  // inclusive running maximum: the last non-empty bucket up to this one
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t ye = __shfl_up(xe, off), yp = __shfl_up(xp, off);
+        const uint32_t ye = __shfl_up(xe, off);
+        const int yl = __shfl_up(last, off);
         if ((int)lane >= off) {
             xe += ye;
-            xp += yp;
+            last = max(last, yl);
         }
     }
     if (lane == 63) {
         wsum[2 * wave] = xe;
-        wsum[2 * wave + 1] = xp;
+        wlast[wave] = last;
     }
     __syncthreads();
-    const uint32_t ebase = chdr[3 * CB + bin], pbase = chdr[4 * CB + bin];
-    const uint32_t eend = chdr[3 * CB + bin + 1], pend = chdr[4 * CB + bin + 1];
-    const uint32_t e_used = wsum[0] + wsum[2], p_used = wsum[1] + wsum[3];
-    const uint32_t e0 = ebase + xe - h + (wave ? wsum[0] : 0), p0 = pbase + xp - np + (wave ? wsum[1] : 0);
-    bstart_all[(size_t)col * nb + b] = e0;
+    const uint32_t s = chdr[bin] + xe - cnt + (wave ? wsum[0] : 0);
+    // the last non-empty bucket strictly before this one
+    int prev = __shfl_up(last, 1);
+    if (lane == 0) prev = -1;
+    if (wave) prev = max(prev, wlast[0]);
+    const uint32_t slots = wide_slot_count(s, cnt);
+    const uint32_t np = (slots + WCAP - 1) / WCAP;
+    // exclusive scan of the part counts -> place in the bin's part region
+    uint32_t xp = np;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t yp = __shfl_up(xp, off);
+        if ((int)lane >= off) xp += yp;
+    }
+    if (lane == 63) wsum[2 * wave + 1] = xp;
+    __syncthreads();
+    const uint32_t pbase = chdr[4 * CB + bin], pend = chdr[4 * CB + bin + 1];
+    const uint32_t p_used = wsum[1] + wsum[3];
+    const uint32_t p0 = pbase + xp - np + (wave ? wsum[1] : 0);
+    bstart_all[(size_t)col * nb + b] = s;
     pstart_all[(size_t)col * nb + b] = p0;
+    if (cnt) {
+        const uint32_t gap = prev < 0 ? WIDE_ESC : (uint32_t)((int)threadIdx.x - prev - 1);
+        delta_all[(size_t)col * nb + b] = (uint8_t)(gap < WIDE_ESC ? gap : WIDE_ESC);
+        // lanes whose first entry lies in this bucket
+        for (uint32_t t = (s + WL - 1) / WL; t * WL < s + cnt; t++) lane_b[t] = b;
+    }
     for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
-    for (uint32_t q = ebase + e_used + threadIdx.x; q < eend; q += 128) entries[q] = SKIP_ENTRY;
     for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 128) pbucket[q] = 0xffffffffu;
+}
+
+// the bucket of the entry at position `pos` of a column (the escape of a first-of-bucket entry whose distance field is
+// saturated): the last bucket whose start is <= pos — empty buckets share their start with the next non-empty one
+__device__ __noinline__ uint32_t wide_bucket_at(const uint32_t* __restrict__ bstart, uint32_t nb, uint32_t pos) {
+    uint32_t lo = 0, hi = nb;  // bstart[lo] <= pos (bstart[0] = 0), hi: first index with bstart > pos (or nb)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bstart[mid] <= pos) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ---- the accumulation of the wide path: lane t of a column sums entries [t WL, (t + 1) WL) of the dense list, storing its
+// running sum and restarting at every first-of-bucket entry (slot index = t + bucket).  SAFE as in accumulate_segment:
+// the unchecked loop vouches that the table holds no identity and reports a lane whose sums show an exceptional step
+// (ZZ = 0) to the redo list; the checked loop is exact for any table.
+template <bool SAFE>
+__device__ __forceinline__ bool wide_accumulate_lane(const uint32_t* __restrict__ e, uint32_t count, uint32_t pos0, uint32_t t, uint32_t b,
+                                                     const uint32_t* __restrict__ bstart, uint32_t nb,
+                                                     const G1Affine* __restrict__ table, G1X29S* __restrict__ slots) {
+    G1X29 acc;
+    acc.inf = true;
+    bool suspicious = false;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t y = e[k];
+        if ((y & WIDE_FLAG) && k) {  // a new bucket begins inside the lane's run
+            if (!SAFE && !acc.inf && is_zero29(acc.zz)) suspicious = true;
+            g1x29_store(slots + t + b, acc);
+            acc.inf = true;
+            const uint32_t d = (y >> 24) & 63u;
+            b = d < WIDE_ESC ? b + 1 + d : wide_bucket_at(bstart, nb, pos0 + k);
+        }
+        G1Affine p = affine_load(table + (y & WIDE_IDX));
+        if (SAFE && affine_is_identity(p)) continue;
+        if (y & SIGN_BIT) p.y = fe_neg(p.y);
+        if (!g1x29_add_affine<SAFE, true>(acc, p.x, p.y)) {
+            // same x as the running sum (doubling or cancellation): the general formulas, rarely.  The table is in the
+            // internal form: back to the standard one for the general addition (divide by 32: one product each)
+            G1X s = g1x29_to_std(acc);
+            Fq px = internal_to_std(to29(p.x)), py = internal_to_std(to29(p.y));
+            g1x_add_affine(s, px, py);
+            acc = g1x29_from_std(s);
+        }
+    }
+    if (!SAFE && !acc.inf && is_zero29(acc.zz)) suspicious = true;
+    g1x29_store(slots + t + b, acc);
+    return suspicious;
+}
+
+#if ZK_ACC_WAVES
+__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
+#endif
+__global__ __launch_bounds__(64) void msm_wacc_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
+                                                      const G1Affine* __restrict__ table, const uint32_t* __restrict__ counts,
+                                                      const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
+                                                      const uint32_t* __restrict__ bstart_all, uint32_t nb,
+                                                      G1X29S* __restrict__ slot_all, uint32_t slot_stride) {
+    const uint32_t col = blockIdx.y, total = counts[4 * col];
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t * WL >= total) return;
+    wide_accumulate_lane<true>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
+                               lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
+                               slot_all + (size_t)col * slot_stride);
+}
+#if ZK_ACC_WAVES
+__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
+#endif
+__global__ __launch_bounds__(64) void msm_wacc_fast_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
+                                                           const G1Affine* __restrict__ table, uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
+                                                           const uint32_t* __restrict__ bstart_all, uint32_t nb,
+                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, uint32_t* __restrict__ redo) {
+    const uint32_t col = blockIdx.y, total = counts[4 * col];
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t * WL >= total) return;
+    if (wide_accumulate_lane<false>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
+                                    lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
+                                    slot_all + (size_t)col * slot_stride))
+        redo[atomicAdd(&counts[1], 1u)] = col * lane_stride + t;  // at most one entry per lane: redo[] has one word each
+}
+__global__ __launch_bounds__(64) void msm_wacc_redo_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
+                                                           const G1Affine* __restrict__ table, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
+                                                           const uint32_t* __restrict__ bstart_all, uint32_t nb,
+                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, const uint32_t* __restrict__ redo) {
+    const uint32_t m = counts[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t col = redo[i] / lane_stride, t = redo[i] - col * lane_stride, total = counts[4 * col];
+        wide_accumulate_lane<true>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
+                                   lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
+                                   slot_all + (size_t)col * slot_stride);
+    }
 }
 
 // T1: part g of a column = up to WCAP consecutive slots of one bucket, summed serially by one lane; then the lanes of a wave
@@ -1156,8 +1291,10 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
     const bool active = b != 0xffffffffu;
     uint32_t s = 0, s_end = 0;
     if (active) {
-        const uint32_t s0 = bstart_all[(size_t)col * nb + b] / SEG0;
-        const uint32_t len = (totals_all[(size_t)col * nb + b] + SEG0 - 1) / SEG0;
+        // the bucket's slots: one per accumulation lane that held some of its entries, at index lane + bucket
+        const uint32_t e0 = bstart_all[(size_t)col * nb + b];
+        const uint32_t s0 = e0 / WL + b;
+        const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
         const uint32_t np = (len + WCAP - 1) / WCAP;
         const uint32_t p = g - pstart_all[(size_t)col * nb + b];
         // balanced shares: part p of np takes slots [s0 + p len / np, s0 + (p + 1) len / np)
@@ -1193,11 +1330,13 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
 // T2: one wave per row (blockIdx.x < rows) or column (blockIdx.x - rows) of the column's bucket matrix [rows][256]: lanes walk
 // their buckets' heads serially, then a shuffle tree.  rc[col][rows + 256]
 __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restrict__ part_all, uint32_t part_stride,
-                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ pstart_all,
-                                                         uint32_t nb, G1X29S* __restrict__ rc_all, uint32_t WCAP) {
+                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
+                                                         const uint32_t* __restrict__ pstart_all, uint32_t nb,
+                                                         G1X29S* __restrict__ rc_all, uint32_t WCAP) {
     const uint32_t col = blockIdx.y, rows = nb >> 8, r = blockIdx.x, lane = threadIdx.x;
     const uint32_t* __restrict__ pstart = pstart_all + (size_t)col * nb;
     const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
+    const uint32_t* __restrict__ bstart = bstart_all + (size_t)col * nb;
     const G1X29S* __restrict__ part = part_all + (size_t)col * part_stride;
     const bool is_row = r < rows;
     // lane's j-th bucket: rows: 256 r + lane + 64 j (j < 4); columns: 256 (lane + 64 j) + (r - rows) (j < rows / 64)
@@ -1208,7 +1347,7 @@ __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restric
         while (j < nj) {
             const uint32_t b = bucket_of(j);
             g = pstart[b];
-            g_end = g + ((totals[b] + SEG0 - 1) / SEG0 + WCAP - 1) / WCAP;
+            g_end = g + (wide_slot_count(bstart[b], totals[b]) + WCAP - 1) / WCAP;
             if (g < g_end) return;
             j++;
         }
@@ -1327,6 +1466,21 @@ hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_
     return hipSuccess;
 }
 
+// x * 2^256 (standard memory form) -> x * 2^261 (the accumulation's internal form, canonical words): times 32
+__global__ void msm_table_internal_kernel(G1Affine* __restrict__ t, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    G1Affine p = affine_load(t + i);
+    for (int k = 0; k < 5; k++) {
+        p.x = fe_add(p.x, p.x);
+        p.y = fe_add(p.y, p.y);
+    }
+    fe_store(&t[i].x, p.x);
+    fe_store(&t[i].y, p.y);
+}
+
+bool msm_table_is_internal(uint32_t c, size_t n) { return msm_wide_applies(c, n); }
+
 hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st) {
     const uint32_t nwin = nwin_for(c);
     hipError_t e = hipMemcpyAsync(table, bases, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToDevice, st);
@@ -1334,6 +1488,11 @@ hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affi
     for (uint32_t w = 1; w < nwin; w++)
         hipLaunchKernelGGL(msm_table_step_kernel, dim3((n + 63) / 64), dim3(64), 0, st, table + (size_t)(w - 1) * n,
                            table + (size_t)w * n, n, c);
+    if (msm_table_is_internal(c, n)) {
+        // the wide path reads its window tables in the accumulation's internal form (the identity stays (0, 0))
+        const size_t count = (size_t)nwin * n;
+        hipLaunchKernelGGL(msm_table_internal_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, table, count);
+    }
     return hipGetLastError();
 }
 
@@ -1399,14 +1558,22 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     MSM_TRY(hipMalloc(&ws->bit_sum, slices * c * BITSUM_MAX_SPLIT * sizeof(G1X)));
     ws->wide = msm_wide_applies(c, max_n);
     if (ws->wide) {
-        ws->w_ent_stride = (max_n * ws->nwin + (size_t)(ws->nb >> WIDE_FB) * (WIDE_KEYS * (SEG0 - 1) + SEG0) + 63) & ~(size_t)63;
+        ws->w_ent_stride = (max_n * ws->nwin + 63) & ~(size_t)63;
         if (ws->w_ent_stride * max_batch > ent) {  // cannot happen: the dense list is padded to 64 per bucket
             if (err) *err = hipErrorInvalidValue;
             msm_workspace_destroy(ws);
             return nullptr;
         }
-        ws->w_slot_stride = (uint32_t)(ws->w_ent_stride / SEG0);
-        ws->w_part_stride = (ws->w_slot_stride / WCAP_MIN + ws->nb + 2 * (ws->nb >> WIDE_FB) + 63) & ~63u;
+        ws->w_lane_stride = (uint32_t)(ws->w_ent_stride / WL) + 64;
+        ws->w_slot_stride = ws->w_lane_stride + ws->nb + 64;
+        ws->w_part_stride = ((ws->w_lane_stride + 2 * ws->nb) / WCAP_MIN + ws->nb + 2 * (ws->nb >> WIDE_FB) + 127) & ~63u;
+        if ((size_t)max_batch * ws->w_slot_stride > threads) {  // cannot happen: sized for 16-entry segments
+            if (err) *err = hipErrorInvalidValue;
+            msm_workspace_destroy(ws);
+            return nullptr;
+        }
+        MSM_TRY(hipMalloc(&ws->w_lane_b, (size_t)max_batch * ws->w_lane_stride * 4));
+        MSM_TRY(hipMalloc(&ws->w_delta, (size_t)max_batch * ws->nb));
         MSM_TRY(hipMalloc(&ws->w_bstart, (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_pstart, (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_pbucket, (size_t)max_batch * ws->w_part_stride * 4));
@@ -1432,6 +1599,8 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->partial);
     hipFree(ws->part);
     hipFree(ws->bit_sum);
+    hipFree(ws->w_lane_b);
+    hipFree(ws->w_delta);
     hipFree(ws->w_bstart);
     hipFree(ws->w_pstart);
     hipFree(ws->w_pbucket);
@@ -1440,7 +1609,8 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     delete ws;
 }
 
-// The wide path's pipeline (see "wide path" above): `batch` columns against the resident basis whose window table is `table`.
+// The wide path's pipeline (see "wide path" above): `batch` columns against the resident basis whose window table — in the
+// internal form, msm_build_table(.., internal = true) — is `table`.
 static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t batch, size_t n, hipStream_t st,
                                G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out, hipEvent_t* accum_events,
                                const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done,
@@ -1461,9 +1631,7 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     }
     const uint32_t n32 = (uint32_t)n;
     const uint32_t stride = (uint32_t)ws->max_n;
-    // worst-case extent of one column's entry region at this n (every bin's region is sized for full padding) -> grid sizes
-    const size_t worst = (size_t)n * nwin + (size_t)(nb >> WIDE_FB) * (WIDE_KEYS * (SEG0 - 1) + SEG0);
-    const uint32_t slots = (uint32_t)((worst + SEG0 - 1) / SEG0);
+    const uint32_t lanes = (uint32_t)(((size_t)n * nwin + WL - 1) / WL);  // accumulation lanes of one column at most
     if (n > 0) {
         const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
         MsmBatch mb;
@@ -1479,20 +1647,22 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         hipLaunchKernelGGL(msm_finehist_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
                            ws->coarse_stride, nb, ws->totals);
         hipLaunchKernelGGL(msm_binscan_kernel, dim3(nb >> WIDE_FB, batch), dim3(128), 0, st, ws->coarse, ws->coarse_stride, nb, ws->totals,
-                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, ws->entries, ws->w_ent_stride, WCAP);
+                           ws->w_bstart, ws->w_delta, ws->w_lane_b, ws->w_lane_stride, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, WCAP);
         hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->cursor, ws->entries, WIDE_FB, SEG0, ws->w_ent_stride);
+                           ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->cursor, ws->entries, WIDE_FB, 1u, ws->w_ent_stride,
+                           (const uint8_t*)ws->w_delta);
         if (accum_events) hipEventRecord(accum_events[0], st);
         if (bases_may_be_identity) {
-            hipLaunchKernelGGL(msm_accumulate_kernel, dim3((slots + 63) / 64, batch), dim3(64), 0, st, ws->entries, table, ws->counts,
-                               ws->slot_pt, ws->w_slot_stride);
+            hipLaunchKernelGGL(msm_wacc_kernel, dim3((lanes + 63) / 64, batch), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts,
+                               ws->w_lane_b, ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride);
         } else {
-            hipLaunchKernelGGL(msm_accumulate_fast_kernel, dim3((slots + 63) / 64, batch), dim3(64), 0, st, ws->entries, table, ws->counts,
-                               ws->redo, ws->slot_pt, ws->w_slot_stride);
+            hipLaunchKernelGGL(msm_wacc_fast_kernel, dim3((lanes + 63) / 64, batch), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table,
+                               ws->counts, ws->w_lane_b, ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo);
         }
         if (accum_events) hipEventRecord(accum_events[1], st);
         if (!bases_may_be_identity)
-            hipLaunchKernelGGL(msm_accumulate_redo_kernel, dim3(1024), dim3(64), 0, st, ws->entries, table, ws->counts, ws->redo, ws->slot_pt);
+            hipLaunchKernelGGL(msm_wacc_redo_kernel, dim3(256), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts, ws->w_lane_b,
+                               ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo);
     }
     hipStream_t ts = st;
     if (tail_st && tail_st != st) {
@@ -1501,12 +1671,13 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         ts = tail_st;
     }
     if (n > 0) {
-        const uint32_t max_parts = slots / WCAP + nb + (nb >> WIDE_FB) + 1;
+        // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_scan_coarse_wide_kernel)
+        const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * (nb >> WIDE_FB) + 64;
         hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, ws->totals,
                            ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
     }
-    hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, ws->totals, ws->w_pstart, nb,
-                       ws->w_rc, WCAP);
+    hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, ws->totals, ws->w_bstart,
+                       ws->w_pstart, nb, ws->w_rc, WCAP);
     hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts);
@@ -1569,7 +1740,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
                                ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride, 6u);
             const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> 6);
             hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                               ws->coarse_stride, nb, ws->totals, ws->bucket_start, ws->cursor, ws->entries, 6u, PAD, (size_t)0);
+                               ws->coarse_stride, nb, ws->totals, ws->bucket_start, ws->cursor, ws->entries, 6u, PAD, (size_t)0, (const uint8_t*)nullptr);
         } else if (fused) {
             const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
             MsmBatch mb;
