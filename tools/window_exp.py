@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import webauthn_halo2_amd as zk
 from webauthn_halo2_amd import batch, circuit, engine as E
 
-p = circuit.K19
+p = circuit.K17 if os.environ.get("K") == "17" else circuit.K19
 jobs = list(range(4))
 wit = batch.synthesize_jobs(p, jobs)
 fixed, copies = batch.structure(p)
@@ -19,7 +19,7 @@ def mk(b):
 
 
 for b in [int(x) for x in (sys.argv[1:] or ["0", "14"])]:
-    pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=mk(b)) for _ in range(2)]
+    pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=mk(b), deterministic_seeds=True) for _ in range(2)]
     for pl in pipes:
         for j in jobs:
             pl.load(j, wit[j])

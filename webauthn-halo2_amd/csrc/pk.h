@@ -66,6 +66,7 @@ struct Layout {
     }
 };
 
+static constexpr uint32_t BATCH_ARGS_MIN = 8;  // more chunks / lookups / columns than this: one batched launch, argument blocks in device memory
 static constexpr uint32_t ROWS_CAP = 512, ROWS_BLOCKS = 16;  // staged row writes per flush / flushes per ring
 
 struct zk_pk_rec {
@@ -95,6 +96,9 @@ struct zk_pk_rec {
     Fr* gp_scal = nullptr;       // device: q, q_inv, k, init (n_prod each)
     Fr* gp_host = nullptr;       // pinned: q and q_inv
     GpItem* d_gp_items = nullptr;
+    // argument blocks of the batched per-chunk / per-lookup / per-column launches (many-column shapes): pinned staging + device
+    void *h_batch_args = nullptr, *d_batch_args = nullptr;
+    size_t batch_args_bytes = 0;
     QuotientArgs* d_qargs = nullptr;
     QuotientArgs* h_qargs = nullptr;  // pinned staging of the same
     EvalItem *d_evargs = nullptr, *h_evargs = nullptr;

@@ -94,6 +94,18 @@ void launch_chacha_fr(const ChaChaKey& key, uint64_t start_block, Fr* out, uint3
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t st);
 void launch_lookup_permute(const LkPtrs& ptrs, uint32_t count, uint32_t usable, uint32_t T, LookupScratch& s, hipStream_t st);
 void launch_perm_numden(const PermArgs& a, hipStream_t st);
+struct LkNumDenArgs {
+    const Fr *ap, *sp, *inp, *tab;
+    Fr *num, *den;
+};
+struct CopyPair {
+    const Fr* src;
+    Fr* dst;
+};
+// batched forms for the many-column shapes (one launch for all chunks / lookups / columns; argument blocks in device memory)
+void launch_perm_numden_batch(const PermArgs* d_args, uint32_t count, uint32_t n, hipStream_t st);
+void launch_lk_numden_batch(const LkNumDenArgs* d_args, uint32_t count, const Fr& beta, const Fr& gamma, uint32_t n, hipStream_t st);
+void launch_copy_columns(const CopyPair* d_pairs, uint32_t count, uint32_t n, hipStream_t st);
 void launch_lk_numden(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, const Fr& beta, const Fr& gamma, Fr* num,
                       Fr* den, uint32_t n, hipStream_t st);
 void launch_frac(const Fr* num, const Fr* den, Fr* frac, uint32_t n, hipStream_t st);

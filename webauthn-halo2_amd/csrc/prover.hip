@@ -112,6 +112,8 @@ void pk_destroy(zk_pk_rec* pk) {
     if (pk->gp_host) hipHostFree(pk->gp_host);
     if (pk->d_gp_items) hipFree(pk->d_gp_items);
     if (pk->d_qargs) hipFree(pk->d_qargs);
+    if (pk->d_batch_args) hipFree(pk->d_batch_args);
+    if (pk->h_batch_args) hipHostFree(pk->h_batch_args);
     if (pk->h_qargs) hipHostFree(pk->h_qargs);
     if (pk->d_evargs) hipFree(pk->d_evargs);
     if (pk->h_evargs) hipHostFree(pk->h_evargs);
@@ -227,6 +229,13 @@ int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk) {
     }
     if (hipMalloc(&pk->d_qargs, sizeof(QuotientArgs)) != hipSuccess || hipHostMalloc(&pk->h_qargs, sizeof(QuotientArgs)) != hipSuccess)
         return fail(ZK_ENOMEM);
+    {
+        size_t bytes = (size_t)lay.n_chunks * sizeof(PermArgs);
+        bytes = std::max(bytes, (size_t)lay.n_lookups * sizeof(LkNumDenArgs));
+        bytes = std::max(bytes, (size_t)lay.n_adv * sizeof(CopyPair));
+        pk->batch_args_bytes = bytes;
+        if (hipMalloc(&pk->d_batch_args, bytes) != hipSuccess || hipHostMalloc(&pk->h_batch_args, bytes) != hipSuccess) return fail(ZK_ENOMEM);
+    }
     return ZK_OK;
 }
 
@@ -812,8 +821,18 @@ struct Prover {
         // polynomial needs a challenge) and collected in transcript order; RNG draws keep
         // halo2's order (the random polynomial's block range is reserved up front).
         // -- 1. advice
+        // (many columns: one launch copies them all — the argument staging is reused by the later batched launches, each
+        // preceded by a stream-ordered upload, so the host must not overwrite it before the upload has been consumed)
+        const bool many = lay.n_adv > BATCH_ARGS_MIN;
+        if (many) {
+            CopyPair* h = static_cast<CopyPair*>(pk->h_batch_args);
+            for (uint32_t j = 0; j < lay.n_adv; j++) h[j] = CopyPair{advice_dev[j], pk->adv_val[j]};
+            if (hipMemcpyAsync(pk->d_batch_args, h, lay.n_adv * sizeof(CopyPair), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
+            launch_copy_columns(static_cast<const CopyPair*>(pk->d_batch_args), lay.n_adv, n, st);
+            if (hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;
+        }
         for (uint32_t j = 0; j < lay.n_adv; j++) {
-            hipMemcpyAsync(pk->adv_val[j], advice_dev[j], (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
+            if (!many) hipMemcpyAsync(pk->adv_val[j], advice_dev[j], (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
             set_rows(pk->adv_val[j], usable, draw(bf + 1));
         }
         draw(lay.n_adv);  // advice blinds (unused by KZG, still drawn)
@@ -944,6 +963,8 @@ struct Prover {
             const uint32_t nblk = gp_blocks(n);
             const Fr delta = fr_delta();
             Fr dcur = Fr::one();
+            const bool many_chunks = lay.n_chunks > BATCH_ARGS_MIN;
+            if (many_chunks && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the argument staging may still be in use
             for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
                 PermArgs a;
                 memset(&a, 0, sizeof(a));
@@ -961,15 +982,33 @@ struct Prover {
                 a.gamma = gamma;
                 a.num = pk->gp_num[ci];
                 a.den = pk->gp_den[ci];
-                launch_perm_numden(a, st);
+                if (many_chunks) static_cast<PermArgs*>(pk->h_batch_args)[ci] = a;
+                else launch_perm_numden(a, st);
                 zs.push_back(pk->z_val[ci]);
             }
+            if (many_chunks) {
+                if (hipMemcpyAsync(pk->d_batch_args, pk->h_batch_args, lay.n_chunks * sizeof(PermArgs), hipMemcpyHostToDevice, st) != hipSuccess)
+                    return ZK_EHIP;
+                launch_perm_numden_batch(static_cast<const PermArgs*>(pk->d_batch_args), lay.n_chunks, n, st);
+            }
+            const bool many_lookups = lay.n_lookups > BATCH_ARGS_MIN;
+            if (many_lookups && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the staging is rewritten below
             for (uint32_t l = 0; l < lay.n_lookups; l++) {
                 const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
                 const uint32_t p = lay.n_chunks + l;
-                launch_lk_numden(pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], beta, gamma, pk->gp_num[p], pk->gp_den[p], n,
-                                 st);
+                if (many_lookups)
+                    static_cast<LkNumDenArgs*>(pk->h_batch_args)[l] =
+                        LkNumDenArgs{pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], pk->gp_num[p], pk->gp_den[p]};
+                else
+                    launch_lk_numden(pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], beta, gamma, pk->gp_num[p], pk->gp_den[p], n,
+                                     st);
                 zs.push_back(pk->lk_z[l]);
+            }
+            if (many_lookups) {
+                if (hipMemcpyAsync(pk->d_batch_args, pk->h_batch_args, lay.n_lookups * sizeof(LkNumDenArgs), hipMemcpyHostToDevice, st) !=
+                    hipSuccess)
+                    return ZK_EHIP;
+                launch_lk_numden_batch(static_cast<const LkNumDenArgs*>(pk->d_batch_args), lay.n_lookups, beta, gamma, n, st);
             }
             for (uint32_t p = 0; p < nprod; p++) {
                 items[p].num = pk->gp_num[p];

@@ -399,6 +399,47 @@ __global__ void perm_numden_kernel(PermArgs a) {
 void launch_perm_numden(const PermArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(perm_numden_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
 }
+// every chunk of a proof in one launch (blockIdx.y = chunk; argument blocks in device memory): the many-column rows of
+// bench_ecdsa.config have up to 176 chunks of 2^11 .. 2^13 rows — launch-bound one by one
+__global__ void perm_numden_batch_kernel(const PermArgs* __restrict__ args) {
+    const PermArgs& a = args[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const Fr beta = a.beta, gamma = a.gamma;
+    const Fr wi_beta = fe_mul(fe_load(a.tw + i), beta);
+    Fr num = Fr::one(), den = Fr::one();
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        const Fr v = fe_load(a.values[c] + i);
+        const Fr vg = fe_add(v, gamma);
+        den = fe_mul(den, fe_add(vg, fe_mul(beta, fe_load(a.sigma[c] + i))));
+        num = fe_mul(num, fe_add(vg, fe_mul(wi_beta, a.delta[c])));
+    }
+    fe_store(a.num + i, num);
+    fe_store(a.den + i, den);
+}
+void launch_perm_numden_batch(const PermArgs* d_args, uint32_t count, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(perm_numden_batch_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, d_args);
+}
+// the same for the lookups' numerators / denominators (argument blocks: LkNumDenArgs)
+__global__ void lk_numden_batch_kernel(const LkNumDenArgs* __restrict__ args, Fr beta, Fr gamma, uint32_t n) {
+    const LkNumDenArgs a = args[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store(a.den + i, fe_mul(fe_add(fe_load(a.ap + i), beta), fe_add(fe_load(a.sp + i), gamma)));
+    fe_store(a.num + i, fe_mul(fe_add(fe_load(a.inp + i), beta), fe_add(fe_load(a.tab + i), gamma)));
+}
+void launch_lk_numden_batch(const LkNumDenArgs* d_args, uint32_t count, const Fr& beta, const Fr& gamma, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(lk_numden_batch_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, d_args, beta, gamma, n);
+}
+// dst[q][0 .. n) = src[q][0 .. n) for `count` columns in one launch (the advice columns of a request -> the prover's copies)
+__global__ void copy_columns_kernel(const CopyPair* __restrict__ pairs, uint32_t n) {
+    const CopyPair p = pairs[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(p.dst + i, fe_load(p.src + i));
+}
+void launch_copy_columns(const CopyPair* d_pairs, uint32_t count, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(copy_columns_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, d_pairs, n);
+}
 
 // den = (a' + beta)(s' + gamma); num = (in + beta)(tab + gamma)
 __global__ void lk_numden_kernel(const Fr* ap, const Fr* sp, const Fr* inp, const Fr* tab, Fr beta, Fr gamma, Fr* num,
