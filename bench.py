@@ -147,7 +147,7 @@ class FakeWorkload:
         pass
 
 
-def pmc_traffic_bytes(kernel="zk::msm_accumulate_fast_kernel"):
+def pmc_traffic_bytes(kernel="zk::msm_wacc_fast_kernel"):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (separate FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/*_pmc_hbm.csv; KiB as
     rocprofv3 reports them — on gfx950 FETCH_SIZE under-counts wide coalesced reads 2x, so this is a
@@ -196,7 +196,7 @@ def alu_roofline(eng, k):
     ms /= max(cnt, 1)
     adds = n * windows * (1.0 - 2.0 ** -c)  # a signed digit is zero with probability 2^-c
     achieved = adds / (ms * 1e-3) / 1e9
-    return {"kernel": "msm_accumulate_fast_kernel", "bound": "int-valu (v_mad_u64_u32 issue rate)", "achieved": achieved,
+    return {"kernel": "msm_wacc_fast_kernel", "bound": "int-valu (v_mad_u64_u32 issue rate)", "achieved": achieved,
             "peak": ALU_PEAK_GADDS, "unit": "G mixed adds/s", "frac": achieved / ALU_PEAK_GADDS, "avg_launch_ms": ms,
             "window_bits": c, "adds_per_launch": adds,
             "peak_model": "%d SIMDs x %.1f GHz / %.1f cycles per wave64 v_mad_u64_u32 x 64 lanes / %d mads per mixed add"
@@ -362,7 +362,7 @@ def main():
             "config": {"workload": WORKLOAD, "k": K, "transcript": "blake2b", "multiopen": "shplonk", "proof_bytes": 960,
                        "parallelism": "replicas:%d (one independent proof stream per GPU, no collective)" % world},
             "roofline": {
-                "kernel": "msm_accumulate_fast_kernel",
+                "kernel": "msm_wacc_fast_kernel",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -941,8 +941,7 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
 //     (lane, bucket) pair: slot index = lane + bucket, unique and ordered along the staircase of the pairs) and restarts.
 //     A restart costs a few moves because the window tables of this path hold the points in the accumulation's internal
 //     form (x * 2^261: g1x29_add_affine<.., INTERNAL>).  Against 16-entry segments padded per bucket: no padding lanes
-//     (3 %), half the slots for the reduction tail to add up (5 % of the bucket additions), and one 2^19 column is exactly
-//     4096 waves = one full round of four waves per SIMD (16-entry segments: 2.07 rounds);
+//     (3 %), no skip markers to write, and the run length WL is free to choose (measured below);
 //   * the reduction tail is shaped for many small buckets: (T1) one lane per "part" of at most WCAP slots sums it
 //     serially, lanes of the same bucket inside a wave are joined by a segmented shuffle tree; (T2) the bucket matrix
 //     [rows = nb / 256][256] is summed along its rows and along its columns, one wave each —
@@ -960,9 +959,13 @@ static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = 8;  // WCAP_MIN sizes the p
 static inline uint32_t wcap_for(uint32_t batch) { return batch == 1 ? (uint32_t)ZK_WCAP_ONE : WCAP_BATCH; }
 static constexpr uint32_t WIDE_SUMS = 16; // bit sums per column handed to the host: 9 column bits, then up to 7 row bits
 #ifndef ZK_WL
-#define ZK_WL 32
+#define ZK_WL 16
 #endif
-static constexpr uint32_t WL = ZK_WL;     // entries per accumulation lane (a 2^19 column of 16-bit windows: 2^23 / 32 = 4096 waves)
+// entries per accumulation lane.  Measured with whole proofs, two pipelines in flight (tools/bench_ab.sh, proofs/s | single
+// proof ms): 8: 90.0 | 12.9, 11: 91.4 | 12.9, 12: 92.8 | 12.5, 16: 95.0 | 12.2, 32: 91.4 | 12.8, 48: 85.8 | 13.7, 64: 84.4 | 13.9
+// — short runs mean more slots for the reduction tail to add up, long runs fewer, longer waves that share the chip badly
+// with the other kernels in flight (a 2^19 column is 8192 waves of 16 additions)
+static constexpr uint32_t WL = ZK_WL;
 // slots of a bucket whose cnt > 0 entries start at position s of the column's entry list: one per lane that holds some of them
 __device__ __forceinline__ uint32_t wide_slot_count(uint32_t s, uint32_t cnt) { return cnt ? (s + cnt - 1) / WL - s / WL + 1 : 0; }
 
