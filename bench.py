@@ -44,8 +44,14 @@ class ProofWorkload:
     """This rank's share of the batch: `inflight` pipelines (own zk_ctx + host thread each) on one GPU, their jobs
     synthesized on the host (process pool) and shipped to HBM before the clock starts."""
 
-    def __init__(self, device, rank, world, inflight, steps, warmup):
+    def __init__(self, device, rank, world, inflight, steps, warmup, options=()):
         from webauthn_halo2_amd import batch, circuit, engine as E
+
+        def factory(dev):  # tuning experiments only (--opt id=value -> zk_ctx_set_option before the SRS is loaded)
+            e = E.Engine(dev)
+            for oid, val in options:
+                e.set_option(oid, val)
+            return e
 
         self.batch, self.E = batch, E
         p = circuit.K19
@@ -57,7 +63,7 @@ class ProofWorkload:
         self.synth_s = (time.time() - t0) / len(self.jobs)
         fixed, copies = batch.structure(p)
         t0 = time.time()
-        self.pipes = [batch.Pipeline(device, p, fixed, copies, deterministic_seeds=True) for _ in range(inflight)]
+        self.pipes = [batch.Pipeline(device, p, fixed, copies, engine_factory=factory, deterministic_seeds=True) for _ in range(inflight)]
         self.keygen_s = (time.time() - t0) / inflight
         for q, pl in enumerate(self.pipes):
             for j in self.jobs[q::inflight]:
@@ -259,7 +265,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent proof pipelines per GPU (each its own zk_ctx + host thread); the K timed steps are "
                          "shared among them.  1 = strictly one proof at a time (single-proof latency).")
+    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE",
+                    help="tuning experiments: zk_ctx_set_option(ID, VALUE) on every pipeline (include/zkmi355.h ZK_OPT_*)")
     args = ap.parse_args()
+    options = [tuple(int(x) for x in o.split("=")) for o in args.opt]
 
     fake = os.environ.get("ZKMI355_BENCH_FAKE") == "1"  # CPU test of the launch/timing logic only
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and os.environ.get("ZKMI355_BENCH_WORKER") != "1":
@@ -288,7 +297,7 @@ def main():
         # independent proof streams: replicas, no data-path collective.  `inflight` pipelines share one GPU so
         # that the latency-bound phases of one proof (transcript round trips, reduction tails) overlap the
         # throughput-bound kernels of another.
-        wl = ProofWorkload(local_rank, rank, world, nfl, args.steps, args.warmup)
+        wl = ProofWorkload(local_rank, rank, world, nfl, args.steps, args.warmup, options)
 
     def barrier():
         if not fake:
