@@ -52,7 +52,9 @@ bool msm_table_is_internal(uint32_t c, size_t n);
 // asynchronously.  `table` != nullptr selects the fixed-base mode: `batch` scalar vectors (columns) against
 // the same bases in ONE pass, one bucket set per column; *nwin_out = batch independent results, each finished
 // with msm_finish_host(sums + q * stride, 1, c).  Without a table batch must be 1 and *nwin_out windows need
-// the host Horner: msm_finish_host(sums, *nwin_out, c).
+// the host Horner: msm_finish_host(sums, *nwin_out, c).  A workspace of 15 / 16-bit windows whose table indexes fit 24 bits runs the
+// fixed-base mode on the "wide path" (msm.hip: dense entry lists, restartable lanes, row / column tail): results through
+// msm_ws_finish_fixed, msm_ws_sums_per_result sums each.
 hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t batch, const G1Affine* bases, size_t n,
                    hipStream_t st, G1X* host_window_sums, uint32_t* nwin_out, uint32_t* c_out,
                    hipEvent_t* accum_events = nullptr, const G1Affine* table = nullptr, uint32_t table_stride = 0,

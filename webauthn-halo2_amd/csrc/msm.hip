@@ -309,7 +309,7 @@ static bool sort2_applies(bool fused, size_t n, uint32_t nb, uint32_t nwin, size
 }
 
 static constexpr uint32_t SUB = ZK_SORT_SUB;  // entries sorted in LDS at a time
-static constexpr uint32_t COARSE_WORDS = 5 * (CBINS_MAX + 1);  // per column: bin starts, chunk prefix, append cursors; wide path: the bins' entry / part regions
+static constexpr uint32_t COARSE_WORDS = 5 * (CBINS_MAX + 1);  // per column, CBINS_MAX + 1 words each: bin starts, chunk prefix, append cursors, (unused), wide path: the bins' part regions
 
 // digits + fine histogram: the global bucket totals (the workgroup's counts are added with one atomic per non-empty bucket)
 __global__ __launch_bounds__(256) void msm_recode_hist2_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c, uint32_t nwin,
@@ -679,16 +679,13 @@ __attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __restrict__ entries,
                                                             const G1Affine* __restrict__ bases,
                                                             const uint32_t* __restrict__ counts,
-                                                            G1X29S* __restrict__ slot_pt, uint32_t slot_stride) {
-    // blockIdx.y = column region of the wide path (slot_stride slots each, counts[4 col] entries in use); the dense
-    // layout is one region
-    const uint32_t total = counts[4 * blockIdx.y];  // multiple of SEG0
+                                                            G1X29S* __restrict__ slot_pt) {
+    const uint32_t total = counts[0];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
-    const size_t gs = (size_t)blockIdx.y * slot_stride + t;
     // the running sum lives on the carry-free 29-bit-limb field (ec29.hip.h); bases are read in
     // their standard memory form, the slot is written in the internal one (the reduction tails stay on that field)
-    g1x29_store(slot_pt + gs, accumulate_segment<true>(entries + gs * SEG0, bases));
+    g1x29_store(slot_pt + t, accumulate_segment<true>(entries + (size_t)t * SEG0, bases));
 }
 
 // Unchecked kernel for a basis without the identity (the resident SRS): no test at all in the loop, and none of the
@@ -701,14 +698,13 @@ __attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
 __global__ __launch_bounds__(64) void msm_accumulate_fast_kernel(const uint32_t* __restrict__ entries,
                                                                  const G1Affine* __restrict__ bases,
                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ redo,
-                                                                 G1X29S* __restrict__ slot_pt, uint32_t slot_stride) {
-    const uint32_t total = counts[4 * blockIdx.y];  // multiple of SEG0
+                                                                 G1X29S* __restrict__ slot_pt) {
+    const uint32_t total = counts[0];  // multiple of SEG0
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * SEG0 >= total) return;
-    const size_t gs = (size_t)blockIdx.y * slot_stride + t;
-    const G1X29 acc = accumulate_segment<false>(entries + gs * SEG0, bases);
-    if (!acc.inf && is_zero29(acc.zz)) redo[atomicAdd(&counts[1], 1u)] = (uint32_t)gs;  // at most one entry per segment: redo[] has one word each
-    g1x29_store(slot_pt + gs, acc);
+    const G1X29 acc = accumulate_segment<false>(entries + (size_t)t * SEG0, bases);
+    if (!acc.inf && is_zero29(acc.zz)) redo[atomicAdd(&counts[1], 1u)] = t;  // at most one entry per segment: redo[] has one word each
+    g1x29_store(slot_pt + t, acc);
 }
 __global__ __launch_bounds__(64) void msm_accumulate_redo_kernel(const uint32_t* __restrict__ entries,
                                                                  const G1Affine* __restrict__ bases,
@@ -1781,10 +1777,10 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
         if (accum_events) hipEventRecord(accum_events[0], st);
         if (bases_may_be_identity) {
             hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                               fixed ? table : bases, ws->counts, ws->slot_pt, 0u);
+                               fixed ? table : bases, ws->counts, ws->slot_pt);
         } else {
             hipLaunchKernelGGL(msm_accumulate_fast_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, st, ws->entries,
-                               fixed ? table : bases, ws->counts, ws->redo, ws->slot_pt, 0u);
+                               fixed ? table : bases, ws->counts, ws->redo, ws->slot_pt);
         }
         if (accum_events) hipEventRecord(accum_events[1], st);  // the dominant kernel alone (bench.py's roofline)
         if (!bases_may_be_identity)
