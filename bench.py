@@ -63,7 +63,11 @@ class ProofWorkload:
         self.synth_s = (time.time() - t0) / len(self.jobs)
         fixed, copies = batch.structure(p)
         t0 = time.time()
-        self.pipes = [batch.Pipeline(device, p, fixed, copies, engine_factory=factory, deterministic_seeds=True) for _ in range(inflight)]
+        # the further pipelines of this GPU share the first one's resident SRS and window tables (zk_ctx_create_shared)
+        self.pipes = []
+        for q in range(inflight):
+            self.pipes.append(batch.Pipeline(device, p, fixed, copies, engine_factory=factory, deterministic_seeds=True,
+                                             share_srs_with=self.pipes[0] if q and not os.environ.get("ZKMI355_BENCH_NO_SHARE") else None))
         self.keygen_s = (time.time() - t0) / inflight
         for q, pl in enumerate(self.pipes):
             for j in self.jobs[q::inflight]:

@@ -57,6 +57,10 @@ typedef uint64_t zk_poly; /* opaque device-resident vector of Fr; 0 is never val
 /* ---- context ------------------------------------------------------------- */
 int zk_device_count(void);
 int zk_ctx_create(int device_id, zk_ctx** out);
+/* a further context on ctx's device that SHARES ctx's resident SRS (bases and window tables, read-only, as loaded at this
+ * moment): one context per proof pipeline / host thread without a copy of the tables each.  Either context may later load
+ * another SRS for itself; the shared memory is freed when its last user lets go (destroying `parent` first is fine). */
+int zk_ctx_create_shared(zk_ctx* parent, zk_ctx** out);
 void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_strerror(int code);
 int zk_last_hip_error(const zk_ctx* ctx); /* raw hipError_t of the last ZK_EHIP */

@@ -553,3 +553,45 @@ def test_k19_batch_of_8_jobs_equals_committed_oracle_proofs():
         assert len(got[j]) == 960
         assert hashlib.sha256(got[j]).hexdigest() == fx["jobs"][str(j)]["sha256"], j
         assert got[j].hex() == fx["jobs"][str(j)]["proof"], j
+
+
+def test_shared_srs_contexts():
+    """zk_ctx_create_shared: a second context on the device uses the first one's resident SRS and window tables — same
+    commitments, byte-identical proofs from its own key; the shared memory outlives the context that loaded it, and a
+    context that loads another SRS for itself leaves the other one's view untouched."""
+    A, L, F, k, lb = SHAPES["k10batched"][:5]
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    asg = zk.circuit.synthesize(p, 0x5EED0019)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    first = zk.Engine(0)
+    first.srs_setup(k)
+    second = zk.Engine(0, share_with=first)
+    assert second.srs_msm_plan() == first.srs_msm_plan()
+    a = np.frombuffer(np.random.default_rng(5).bytes(32 << k), dtype=np.uint64).reshape(-1, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    want = first.commit(first.poly(1 << k, a), 1)
+    assert np.array_equal(second.commit(second.poly(1 << k, a), 1), want)
+    proofs = []
+    for eng in (first, second):
+        pk = eng.keygen(p, fixed, asg.copies)
+        polys = []
+        for col in asg.advice:
+            h = eng.poly(1 << k)
+            eng.upload_canonical(h, asg.to_limbs(col))
+            polys.append(h)
+        proofs.append((eng, pk, polys, eng.prove(pk, polys, b"\x09" * 32, E.ZK_TRANSCRIPT_EVM)))
+    assert proofs[0][3] == proofs[1][3]
+    # the loader goes away first: the child keeps the SRS alive
+    first.close()
+    eng, pk, polys, pf = proofs[1]
+    assert eng.prove(pk, polys, b"\x09" * 32, E.ZK_TRANSCRIPT_EVM) == pf
+    assert np.array_equal(eng.commit(eng.poly(1 << k, a), 1), want)
+    # a third context shares the second's; the second then loads another SRS for itself: the third still sees the old one
+    third = zk.Engine(0, share_with=second)
+    second.srs_setup(k, bytes([7]) * 32)
+    assert not np.array_equal(second.commit(second.poly(1 << k, a), 1), want)
+    assert np.array_equal(third.commit(third.poly(1 << k, a), 1), want)
+    with pytest.raises(zk.ZkError):
+        second.prove(pk, polys, b"\x09" * 32, E.ZK_TRANSCRIPT_EVM)  # the key was made under the SRS the context let go of
+    second.close()
+    third.close()

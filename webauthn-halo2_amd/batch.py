@@ -73,13 +73,19 @@ def structure(params):
 class Pipeline:
     """One proof in flight: a zk_ctx on `device` with the SRS of params.degree and the proving key resident."""
 
-    def __init__(self, device, params, fixed=None, copies=None, engine_factory=Engine, deterministic_seeds=False):
+    def __init__(self, device, params, fixed=None, copies=None, engine_factory=Engine, deterministic_seeds=False,
+                 share_srs_with=None):
         """deterministic_seeds: blinding from job_rng_seed(job) instead of the OS entropy source — reproducible
-        proofs for tests and benchmarks, at the price of zero-knowledge (see job_rng_seed)."""
+        proofs for tests and benchmarks, at the price of zero-knowledge (see job_rng_seed).
+        share_srs_with: another Pipeline on the same device whose resident SRS and window tables this one uses too
+        (zk_ctx_create_shared) — the further pipelines of a GPU need no copy of their own."""
         self.params = params
         self.deterministic_seeds = deterministic_seeds
-        self.eng = engine_factory(device)
-        self.eng.srs_setup(params.degree)
+        if share_srs_with is not None:
+            self.eng = Engine(device, share_with=share_srs_with.eng)
+        else:
+            self.eng = engine_factory(device)
+            self.eng.srs_setup(params.degree)
         if fixed is None:
             fixed, copies = structure(params)
         self.pk = self.eng.keygen(params, fixed, copies)

@@ -1,6 +1,7 @@
 // ctx.h — the engine context shared by engine.hip (C-ABI) and prover.hip.
 #pragma once
 #include <map>
+#include <memory>
 #include <new>
 #include <mutex>
 #include <unordered_map>
@@ -19,6 +20,21 @@ struct PolyRec {
     size_t n;
 };
 
+// The resident SRS of a context: both bases and their window tables.  Reference-counted: contexts made with
+// zk_ctx_create_shared use the block of the context they were made from (read-only; several proof pipelines on one device
+// then gather from ONE copy of the tables), and a context that loads another SRS simply lets go of its reference.
+struct SrsBlock {
+    int device = -1;
+    G1Affine *g = nullptr, *g_lagrange = nullptr, *g_table = nullptr, *g_lagrange_table = nullptr;
+    ~SrsBlock() {
+        if (device >= 0) hipSetDevice(device);
+        if (g) hipFree(g);
+        if (g_lagrange) hipFree(g_lagrange);
+        if (g_table) hipFree(g_table);
+        if (g_lagrange_table) hipFree(g_lagrange_table);
+    }
+};
+
 struct zk_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -27,7 +43,8 @@ struct zk_ctx {
     std::map<uint32_t, Fr*> twiddles;      // log_n -> w_{2^log_n}^i table (standard form: quotient, permutation kernels)
     std::map<uint32_t, Fr*> coset_points;  // zeta * w^i (standard form): the x of the quotient's permutation terms
     std::map<uint32_t, Fr*> twiddles_ntt;  // the same powers in the NTT's internal form (x 2^261, ntt.hip)
-    // SRS
+    // SRS (the pointers below alias the members of `srs`, the owner)
+    std::shared_ptr<SrsBlock> srs;
     int srs_k = -1;
     G1Affine* g = nullptr;
     G1Affine* g_lagrange = nullptr;

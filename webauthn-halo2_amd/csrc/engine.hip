@@ -312,6 +312,38 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
     return ZK_OK;
 }
 
+// A second context on the same device that shares `parent`'s resident SRS (bases + window tables, read-only): the way to run
+// several proof pipelines per GPU (one zk_ctx per host thread) without a copy of the tables each.  The child sees the SRS as it
+// is NOW; either context may later load another SRS for itself (the shared block lives until its last user lets go).
+ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
+    if (!parent || !out) return ZK_EINVAL;
+    zk_ctx* c = nullptr;
+    int rc = zk_ctx_create(parent->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(parent->mu);
+    if (parent->srs_k >= 0) {
+        c->srs = parent->srs;
+        c->srs_k = parent->srs_k;
+        c->g = parent->g;
+        c->g_lagrange = parent->g_lagrange;
+        c->g_table = parent->g_table;
+        c->g_lagrange_table = parent->g_lagrange_table;
+        c->table_c = parent->table_c;
+        c->g_has_identity = parent->g_has_identity;
+        c->g_lagrange_has_identity = parent->g_lagrange_has_identity;
+        c->g2_valid = parent->g2_valid;
+        memcpy(c->g2_raw, parent->g2_raw, 128);
+        memcpy(c->s_g2_raw, parent->s_g2_raw, 128);
+        c->opt_msm_window = parent->opt_msm_window;  // the tables were built for this window
+        c->opt_msm_batch = parent->opt_msm_batch;
+        c->opt_ntt_max_r = parent->opt_ntt_max_r;
+        c->opt_gp_batch_invert = parent->opt_gp_batch_invert;
+        c->srs_gen++;
+    }
+    *out = c;
+    return ZK_OK;
+}
+
 void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -321,10 +353,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (auto& kv : c->coset_points) hipFree(kv.second);
     pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
-    if (c->g) hipFree(c->g);
-    if (c->g_lagrange) hipFree(c->g_lagrange);
-    if (c->g_table) hipFree(c->g_table);
-    if (c->g_lagrange_table) hipFree(c->g_lagrange_table);
+    c->srs.reset();  // frees the bases and tables unless another context shares them
     for (int i = 0; i < zk_ctx::MSM_LANES; i++) {
         zk_ctx::MsmLane& L = c->lanes[i];
         if (L.tail) hipStreamSynchronize(L.tail);
@@ -545,9 +574,11 @@ int srs_build_tables(zk_ctx* c, uint32_t k) {
     const uint32_t n = 1u << k;
     const uint32_t cw = msm_auto_window(n, c->opt_msm_window);
     const size_t cnt = (size_t)msm_num_windows(cw) * n;
-    if (hipMalloc(&c->g_table, cnt * sizeof(G1Affine)) != hipSuccess ||
-        hipMalloc(&c->g_lagrange_table, cnt * sizeof(G1Affine)) != hipSuccess)
+    if (hipMalloc(&c->srs->g_table, cnt * sizeof(G1Affine)) != hipSuccess ||
+        hipMalloc(&c->srs->g_lagrange_table, cnt * sizeof(G1Affine)) != hipSuccess)
         return ZK_ENOMEM;
+    c->g_table = c->srs->g_table;
+    c->g_lagrange_table = c->srs->g_lagrange_table;
     hipError_t e = msm_build_table(c->g, n, cw, c->g_table, c->stream);
     if (e == hipSuccess) e = msm_build_table(c->g_lagrange, n, cw, c->g_lagrange_table, c->stream);
     if (e == hipSuccess) e = msm_bases_have_identity(c->g, n, c->stream, (uint32_t*)c->small, (uint32_t*)c->host_small, &c->g_has_identity);
@@ -562,35 +593,32 @@ int srs_build_tables(zk_ctx* c, uint32_t k) {
     return ZK_OK;
 }
 
-void srs_adopt(zk_ctx* c, uint32_t k, G1Affine* g, G1Affine* g_lagrange) {
-    (void)k;
+// a fresh, empty block for this context (the previous one is released: freed unless another context still shares it)
+static void srs_new_block(zk_ctx* c) {
     c->g2_valid = false;
     c->srs_gen++;  // proving keys made under the previous SRS are refused from now on (ZK_ESTATE)
-    if (c->g) hipFree(c->g);
-    if (c->g_lagrange) hipFree(c->g_lagrange);
-    if (c->g_table) hipFree(c->g_table);
-    if (c->g_lagrange_table) hipFree(c->g_lagrange_table);
-    c->g_table = c->g_lagrange_table = nullptr;
+    c->srs = std::make_shared<SrsBlock>();
+    c->srs->device = c->device;
+    c->g = c->g_lagrange = c->g_table = c->g_lagrange_table = nullptr;
     c->table_c = 0;
     c->srs_k = -1;
-    c->g = g;
-    c->g_lagrange = g_lagrange;
+}
+
+void srs_adopt(zk_ctx* c, uint32_t k, G1Affine* g, G1Affine* g_lagrange) {
+    (void)k;
+    srs_new_block(c);
+    c->g = c->srs->g = g;
+    c->g_lagrange = c->srs->g_lagrange = g_lagrange;
 }
 
 int srs_alloc(zk_ctx* c, uint32_t k) {
     if (k < 1 || k > 24) return ZK_EINVAL;
-    c->g2_valid = false;
-    c->srs_gen++;  // proving keys made under the previous SRS are refused from now on (ZK_ESTATE)
     const size_t n = (size_t)1 << k;
-    if (c->g) hipFree(c->g);
-    if (c->g_lagrange) hipFree(c->g_lagrange);
-    if (c->g_table) hipFree(c->g_table);
-    if (c->g_lagrange_table) hipFree(c->g_lagrange_table);
-    c->g = c->g_lagrange = c->g_table = c->g_lagrange_table = nullptr;
-    c->table_c = 0;
-    c->srs_k = -1;
-    if (hipMalloc(&c->g, n * sizeof(G1Affine)) != hipSuccess || hipMalloc(&c->g_lagrange, n * sizeof(G1Affine)) != hipSuccess)
+    srs_new_block(c);
+    if (hipMalloc(&c->srs->g, n * sizeof(G1Affine)) != hipSuccess || hipMalloc(&c->srs->g_lagrange, n * sizeof(G1Affine)) != hipSuccess)
         return ZK_ENOMEM;
+    c->g = c->srs->g;
+    c->g_lagrange = c->srs->g_lagrange;
     return ZK_OK;
 }
 

@@ -58,6 +58,7 @@ def load_library():
     sig = {
         "zk_device_count": ([], ctypes.c_int),
         "zk_ctx_create": ([ctypes.c_int, ctypes.POINTER(vp)], ctypes.c_int),
+        "zk_ctx_create_shared": ([vp, ctypes.POINTER(vp)], ctypes.c_int),
         "zk_ctx_destroy": ([vp], None),
         "zk_strerror": ([ctypes.c_int], ctypes.c_char_p),
         "zk_last_hip_error": ([vp], ctypes.c_int),
@@ -142,10 +143,15 @@ class Poly:
 class Engine:
     """One zk_ctx = one HIP device + stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, share_with=None):
+        """share_with: another Engine on the same device whose resident SRS (bases + window tables) this one uses too
+        (zk_ctx_create_shared) instead of loading its own copy."""
         self.L = load_library()
         ctx = ctypes.c_void_p()
-        rc = self.L.zk_ctx_create(device, ctypes.byref(ctx))
+        if share_with is not None:
+            rc = self.L.zk_ctx_create_shared(share_with.ctx, ctypes.byref(ctx))
+        else:
+            rc = self.L.zk_ctx_create(device, ctypes.byref(ctx))
         if rc != 0:
             raise ZkError(rc, "zk_ctx_create: " + self.L.zk_strerror(rc).decode())
         self.ctx = ctx
