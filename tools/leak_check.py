@@ -8,7 +8,7 @@ def used():
     f, t = ctypes.c_size_t(), ctypes.c_size_t()
     hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t))
     return (t.value - f.value) / 2**30
-p = zk.circuit.K17
+p = zk.circuit.K19 if len(sys.argv) > 1 and sys.argv[1] == "19" else zk.circuit.K17
 asg = zk.circuit.synthesize(p, 1)
 fx = np.stack([asg.to_limbs(c) for c in asg.fixed])
 base = used()

@@ -12,7 +12,8 @@ p = circuit.K19 if k == 19 else circuit.K17
 jobs = list(range(4))
 wit = batch.synthesize_jobs(p, jobs)
 fixed, copies = batch.structure(p)
-pipes = [batch.Pipeline(0, p, fixed, copies) for _ in range(2)]
+pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)]
+pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
 for pl in pipes:
     for j in jobs:
         pl.load(j, wit[j])
