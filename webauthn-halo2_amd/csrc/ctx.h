@@ -62,7 +62,9 @@ struct zk_ctx {
     // MSM lanes: each in-flight MSM owns a workspace, a tail stream and a pinned result buffer
     static constexpr int MSM_LANES = 3;
     struct MsmLane {
-        MsmWorkspace* ws = nullptr;
+        MsmWorkspace* ws = nullptr;      // fixed-base mode over the resident SRS (window = the tables')
+        MsmWorkspace* ws_gen = nullptr;  // arbitrary bases (the fine-grained seam): its own workspace, so that a host mixing both does not rebuild one per call
+        MsmWorkspace* ws_run = nullptr;  // the one the MSM in flight uses
         hipStream_t tail = nullptr;
         hipEvent_t head_done = nullptr, tail_done = nullptr;
         hipEvent_t t_head[2] = {nullptr, nullptr}, t_acc[2] = {nullptr, nullptr};  // timing: whole head / accumulate kernel

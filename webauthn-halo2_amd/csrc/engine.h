@@ -38,7 +38,8 @@ struct MsmWorkspace;  // opaque, sized for a maximum n and a maximum number of c
 static constexpr uint32_t MSM_MAX_BATCH = 64;
 MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, uint32_t max_batch = 1);
 void msm_workspace_destroy(MsmWorkspace* ws);
-uint32_t msm_auto_window(size_t n, uint32_t override_c = 0);
+uint32_t msm_auto_window(size_t n, uint32_t override_c = 0);  // fixed-base mode (the resident SRS's window tables)
+uint32_t msm_auto_window_generic(size_t n);                   // arbitrary bases
 uint32_t msm_num_windows(uint32_t c);
 size_t msm_ws_max_n(const MsmWorkspace* ws);
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws);

@@ -149,22 +149,23 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     size_t want = 1;
     while (want < n) want <<= 1;
     if (want < 1024) want = 1024;
-    uint32_t cw = table_window ? table_window : msm_auto_window(want, c->opt_msm_window);
-    if (!table_window && cw > 15) cw = 15;
+    const uint32_t cw = table_window ? table_window : msm_auto_window_generic(want);
     zk_ctx::MsmLane& L = c->lanes[lane];
-    if (L.ws && (msm_ws_max_n(L.ws) != want || msm_ws_window(L.ws) != cw)) {
-        msm_workspace_destroy(L.ws);
-        L.ws = nullptr;
+    MsmWorkspace*& slot = table_window ? L.ws : L.ws_gen;
+    if (slot && (msm_ws_max_n(slot) != want || msm_ws_window(slot) != cw)) {
+        msm_workspace_destroy(slot);
+        slot = nullptr;
     }
-    if (!L.ws) {
+    if (!slot) {
         hipError_t e;
-        L.ws = msm_workspace_create(want, cw, &e, batch_for(c, want));
-        if (!L.ws) {
+        slot = msm_workspace_create(want, cw, &e, table_window ? batch_for(c, want) : 1u);
+        if (!slot) {
             c->last_hip = (int)e;
             return e == hipErrorInvalidValue ? ZK_EINVAL : ZK_ENOMEM;
         }
     }
-    *out = L.ws;
+    L.ws_run = slot;
+    *out = slot;
     return ZK_OK;
 }
 
@@ -213,8 +214,8 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
     HIPCHK(c, hipEventSynchronize(L.tail_done));
     if (L.fixed) {
         // fixed-base mode: one independent result per column
-        const uint32_t per = msm_ws_sums_per_result(L.ws);
-        for (uint32_t q = 0; q < L.batch; q++) out[q] = msm_ws_finish_fixed(L.ws, L.host_buf + (size_t)q * per);
+        const uint32_t per = msm_ws_sums_per_result(L.ws_run);
+        for (uint32_t q = 0; q < L.batch; q++) out[q] = msm_ws_finish_fixed(L.ws_run, L.host_buf + (size_t)q * per);
     } else {
         out[0] = msm_finish_host(L.host_buf, L.nwin, L.cw);  // generic mode: Horner over the windows
     }
@@ -358,6 +359,7 @@ void zk_ctx_destroy(zk_ctx* c) {
         zk_ctx::MsmLane& L = c->lanes[i];
         if (L.tail) hipStreamSynchronize(L.tail);
         if (L.ws) msm_workspace_destroy(L.ws);
+        if (L.ws_gen) msm_workspace_destroy(L.ws_gen);
         if (L.host_buf) hipHostFree(L.host_buf);
         for (int j = 0; j < 2; j++) {
             if (L.t_head[j]) hipEventDestroy(L.t_head[j]);

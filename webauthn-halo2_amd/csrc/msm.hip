@@ -131,6 +131,17 @@ uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     return (uint32_t)c;
 }
 
+// arbitrary bases (generic mode: a bucket set per window, host Horner over the windows): the round-2 rule — lg - 6 from 2^19
+// (13 bits at 2^19), 12 at 2^16 .. 2^18, lg - 5 below, at most 14 (15 from 2^21)
+uint32_t msm_auto_window_generic(size_t n) {
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg >= 19 ? (int)lg - 6 : (lg >= 16 ? 12 : (int)lg - 5);
+    if (c > 14) c = lg >= 21 ? 15 : 14;
+    if (c < 9) c = 9;
+    return (uint32_t)c;
+}
+
 uint32_t msm_num_windows(uint32_t c) { return nwin_for(c); }
 size_t msm_ws_max_n(const MsmWorkspace* ws) { return ws->max_n; }
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws) { return ws->max_batch; }
