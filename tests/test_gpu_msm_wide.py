@@ -55,8 +55,12 @@ def test_wide_commit_matches_tau_oracle(windowed, bits, k):
     mixm = cops.fr_mont(mix)
     boolc = cops.fr_mont([pr.randrange(2) for _ in range(n)])   # one giant bucket
     top = cops.fr_mont([F.R - 1 - pr.randrange(3) for _ in range(n)])  # largest scalars: every window's top digits, carries
-    polys = [eng.poly(n, c) for c in cols[:3]] + [eng.poly(n, mixm), eng.poly(n, boolc), eng.poly(n, top)]
-    data = cols[:3] + [mixm, boolc, top]
+    # a handful of distinct digits: non-empty buckets hundreds apart and whole coarse bins empty — every first-of-bucket entry
+    # takes the escape of the lanes' bucket tracking (distance field saturated / first bucket of a bin)
+    vals = [1, 40000, (3 << 16) | 7, (12345 << 32) | (65535 << 16) | 200, (1 << 253) | (9 << 128), F.R - 2]
+    sparse = cops.fr_mont([vals[pr.randrange(len(vals))] if pr.random() < 0.7 else 0 for _ in range(n)])
+    polys = [eng.poly(n, c) for c in cols[:3]] + [eng.poly(n, mixm), eng.poly(n, boolc), eng.poly(n, top), eng.poly(n, sparse)]
+    data = cols[:3] + [mixm, boolc, top, sparse]
     want = [tau_commit(d) for d in data]
     for j, p in enumerate(polys):
         got = cops.affine_arr_to_ints(eng.commit(p, 0))[0]
