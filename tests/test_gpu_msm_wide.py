@@ -141,3 +141,21 @@ def test_wide_commit_tau_oracle_k19(windowed, bits):
     p2.free()
     for p in polys:
         p.free()
+
+
+def test_wide_commit_at_the_24_bit_index_boundary(windowed):
+    """k = 20 is the largest SRS of the wide path: 16 windows x 2^20 points = 2^24 table entries, the index field of an entry."""
+    eng = windowed(0)
+    k = 20
+    n = 1 << k
+    eng.srs_setup(k)
+    assert eng.srs_msm_plan() == (16, 16)
+    a = rand_col(np.random.default_rng(20), n)
+    a[n - 5:] = np.array([0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0x0FFFFFFFFFFFFFFF], dtype=np.uint64)  # the last points, every window
+    p = eng.poly(n, a)
+    assert cops.affine_arr_to_ints(eng.commit(p, 0))[0] == tau_commit(a)
+    q = eng.poly(n, a)
+    eng.lagrange_to_coeff(q)
+    assert (eng.commit(p, 1) == eng.commit(q, 0)).all()
+    p.free()
+    q.free()
