@@ -33,8 +33,13 @@ ROWS = [
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     eng = zk.Engine(0)
+    if os.environ.get("MSM_WINDOW"):  # tuning runs: force the fixed-base MSM window for every row
+        eng.set_option(E.ZK_OPT_MSM_WINDOW, int(os.environ["MSM_WINDOW"]))
+    only = [int(x) for x in os.environ["ROWS"].split(",")] if os.environ.get("ROWS") else None
     print("degree,num_advice,num_lookup,num_fixed,lookup_bits,proof_ms,proof_size,published_cpu_s,speedup")
     for k, A, L, F, lb, idle, pub_s, pub_b in ROWS:
+        if only and k not in only:
+            continue
         p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb,
                                      idle_gate_columns=idle)
         asg = zk.circuit.synthesize(p, 0x5EED0019)

@@ -16,6 +16,8 @@ else:
     p = zk.circuit.CircuitParams(degree=v[0], num_advice=v[1], num_lookup_advice=v[2], num_fixed=v[3], lookup_bits=v[4],
                                  idle_gate_columns=v[5])
 eng = zk.Engine(0)
+if os.environ.get("MSM_WINDOW", "0") != "0":
+    eng.set_option(E.ZK_OPT_MSM_WINDOW, int(os.environ["MSM_WINDOW"]))
 eng.srs_setup(p.degree)
 asg = zk.circuit.synthesize(p, 0x5EED0019)
 pk = eng.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)

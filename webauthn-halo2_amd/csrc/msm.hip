@@ -118,12 +118,11 @@ static bool msm_wide_applies(uint32_t c, size_t table_stride) {
 uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    // measured on MI355X with whole proofs (tools/single_ab.py, tools/window_exp.py): the wide path's 16-bit windows at 2^18 ..
-    // 2^20 (16 bucket additions per scalar instead of 20 / 22: k = 19 single proof 13.7 -> 12.5 ms, k = 18 10.3 -> 9.2 ms);
-    // 12 bits at 2^16 and 2^17 (k = 17: 7.6 ms / 158 proofs/s against 7.85 ms / 147 with 16 bits — lone commitments are faster
-    // on the wide path there too, but the proof's eight-column passes and short reduction tails are not), then lg - 5;
-    // 2^21 and up (window table indexes beyond 24 bits) 15 bits on the swept sort
-    int c = lg >= 21 ? 15 : (lg >= 18 ? 16 : (lg >= 16 ? 12 : (int)lg - 5));
+    // measured on MI355X with whole proofs (tools/single_ab.py, tools/window_exp.py, tools/bench_rows.py): the wide path's 16-bit
+    // windows at 2^16 .. 2^20 (16 bucket additions per scalar instead of 20 / 22: k = 19 single proof 13.7 -> 12.3 ms, k = 18
+    // 10.3 -> 9.2, k = 17 7.5 -> 6.95 ms and 160 -> 169 proofs/s, k = 16 7.4 -> 7.0); below, lg - 5 bits on the 13-bit plan (k = 15:
+    // 7.0 ms against 7.6 / 7.9 with 15 / 16 bits); 2^21 and up (window table indexes beyond 24 bits) 15 bits on the swept sort
+    int c = lg >= 21 ? 15 : (lg >= 16 ? 16 : (int)lg - 5);
     if (override_c) c = (int)override_c;  // zk_ctx_set_option(ZK_OPT_MSM_WINDOW)
     if (c < 9) c = 9;
     if (c > 16) c = 16;  // digits are int16
