@@ -958,7 +958,10 @@ static constexpr uint32_t WIDE_KEYS = 1u << WIDE_FB;
 // slots per part (T1's serial run), a per-pass parameter.  8 everywhere: lane-serial additions are the cheap ones (every lane
 // busy); shorter runs for a lone column — whose tail is exposed latency — were measured (tools/single_ab.py, k = 19 single
 // proof): 8: 12.37-12.41 ms, 4: 12.41-12.49, 2: 12.55-12.60 (more waves and more tree levels cost what the shorter chain saves)
-static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = 8;  // WCAP_MIN sizes the part lists
+#ifndef ZK_WCAP_BATCH
+#define ZK_WCAP_BATCH 8
+#endif
+static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = ZK_WCAP_BATCH;  // WCAP_MIN sizes the part lists
 #ifndef ZK_WCAP_ONE
 #define ZK_WCAP_ONE 8
 #endif
