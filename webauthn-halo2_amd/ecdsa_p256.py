@@ -195,9 +195,5 @@ def generate_proof_evm_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key
     return _prove_synthetic(pubkey_x, pubkey_y, r, s, msg_hash, proving_key_path, degree, ZK_TRANSCRIPT_EVM, device, rng_seed)
 
 
-def verify(*_a, **_k):
-    raise ZkError(-1, "verify/verify_evm are host-side and out of the engine's scope (DESIGN.md §1); "
-                      "use the reference's verify_proof, the generated verifier, or the oracle verifier in tests")
-
-
-verify_evm = verify
+# `verify` / `verify_evm` (ecdsa_p256.rs:429-469) are not mirrored: verification is host-side pairing work outside the engine's
+# path — the reference's verify_proof, its generated verifier, or (in tests) the oracle verifier check the proofs.
