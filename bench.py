@@ -92,6 +92,9 @@ class ProofWorkload:
         out, errs = {}, []
 
         def work(q):
+            # inline, by the pipeline's own host thread right before its proof: 0.4 ms per 16 MiB column, hidden behind the
+            # other pipeline's kernels.  Staging job i+1 from a loader thread on its own stream (Pipeline.stage / adopt) was
+            # measured slower: tools/stage_timing.py, DESIGN.md
             try:
                 pl = self.pipes[q]
                 for j in jobs[q::len(self.pipes)]:

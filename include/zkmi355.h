@@ -124,6 +124,12 @@ int zk_srs_set_g2(zk_ctx* ctx, const uint64_t g2[16], const uint64_t s_g2[16]);
 /* ---- resident polynomials -------------------------------------------------- */
 int zk_poly_alloc(zk_ctx* ctx, size_t n, zk_poly* out);
 int zk_poly_free(zk_ctx* ctx, zk_poly p);
+/* Hand-over of a resident vector between two contexts of one device, no copy and no cross-context lock: the owner detaches
+ * (its stream is drained first; the handle dies, a process-wide token is returned), the new owner attaches (new handle).  A
+ * loader context with its own stream and host thread uploads the next request's columns while the proving context is inside
+ * zk_prove.  A detached vector belongs to nobody until it is attached (ZK_EINVAL: unknown token, or another device). */
+int zk_poly_detach(zk_ctx* ctx, zk_poly p, uint64_t* token);
+int zk_poly_attach(zk_ctx* ctx, uint64_t token, zk_poly* out);
 int zk_poly_len(zk_ctx* ctx, zk_poly p, size_t* out);
 int zk_poly_upload(zk_ctx* ctx, zk_poly p, const uint64_t* host_mont, size_t n);
 int zk_poly_download(zk_ctx* ctx, zk_poly p, uint64_t* host_mont, size_t n);

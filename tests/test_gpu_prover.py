@@ -595,3 +595,61 @@ def test_shared_srs_contexts():
         second.prove(pk, polys, b"\x09" * 32, E.ZK_TRANSCRIPT_EVM)  # the key was made under the SRS the context let go of
     second.close()
     third.close()
+
+
+@pytest.mark.gpu
+def test_poly_detach_attach_and_staged_loading():
+    """zk_poly_detach / zk_poly_attach: a loader context uploads columns on its own stream and hands them to the proving
+    context (no copy, new handle, the old one is gone); a proof from handed-over columns is byte-identical to one from columns loaded directly —
+    also when a loader thread stages the next job while the pipeline proves the current one."""
+    import threading
+    from webauthn_halo2_amd import batch
+    A, L, F, k, lb = SHAPES["k10batched"][:5]
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+    asg = zk.circuit.synthesize(p, 0x5EED0019)
+    fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+    pl = batch.Pipeline(0, p, fixed, asg.copies, deterministic_seeds=True)
+    wit = {}
+    for j in range(6):
+        cols = [asg.to_limbs(c).copy() for c in asg.advice]
+        wit[j] = cols
+    # jobs differ through their seeds (job_rng_seed) — and in one cell-free way: identical columns, distinct blinding
+    want = {}
+    for j in wit:
+        pl.load(j, wit[j])
+        want[j] = pl.prove(j, E.ZK_TRANSCRIPT_BLAKE2B)
+        pl.unload(j)
+    # a detached vector is unknown to the loader, attaches once, and only on its device
+    ld = pl.loader()
+    h = ld.poly(1 << k)
+    ld.upload_canonical(h, wit[0][0])
+    old = h.h
+    d = ld.poly_detach(h)
+    assert h.h == 0
+    assert ld.L.zk_poly_free(ld.ctx, old) != 0
+    got = pl.eng.poly_attach(d)
+    with pytest.raises(zk.ZkError):
+        pl.eng.poly_attach(d)
+    direct = pl.eng.poly(1 << k)
+    pl.eng.upload_canonical(direct, wit[0][0])
+    assert np.array_equal(pl.eng.download(got), pl.eng.download(direct))
+    got.free()
+    direct.free()
+    pl.adopt(0, pl.stage(wit[0]))
+    assert pl.prove(0, E.ZK_TRANSCRIPT_BLAKE2B) == want[0]
+    # overlapped: a thread stages job i+1 while job i is proved
+    import queue
+    q = queue.Queue(maxsize=2)
+
+    def load():
+        for j in wit:
+            q.put((j, pl.stage(wit[j])))
+
+    t = threading.Thread(target=load)
+    t.start()
+    for _ in wit:
+        j, polys = q.get()
+        pl.adopt(j, polys)
+        assert pl.prove(j, E.ZK_TRANSCRIPT_BLAKE2B) == want[j]
+    t.join()
+    pl.close()

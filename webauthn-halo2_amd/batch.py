@@ -80,6 +80,7 @@ class Pipeline:
         share_srs_with: another Pipeline on the same device whose resident SRS and window tables this one uses too
         (zk_ctx_create_shared) — the further pipelines of a GPU need no copy of their own."""
         self.params = params
+        self.device = device
         self.deterministic_seeds = deterministic_seeds
         if share_srs_with is not None:
             self.eng = Engine(device, share_with=share_srs_with.eng)
@@ -101,6 +102,30 @@ class Pipeline:
             polys.append(h)
         self.resident[job] = polys
 
+    def loader(self):
+        """A loader context beside this pipeline (shared SRS, own stream): `stage` uploads a job's columns on it — from another
+        host thread, while this pipeline proves — and `adopt` hands them over between two proofs."""
+        if getattr(self, "_loader", None) is None:
+            self._loader = Engine(self.device, share_with=self.eng)
+        return self._loader
+
+    def stage(self, columns):
+        """Upload + convert a job's advice columns on the loader context and detach them (thread-safe against `prove`: the
+        loader context has its own lock and stream) -> staged columns for `adopt`."""
+        ld = self.loader()
+        n = 1 << self.params.degree
+        staged = []
+        for col in columns:
+            h = ld.poly(n)
+            ld.upload_canonical(h, col)
+            staged.append(ld.poly_detach(h))
+        return staged
+
+    def adopt(self, job, staged):
+        """Make staged columns this pipeline's resident advice of `job` (no copy)."""
+        self.unload(job)
+        self.resident[job] = [self.eng.poly_attach(d) for d in staged]
+
     def prove(self, job, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False, rng_seed=None):
         if rng_seed is None:
             rng_seed = job_rng_seed(job) if self.deterministic_seeds else os.urandom(32)
@@ -116,6 +141,8 @@ class Pipeline:
     def close(self):
         for job in list(self.resident):
             self.unload(job)
+        if getattr(self, "_loader", None) is not None:
+            self._loader.close()
         self.eng.close()
 
 

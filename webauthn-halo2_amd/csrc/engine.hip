@@ -776,6 +776,54 @@ ZK_API(zk_poly_free, (zk_ctx* c, zk_poly h), (c, h)) {
     return ZK_OK;
 }
 
+// Handing a resident vector from one context to another of the same device, without a copy and without either context
+// waiting on the other's lock: the owner detaches it (the record leaves the context for a process-wide table), the new owner
+// attaches it.  A loader context (its own stream and host thread, e.g. one made with zk_ctx_create_shared) can thus upload
+// and convert the next request's advice columns while the proving context is inside zk_prove, and the prover's thread picks
+// them up between two proofs.
+namespace {
+struct Detached {
+    PolyRec rec;
+    int device;
+};
+std::mutex g_detached_mu;
+std::map<uint64_t, Detached> g_detached;
+uint64_t g_detached_next = 1;
+}  // namespace
+
+ZK_API(zk_poly_detach, (zk_ctx* c, zk_poly h, uint64_t* token), (c, h, token)) {
+    if (!c || !token) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // whatever this context still does with the vector finishes first
+    const Detached d{*r, c->device};
+    c->polys.erase(h);
+    std::lock_guard<std::mutex> lg(g_detached_mu);
+    *token = g_detached_next++;
+    g_detached[*token] = d;
+    return ZK_OK;
+}
+
+ZK_API(zk_poly_attach, (zk_ctx* c, uint64_t token, zk_poly* out), (c, token, out)) {
+    if (!c || !out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    Detached d;
+    {
+        std::lock_guard<std::mutex> lg(g_detached_mu);
+        auto it = g_detached.find(token);
+        if (it == g_detached.end() || it->second.device != c->device) return ZK_EINVAL;
+        d = it->second;
+        g_detached.erase(it);
+    }
+    const uint64_t nh = c->next_handle++;
+    c->polys[nh] = d.rec;
+    *out = nh;
+    return ZK_OK;
+}
+
 ZK_API(zk_poly_len, (zk_ctx* c, zk_poly h, size_t* out), (c, h, out)) {
     if (!c || !out) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);

@@ -74,6 +74,8 @@ def load_library():
         "zk_srs_msm_plan": ([vp, ctypes.POINTER(u32), ctypes.POINTER(u32)], ctypes.c_int),
         "zk_poly_alloc": ([vp, sz, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_poly_free": ([vp, ctypes.c_uint64], ctypes.c_int),
+        "zk_poly_detach": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_poly_attach": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_poly_len": ([vp, ctypes.c_uint64, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_poly_upload": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
         "zk_poly_download": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
@@ -315,6 +317,20 @@ class Engine:
         out = np.zeros(4, dtype=np.uint64)
         self._chk(self.L.zk_eval(self.ctx, p.h, _p(x), _p(out)), "zk_eval")
         return out
+
+    def poly_detach(self, p):
+        """Take a resident vector out of this engine for another one on the same device -> (token, n); see poly_attach."""
+        t = ctypes.c_uint64()
+        self._chk(self.L.zk_poly_detach(self.ctx, p.h, ctypes.byref(t)), "zk_poly_detach")
+        p.h = 0
+        return t.value, p.n
+
+    def poly_attach(self, detached):
+        """Adopt a vector another engine detached (no copy) -> Poly of this engine."""
+        token, n = detached
+        h = ctypes.c_uint64()
+        self._chk(self.L.zk_poly_attach(self.ctx, token, ctypes.byref(h)), "zk_poly_attach")
+        return Poly(self, h.value, n)
 
     def kate_division(self, p, z_mont, q=None):
         """arithmetic::kate_division: q = (p - p(z)) / (X - z), same length as p (top coefficient 0); in place by default."""
