@@ -59,8 +59,12 @@ def test_wide_commit_matches_tau_oracle(windowed, bits, k):
     # takes the escape of the lanes' bucket tracking (distance field saturated / first bucket of a bin)
     vals = [1, 40000, (3 << 16) | 7, (12345 << 32) | (65535 << 16) | 200, (1 << 253) | (9 << 128), F.R - 2]
     sparse = cops.fr_mont([vals[pr.randrange(len(vals))] if pr.random() < 0.7 else 0 for _ in range(n)])
-    polys = [eng.poly(n, c) for c in cols[:3]] + [eng.poly(n, mixm), eng.poly(n, boolc), eng.poly(n, top), eng.poly(n, sparse)]
-    data = cols[:3] + [mixm, boolc, top, sparse]
+    # every digit of every scalar the same: ALL 16 n entries of the column in one bucket (one bin, one bucket, every
+    # accumulation lane a slot of it, thousands of parts); and the digit 0x8000 throughout (-2^15 with a carry into every window)
+    ones = cops.fr_mont([sum(1 << (bits * w) for w in range(250 // bits))] * n)
+    halves = cops.fr_mont([sum((1 << (bits - 1)) << (bits * w) for w in range(250 // bits))] * n)
+    polys = [eng.poly(n, c) for c in cols[:3]] + [eng.poly(n, x) for x in (mixm, boolc, top, sparse, ones, halves)]
+    data = cols[:3] + [mixm, boolc, top, sparse, ones, halves]
     want = [tau_commit(d) for d in data]
     for j, p in enumerate(polys):
         got = cops.affine_arr_to_ints(eng.commit(p, 0))[0]
