@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <unordered_map>
 #include <vector>
 
 #include "pk.h"
@@ -86,6 +87,21 @@ std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& pts, const std::vect
         for (size_t t = 0; t < m; t++) coeffs[t] = fe_add(coeffs[t], fe_mul(num[t], sc));
     }
     return coeffs;
+}
+
+// The Lagrange basis over `pts` as coefficient vectors: basis[j] = L_j(X).  A rotation set's commitments share their points,
+// so the denominators' inversions are paid once per set and a commitment's interpolant is sum_j eval_j L_j (m^2 products) —
+// the same field elements lagrange_interpolate computes, hence the same bytes.
+std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& pts) {
+    const size_t m = pts.size();
+    std::vector<Fr> ones(m, Fr::zero());
+    std::vector<std::vector<Fr>> basis(m);
+    for (size_t j = 0; j < m; j++) {
+        std::fill(ones.begin(), ones.end(), Fr::zero());
+        ones[j] = Fr::one();
+        basis[j] = lagrange_interpolate(pts, ones);
+    }
+    return basis;
 }
 
 Fr eval_small(const std::vector<Fr>& c, const Fr& x) {
@@ -1240,18 +1256,39 @@ struct Prover {
             std::vector<Fr> evals;
         };
         std::vector<CR> com;
-        for (auto& qq : queries) {
-            CR* hit = nullptr;
-            for (auto& cr : com)
-                if (cr.poly == qq.poly) hit = &cr;
-            if (!hit) {
-                com.push_back(CR{qq.poly, {}, {}});
-                hit = &com.back();
+        {
+            std::unordered_map<const Fr*, size_t> seen;  // wide circuits open hundreds of polynomials: no linear searches here
+            seen.reserve(queries.size());
+            for (auto& qq : queries) {
+                auto it = seen.find(qq.poly);
+                if (it == seen.end()) {
+                    it = seen.emplace(qq.poly, com.size()).first;
+                    com.push_back(CR{qq.poly, {}, {}});
+                }
+                com[it->second].rots.push_back(qq.rot);
+                com[it->second].evals.push_back(qq.eval);
             }
-            hit->rots.push_back(qq.rot);
-            hit->evals.push_back(qq.eval);
         }
-        auto pt_less = [&](int ra, int rb) { return fr_less(xrot(x, ra), xrot(x, rb)); };
+        // the points, once per distinct rotation: x w^rot and its canonical image (BTreeSet<Fr> orders by the integer value)
+        struct RotPt {
+            int rot;
+            Fr pt, canon;
+        };
+        std::vector<RotPt> rot_pts;
+        auto rot_pt = [&](int r) -> const RotPt& {
+            for (auto& e : rot_pts)
+                if (e.rot == r) return e;
+            const Fr pt = xrot(x, r);
+            rot_pts.push_back(RotPt{r, pt, fe_from_mont(pt)});
+            return rot_pts.back();
+        };
+        for (auto& qq : queries) rot_pt(qq.rot);  // filled before any reference into rot_pts is held
+        auto pt_less = [&](int ra, int rb) {
+            const Fr &a = rot_pt(ra).canon, &b = rot_pt(rb).canon;
+            for (int i = 7; i >= 0; i--)
+                if (a.v[i] != b.v[i]) return a.v[i] < b.v[i];
+            return false;
+        };
         struct RS {
             std::vector<int> rots;  // sorted by point value (BTreeSet<Fr>)
             std::vector<CR*> coms;
@@ -1297,12 +1334,16 @@ struct Prover {
         for (size_t si = 0; si < rsets.size(); si++) {
             auto& rs = rsets[si];
             std::vector<Fr> pts;
-            for (int r : rs.rots) pts.push_back(xrot(x, r));
+            for (int r : rs.rots) pts.push_back(rot_pt(r).pt);
+            const std::vector<std::vector<Fr>> basis = lagrange_basis(pts);
             std::vector<Term> terms;
             std::vector<Fr> rsum(pts.size(), Fr::zero());
             Fr py = Fr::one();
             for (CR* cr : rs.coms) {
-                low[com_index(cr)] = lagrange_interpolate(pts, cr->evals);
+                std::vector<Fr>& lo = low[com_index(cr)];
+                lo.assign(pts.size(), Fr::zero());
+                for (size_t j = 0; j < pts.size(); j++)
+                    for (size_t t = 0; t < pts.size(); t++) lo[t] = fe_add(lo[t], fe_mul(basis[j][t], cr->evals[j]));
                 terms.push_back(Term{cr->poly, py});
                 for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
                 py = fe_mul(py, yc);
@@ -1345,7 +1386,7 @@ struct Prover {
         for (auto& rs : rsets) {
             std::vector<Fr> diffs;
             for (int r : all_rots)
-                if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(xrot(x, r));
+                if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(rot_pt(r).pt);
             const Fr zi = vanishing_eval(diffs, u);
             z_diffs.push_back(zi);
             Fr py = Fr::one();
@@ -1358,7 +1399,7 @@ struct Prover {
             pv = fe_mul(pv, v);
         }
         std::vector<Fr> all_pts;
-        for (int r : all_rots) all_pts.push_back(xrot(x, r));
+        for (int r : all_rots) all_pts.push_back(rot_pt(r).pt);
         const Fr zt = vanishing_eval(all_pts, u);
         terms.push_back(Term{hx, fe_neg(zt)});
         lincomb_many(pk->t_a, terms, true, sub);
