@@ -35,7 +35,7 @@ int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
 
 // ---- MSM (msm.hip) ---------------------------------------------------------
 struct MsmWorkspace;  // opaque, sized for a maximum n and a maximum number of columns per launch
-static constexpr uint32_t MSM_MAX_BATCH = 64;
+static constexpr uint32_t MSM_MAX_BATCH = 256;
 MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, uint32_t max_batch = 1);
 void msm_workspace_destroy(MsmWorkspace* ws);
 uint32_t msm_auto_window(size_t n, uint32_t override_c = 0);  // fixed-base mode (the resident SRS's window tables)
