@@ -79,6 +79,7 @@ struct QuotientArgs {
     Fr t_inv[4];                  // 1 / ((zeta w_ext^i)^n - 1), period 4, standard form; all 1 when divide == 0
     uint32_t divide, n_terms;     // divide: multiply by t_inv (divide_by_vanishing_poly); 0: the bare numerator of evaluate_h
     Fr* out;
+    Fr delta_chunk[MAX_CHUNKS];   // 32 delta^(c chunk_len): where chunk c's column factors start (the sliced kernel)
     Fr ypow[MAX_TERMS];           // 32 y^(T-1-j) for term j of the y-combination, T = n_terms
 };
 // terms of the y-combination: gates, 2 + (chunks - 1) + chunks permutation terms, 5 per lookup
@@ -140,7 +141,8 @@ uint32_t kate_division_scratch(uint32_t n);  // elements of scratch per division
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* scratch, hipStream_t st);
 void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, uint32_t count, uint32_t n, Fr* scratch,
                                 hipStream_t st);
-void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st);
+void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, uint32_t log_slices, hipStream_t st);
+uint32_t quotient_log_slices(uint32_t log_ext, uint32_t n_gate);
 
 // poly.hip
 struct EvalItem {

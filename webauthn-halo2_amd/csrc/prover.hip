@@ -500,11 +500,20 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
         yp = fe_mul(yp, y);
     }
     q.out = out;
+    const uint32_t log_slices = quotient_log_slices(lay.ext_k, lay.n_gate);
+    if (log_slices) {
+        const Fr dstep = fe_pow_u64(fr_delta(), lay.chunk_len);
+        Fr dc = k32;
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+            q.delta_chunk[ci] = dc;
+            dc = fe_mul(dc, dstep);
+        }
+    }
     hipStream_t st = c->stream;
     hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
     const size_t bytes = sizeof(q) - sizeof(q.ypow) + (size_t)q.n_terms * sizeof(Fr);
     if (hipMemcpyAsync(pk->d_qargs, &q, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
-    launch_quotient_dev(pk->d_qargs, lay.ext_k, st);
+    launch_quotient_dev(pk->d_qargs, lay.ext_k, log_slices, st);
     hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
     c->ev_valid[ZK_T_QUOTIENT] = true;
     return ZK_OK;

@@ -45,60 +45,63 @@ __device__ __forceinline__ void q_acc(Fr29& sum, uint32_t& cnt, const Fr29& term
     }
 }
 
-__global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __restrict__ ap) {
-    const QuotientArgs& a = *ap;
+// One row's share of the y-combination: slice `sl` of `ns` takes the gates, permutation chunks and lookups whose index is
+// sl mod ns (every group sum is linear in its terms, so the slices' results simply add up).  Returns
+// acc + l_0 s0 + l_last sl + l_active sa of the share: (<= 108 ; normalised).  SLICED = false is the whole row (sl = 0, ns = 1).
+template <bool SLICED>
+__device__ __forceinline__ Fr29 quotient_row(const QuotientArgs& a, uint32_t i, uint32_t sl, uint32_t ns) {
     const uint32_t N = 1u << a.log_ext;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
     const uint32_t mask = N - 1;
     auto rot = [&](int r) { return (i + (uint32_t)(r * 4)) & mask; };  // two's complement wraps correctly mod N
 
     const Fr29 beta = to29(a.beta), gamma = to29(a.gamma);  // (1 ; 29): the host passes 32 x the challenge (internal form)
     const Fr29 one = const_pow2_29<261, FrParams>();
     const Fr* __restrict__ yp = a.ypow;
-    uint32_t term = 0;
     Fr29 zero;
 #pragma unroll
     for (int l = 0; l < 9; l++) zero.l[l] = 0;
-    Fr29 acc = zero, s0 = zero, sl = zero, sa = zero;  // gate terms; l_0 terms; l_last terms; active-row terms
+    Fr29 acc = zero, s0 = zero, sl_ = zero, sa = zero;  // gate terms; l_0 terms; l_last terms; active-row terms
     uint32_t nacc = 0, n0 = 0, nl = 0, na = 0;
-    // e: limbs < 2^31.4, value bound <= 168 -> e * y^(..) < 2p
-    auto add_to = [&](Fr29& sum, uint32_t& cnt, const Fr29& e) { q_acc(sum, cnt, mul29(e, to29(yp[term++]))); };
+    // e: limbs < 2^31.4, value bound <= 168 -> e * y^(..) < 2p.  `term` = the term's place in halo2's order
+    auto add_to = [&](Fr29& sum, uint32_t& cnt, const Fr29& e, uint32_t term) { q_acc(sum, cnt, mul29(e, to29(yp[term]))); };
 
-    // ---- gates
-    for (uint32_t j = 0; j < a.n_gate; j++) {
-        if (a.fx_sel[j] == NO_SELECTOR) {  // never-enabled gate: contributes 0 but keeps its power of y
-            term++;
-            continue;
-        }
+    // ---- gates: term j
+    for (uint32_t j = sl; j < a.n_gate; j += ns) {
+        if (a.fx_sel[j] == NO_SELECTOR) continue;  // never-enabled gate: contributes 0 but keeps its power of y
         const Fr* c = a.adv[j];
         const Fr29 a0 = q_load(c + i), a1 = q_load(c + rot(1)), a2 = q_load(c + rot(2)), a3 = q_load(c + rot(3));
         const Fr29 q = q_load(a.fix[a.fx_sel[j]] + i);
         const Fr29 m = mul29(a1, a2);                        // 32 * 32 = 1024: (8 ; 29)
         const Fr29 w = sub29<33, 29>(add29(a0, m), a3);      // (40 ; 30) - (32 ; 29): (73 ; 31.3)
         const Fr29 g = mul29(q, w);                          // 32 * 73 = 2336: (15 ; 29)
-        add_to(acc, nacc, g);
+        add_to(acc, nacc, g, j);
     }
 
-    // ---- permutation
+    // ---- permutation: terms n_gate (l0 (1 - z0)), + 1 (l_last ..), + 2 .. (chunk links), then one per chunk
     {
-        const Fr29 z0 = q_load(a.z[0] + i);
-        add_to(s0, n0, sub29<33, 29>(one, z0));              // (34 ; 31)
-        const Fr29 zl = q_load(a.z[a.n_chunks - 1] + i);
-        add_to(sl, nl, sub29<33, 29>(sqr29(zl), zl));        // (8 ; 29) - (32 ; 29): (41 ; 31)
-        for (uint32_t c = 1; c < a.n_chunks; c++) {
+        const uint32_t t_perm = a.n_gate;
+        const uint32_t t_link = t_perm + 2, t_prod = t_link + (a.n_chunks - 1);
+        if (sl == 0) {
+            const Fr29 z0 = q_load(a.z[0] + i);
+            add_to(s0, n0, sub29<33, 29>(one, z0), t_perm);              // (34 ; 31)
+            const Fr29 zl = q_load(a.z[a.n_chunks - 1] + i);
+            add_to(sl_, nl, sub29<33, 29>(sqr29(zl), zl), t_perm + 1);   // (8 ; 29) - (32 ; 29): (41 ; 31)
+        }
+        for (uint32_t c = SLICED ? (sl ? sl : ns) : 1; c < a.n_chunks; c += ns) {
             const Fr29 zc = q_load(a.z[c] + i);
             const Fr29 zp = q_load(a.z[c - 1] + rot(a.last_rot));
-            add_to(s0, n0, sub29<33, 29>(zc, zp));           // (65 ; 31)
+            add_to(s0, n0, sub29<33, 29>(zc, zp), t_link + c - 1);       // (65 ; 31)
         }
         // beta * x with x = zeta * w_ext^i (resident vector), then times delta per column
         const Fr29 delta = to29(a.delta);
-        Fr29 bx = mul29(q_load(a.xs + i), beta);             // (2 ; 29)
-        for (uint32_t c = 0; c < a.n_chunks; c++) {
+        const Fr29 bx0 = mul29(q_load(a.xs + i), beta);      // (2 ; 29)
+        Fr29 bx = bx0;
+        for (uint32_t c = sl; c < a.n_chunks; c += ns) {
             Fr29 left = q_load(a.z[c] + rot(1));             // (32 ; 29), then <= (8 ; 29)
             Fr29 right = q_load(a.z[c] + i);
             const uint32_t lo = c * a.chunk_len;
             const uint32_t hi = min(a.n_perm, lo + a.chunk_len);
+            if (SLICED) bx = mul29(bx0, to29(a.delta_chunk[c]));  // beta x delta^lo: (2 ; 29)
             for (uint32_t p = lo; p < hi; p++) {
                 const Fr29 vg = add29(q_load(a.perm_val[p] + i), gamma);              // (33 ; 30)
                 const Fr29 bs = mul29(beta, q_load(a.sigma[p] + i));                  // (2 ; 29)
@@ -106,12 +109,14 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __res
                 right = mul29(right, add29(vg, bx));
                 if (p + 1 < a.n_perm) bx = mul29(bx, delta);  // (2 ; 29)
             }
-            add_to(sa, na, sub29<9, 29>(left, right));       // (17 ; 31)
+            add_to(sa, na, sub29<9, 29>(left, right), t_prod + c);       // (17 ; 31)
         }
     }
 
-    // ---- lookups
-    for (uint32_t l = 0; l < a.n_lookups; l++) {
+    // ---- lookups: five terms each
+    const uint32_t t_lk = a.n_gate + 2 + (a.n_chunks - 1) + a.n_chunks;
+    for (uint32_t l = sl; l < a.n_lookups; l += ns) {
+        const uint32_t t = t_lk + 5 * l;
         const Fr29 z = q_load(a.lk_z[l] + i), zn = q_load(a.lk_z[l] + rot(1));
         const Fr29 pa = q_load(a.lk_a[l] + i), pam = q_load(a.lk_a[l] + rot(-1));
         const Fr29 ps = q_load(a.lk_s[l] + i);
@@ -119,31 +124,81 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __res
         if (a.single) inp = mul29(q_load(a.fix[a.fx_qlookup] + i), q_load(a.adv[0] + i));  // (8 ; 29)
         else inp = q_load(a.lk_in[l] + i);                                                   // (32 ; 29)
         const Fr29 tab = q_load(a.fix[a.fx_table] + i);
-        add_to(s0, n0, sub29<33, 29>(one, z));
-        add_to(sl, nl, sub29<33, 29>(sqr29(z), z));
+        add_to(s0, n0, sub29<33, 29>(one, z), t);
+        add_to(sl_, nl, sub29<33, 29>(sqr29(z), z), t + 1);
         const Fr29 left = mul29(mul29(zn, add29(pa, beta)), add29(ps, gamma));     // 32 * 33: (8 ; 29); 8 * 33: (3 ; 29)
         const Fr29 right = mul29(mul29(z, add29(inp, beta)), add29(tab, gamma));
-        add_to(sa, na, sub29<4, 29>(left, right));           // (7 ; 31)
+        add_to(sa, na, sub29<4, 29>(left, right), t + 2);    // (7 ; 31)
         const Fr29 d = sub29<33, 29>(pa, ps);                // (65 ; 31.3)
-        add_to(s0, n0, d);
+        add_to(s0, n0, d, t + 3);
         const Fr29 dd = mul29(norm29(d), sub29<33, 29>(pa, pam));  // 65 * 65 = 4225: (26 ; 29)
-        add_to(sa, na, dd);
+        add_to(sa, na, dd, t + 4);
     }
 
     // sums are (<= 66 ; normalised): each times its multiplier (32) is < 14 p
     const Fr29 t0 = mul29(s0, q_load(a.l0 + i));
-    const Fr29 t1 = mul29(sl, q_load(a.l_last + i));
+    const Fr29 t1 = mul29(sl_, q_load(a.l_last + i));
     const Fr29 t2 = mul29(sa, q_load(a.l_active + i));
-    const Fr29 total = norm29(add29(add29(acc, t0), add29(t1, t2)));  // 66 + 3 * 14 = 108 <= 168
+    return norm29(add29(add29(acc, t0), add29(t1, t2)));  // 66 + 3 * 14 = 108 <= 168
+}
+
+__global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __restrict__ ap) {
+    const QuotientArgs& a = *ap;
+    const uint32_t N = 1u << a.log_ext;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const Fr29 total = quotient_row<false>(a, i, 0, 1);
     // times 1/(X^n - 1) (or 1) in the standard form: the product is the standard form of the result, < 2p
     Fr r = from29(mul29(total, to29(a.t_inv[i & 3])));
     reduce_once(r);
     fe_store(a.out + i, r);
 }
+
+// The many-column shapes (k <= 14: hundreds of gates and lookups over a few thousand rows) have too few rows to fill the chip
+// with one lane per row: 2^log_ns lanes share a row, each takes every 2^log_ns-th gate / chunk / lookup, and the shares are
+// added through LDS (each first brought below 2p by a product with "one").  Lanes of a workgroup: row-major within a slice.
+__global__ __launch_bounds__(256) void quotient_sliced_kernel(const QuotientArgs* __restrict__ ap, uint32_t log_ns) {
+    __shared__ uint32_t part[256 * 9];
+    const QuotientArgs& a = *ap;
+    const uint32_t ns = 1u << log_ns, rows = 256u >> log_ns;
+    const uint32_t row = threadIdx.x & (rows - 1), sl = threadIdx.x >> (8 - log_ns);
+    const uint32_t i = blockIdx.x * rows + row;  // N is a multiple of 256: no partial workgroups
+    const Fr29 share = mul29(quotient_row<true>(a, i, sl, ns), const_pow2_29<261, FrParams>());  // (2 ; 29)
+#pragma unroll
+    for (int l = 0; l < 9; l++) part[l * 256 + threadIdx.x] = share.l[l];
+    __syncthreads();
+    if (sl) return;
+    Fr29 total = share;
+    for (uint32_t s = 1; s < ns; s++) {
+        Fr29 v;
+#pragma unroll
+        for (int l = 0; l < 9; l++) v.l[l] = part[l * 256 + s * rows + row];
+        total = norm29(add29(total, v));  // <= 2 * 16 p
+    }
+    Fr r = from29(mul29(total, to29(a.t_inv[i & 3])));
+    reduce_once(r);
+    fe_store(a.out + i, r);
+}
+
 // `d_args` is the argument block in device memory (too large for a kernarg segment)
-void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, hipStream_t st) {
+// `log_slices`: lanes per row (quotient_log_slices); 0 = one lane per row
+void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, uint32_t log_slices, hipStream_t st) {
     const uint32_t N = 1u << log_ext;
-    hipLaunchKernelGGL(quotient_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d_args);
+    if (log_slices == 0 || N < 256) {
+        hipLaunchKernelGGL(quotient_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d_args);
+    } else {
+        hipLaunchKernelGGL(quotient_sliced_kernel, dim3(N >> (8 - log_slices)), dim3(256), 0, st, d_args, log_slices);
+    }
+}
+
+// lanes per row: enough for ~2^16 lanes in all (measured with whole proofs, tools/quot_ab.sh: k = 11 15.2 -> 13.2 ms, k = 12 10.1 -> 9.2, k = 13 7.8 -> 7.3), at most 16, and not more than there are gates to share out
+uint32_t quotient_log_slices(uint32_t log_ext, uint32_t n_gate) {
+    uint32_t ls = 0;
+#ifndef ZK_QUOT_LANES_LOG
+#define ZK_QUOT_LANES_LOG 16
+#endif
+    while (ls < 4 && log_ext + ls < ZK_QUOT_LANES_LOG && (2u << ls) <= n_gate) ls++;
+    return ls;
 }
 
 }  // namespace zk
