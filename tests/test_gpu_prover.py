@@ -28,6 +28,9 @@ SHAPES = {
     # more than 32 terms in every group of the quotient's y-combination (gate terms, l_0 terms, active-row terms): the
     # lazy sums of quotient.hip are folded back below 2p (the k <= 13 bench rows do that at full size)
     "manycols": (36, 12, 2, 7, 5),
+    # more than 40 polynomials in one rotation set over >= 256 rows: the multi-open's linear combinations go through the
+    # argument-list kernel (lincomb_terms), the quotient through the lanes-per-row kernel
+    "manycols_k8": (44, 6, 2, 8, 6),
 }
 KIND = {"evm": E.ZK_TRANSCRIPT_EVM, "blake2b": E.ZK_TRANSCRIPT_BLAKE2B}
 

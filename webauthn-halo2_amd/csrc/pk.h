@@ -103,6 +103,8 @@ struct zk_pk_rec {
     QuotientArgs* h_qargs = nullptr;  // pinned staging of the same
     EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
     uint32_t max_evals = 0;
+    LcTerm *d_lc_terms = nullptr, *h_lc_terms = nullptr;  // argument lists of the multi-open's long linear combinations
+    uint32_t lc_cap = 0, lc_used = 0;                     // slots, and how many this proof has used so far
     Fr *ev_scratch = nullptr, *ev_out = nullptr;
 };
 

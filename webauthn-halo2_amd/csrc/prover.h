@@ -31,6 +31,16 @@ struct LincombArgs {
     Fr c[MAX_LC];
 };
 
+// one input of a long linear combination whose argument list lives in device memory (launch_lincomb_terms)
+struct LcTerm {
+    const Fr* in;   // n coefficients
+    uint64_t pad_;
+    Fr c;
+};
+struct LcLow {
+    Fr v[8];
+};
+
 struct ChaChaKey {
     uint32_t w[8];
 };
@@ -90,6 +100,10 @@ static constexpr uint32_t quotient_terms(uint32_t n_gate, uint32_t n_chunks, uin
 void launch_to_mont(Fr* a, uint32_t n, hipStream_t st);
 void launch_mul(Fr* out, const Fr* a, const Fr* b, uint32_t n, hipStream_t st);
 void launch_lincomb(const LincombArgs& a, hipStream_t st);
+// out = sum_j terms[j].c * terms[j].in (- sub0_val on coefficient 0, - low[i] on the first low_n coefficients); `h_terms` is
+// pinned host memory the caller keeps intact until the stream has passed this point, `d_terms` its place in device memory
+void launch_lincomb_terms(LcTerm* h_terms, LcTerm* d_terms, uint32_t count, Fr* out, uint32_t n, bool sub0, const Fr& sub0_val,
+                          const Fr* low, uint32_t low_n, hipStream_t st);
 void launch_scale(Fr* a, const Fr& c, uint32_t n, hipStream_t st);
 void launch_chacha_fr(const ChaChaKey& key, uint64_t start_block, Fr* out, uint32_t count, hipStream_t st);
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t m, hipStream_t st);

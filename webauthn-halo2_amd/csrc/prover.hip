@@ -131,6 +131,8 @@ void pk_destroy(zk_pk_rec* pk) {
     if (pk->d_batch_args) hipFree(pk->d_batch_args);
     if (pk->h_batch_args) hipHostFree(pk->h_batch_args);
     if (pk->h_qargs) hipHostFree(pk->h_qargs);
+    if (pk->d_lc_terms) hipFree(pk->d_lc_terms);
+    if (pk->h_lc_terms) hipHostFree(pk->h_lc_terms);
     if (pk->d_evargs) hipFree(pk->d_evargs);
     if (pk->h_evargs) hipHostFree(pk->h_evargs);
     delete pk;
@@ -224,6 +226,10 @@ int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk) {
         return fail(ZK_ENOMEM);
     if (hipHostMalloc(&pk->h_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess ||
         hipMalloc(&pk->d_evargs, pk->max_evals * sizeof(EvalItem)) != hipSuccess)
+        return fail(ZK_ENOMEM);
+    pk->lc_cap = 2 * (pk->max_evals + 8);
+    if (hipHostMalloc(&pk->h_lc_terms, pk->lc_cap * sizeof(LcTerm)) != hipSuccess ||
+        hipMalloc(&pk->d_lc_terms, pk->lc_cap * sizeof(LcTerm)) != hipSuccess)
         return fail(ZK_ENOMEM);
     pk->ev_scratch = d.alloc((size_t)pk->max_evals * eval_blocks(n));
     pk->ev_out = d.alloc(pk->max_evals);
@@ -775,6 +781,16 @@ struct Prover {
     };
     void lincomb_many(Fr* out, const std::vector<Term>& terms, bool sub0, const Fr& sub0_val, bool accumulate_first = false,
                       const std::vector<Fr>* sub_low = nullptr) {
+        if (terms.size() > MAX_LC && !accumulate_first && n >= 256 && pk->lc_used + terms.size() <= pk->lc_cap) {
+            // hundreds of inputs: one launch over an argument list in device memory.  The list's slots are not reused within a
+            // proof (the copies are asynchronous; capacity: every opened polynomial twice, pk_alloc_workspace)
+            LcTerm* h = pk->h_lc_terms + pk->lc_used;
+            for (size_t j = 0; j < terms.size(); j++) h[j] = LcTerm{terms[j].poly, 0, terms[j].c};
+            launch_lincomb_terms(h, pk->d_lc_terms + pk->lc_used, (uint32_t)terms.size(), out, n, sub0, sub0_val,
+                                 sub_low ? sub_low->data() : nullptr, sub_low ? (uint32_t)sub_low->size() : 0u, st);
+            pk->lc_used += (uint32_t)terms.size();
+            return;
+        }
         size_t done = 0;
         bool first = !accumulate_first;
         do {
@@ -1210,6 +1226,7 @@ struct Prover {
         if (!ok()) return rc;
 
         // -- 8. multi-open
+        pk->lc_used = 0;
         return scheme == ZK_SCHEME_GWC ? open_gwc(queries, x, max_batch) : open_shplonk(queries, x);
     }
 

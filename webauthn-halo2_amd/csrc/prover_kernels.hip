@@ -82,6 +82,69 @@ void launch_lincomb(const LincombArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(lincomb_kernel, dim3((b.n + 255) / 256), dim3(256), 0, st, b);
 }
 
+// The same sum for hundreds of inputs (the many-column shapes open 350 polynomials of a few thousand coefficients each):
+// the argument list is read from device memory, 2^log_ns lanes share a coefficient — lane s takes terms s, s + ns, ... in
+// groups of four per reduction — and the shares are added through LDS.  One launch instead of one per 40 inputs.
+__global__ __launch_bounds__(256) void lincomb_terms_kernel(const LcTerm* __restrict__ terms, uint32_t count, Fr* __restrict__ out,
+                                                            uint32_t log_ns, uint32_t sub0, Fr sub0_val, uint32_t low_n, LcLow low) {
+    typedef Fe29<FrParams> Fr29;
+    __shared__ uint32_t part[256 * 9];
+    const uint32_t ns = 1u << log_ns, rows = 256u >> log_ns;
+    const uint32_t row = threadIdx.x & (rows - 1), sl = threadIdx.x >> (8 - log_ns);
+    const uint32_t i = blockIdx.x * rows + row;  // n is a multiple of 256
+    const Fr29 id = const_pow2_29<261, FrParams>();  // the identity of this product (see lincomb_kernel)
+    Fr29 acc;
+#pragma unroll
+    for (int l = 0; l < 9; l++) acc.l[l] = 0;
+    uint32_t j = sl, groups = 0;
+#pragma unroll 1
+    for (; j + 3 * ns < count; j += 4 * ns) {
+        const Fr29 v[4] = {to29(fe_load(terms[j].in + i)), to29(fe_load(terms[j + ns].in + i)),
+                           to29(fe_load(terms[j + 2 * ns].in + i)), to29(fe_load(terms[j + 3 * ns].in + i))};
+        const Fr29 c[4] = {to29(fe_load(&terms[j].c)), to29(fe_load(&terms[j + ns].c)), to29(fe_load(&terms[j + 2 * ns].c)),
+                           to29(fe_load(&terms[j + 3 * ns].c))};
+        acc = norm29(add29(acc, mulKadd29<4>(v, c)));  // + 2p
+        if (++groups == 64) {                          // uniform: the sum goes back below 2p
+            acc = mul29(acc, id);
+            groups = 0;
+        }
+    }
+#pragma unroll 1
+    for (; j < count; j += ns) acc = norm29(add29(acc, mul29(to29(fe_load(terms[j].in + i)), to29(fe_load(&terms[j].c)))));
+    const Fr29 share = mul29(acc, id);  // <= 136 p -> (2 ; 29)
+#pragma unroll
+    for (int l = 0; l < 9; l++) part[l * 256 + threadIdx.x] = share.l[l];
+    __syncthreads();
+    if (sl) return;
+    Fr29 total = share;
+    for (uint32_t s = 1; s < ns; s++) {
+        Fr29 v;
+#pragma unroll
+        for (int l = 0; l < 9; l++) v.l[l] = part[l * 256 + s * rows + row];
+        total = norm29(add29(total, v));  // <= 32 p
+    }
+    if (i == 0 && sub0) total = norm29(sub29<2, 29>(total, to29(sub0_val)));
+    if (i < low_n) total = norm29(sub29<2, 29>(total, to29(low.v[i])));
+    Fr r = from29(mul29(total, id));
+    reduce_once(r);
+    fe_store(out + i, r);
+}
+void launch_lincomb_terms(LcTerm* h_terms, LcTerm* d_terms, uint32_t count, Fr* out, uint32_t n, bool sub0, const Fr& sub0_val,
+                          const Fr* low, uint32_t low_n, hipStream_t st) {
+    const Fr k32 = fr_from_u64(32);
+    for (uint32_t j = 0; j < count; j++) h_terms[j].c = fe_mul(h_terms[j].c, k32);  // the kernel's products divide by 32
+    hipMemcpyAsync(d_terms, h_terms, (size_t)count * sizeof(LcTerm), hipMemcpyHostToDevice, st);
+    uint32_t lg = 0;
+    while ((1u << (lg + 1)) <= n) lg++;
+    uint32_t log_ns = 0;  // lanes per coefficient: ~2^16 lanes in all, at most 16, at least 8 terms each
+    while (log_ns < 4 && lg + log_ns < 16 && (count >> (log_ns + 1)) >= 8) log_ns++;
+    LcLow lw;
+    memset(&lw, 0, sizeof(lw));
+    for (uint32_t t = 0; t < low_n && t < 8; t++) lw.v[t] = low[t];
+    hipLaunchKernelGGL(lincomb_terms_kernel, dim3(n >> (8 - log_ns)), dim3(256), 0, st, d_terms, count, out, log_ns, sub0 ? 1u : 0u,
+                       sub0_val, low_n, lw);
+}
+
 __global__ void scale_kernel(Fr* a, Fr c, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) fe_store(a + i, fe_mul(fe_load(a + i), c));
