@@ -656,3 +656,47 @@ def test_poly_detach_attach_and_staged_loading():
         assert pl.prove(j, E.ZK_TRANSCRIPT_BLAKE2B) == want[j]
     t.join()
     pl.close()
+
+
+def _random_shapes(count, seed):
+    """Circuit shapes drawn at random (fixed seed): small enough for the plain-Python oracle, spread over everything the
+    engine branches on — one or many gate columns, 1 ... 8 lookups, idle gate columns, 6 <= k <= 9, 1 ... 3 constants columns."""
+    import random
+    pr = random.Random(seed)
+    shapes = []
+    while len(shapes) < count:
+        k = pr.choice([6, 7, 7, 8, 8, 9])
+        A = pr.choice([1, 2, 3, 5, 9, 17, 33, 45]) if k <= 8 else pr.choice([1, 2, 4, 9])
+        L = 1 if A == 1 else pr.choice([1, 2, 3, 8 if A >= 9 else 2])
+        F = pr.choice([1, 1, 2, 3])
+        lb = pr.randrange(3, k)            # lookup table of 2^lb rows inside the usable rows
+        idle = pr.choice([0, 0, 1, 2]) if A >= 3 else 0
+        if A - idle < 1:
+            continue
+        shapes.append((A, L, F, k, lb, idle))
+    return shapes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", _random_shapes(10, 0x5EED0305), ids=lambda s: "A%dL%dF%dk%dlb%di%d" % s)
+def test_random_shapes_byte_identical_to_oracle(engine, shape):
+    """Proof bytes of randomly drawn circuit shapes (both transcripts) against the plain-Python oracle: every structural
+    branch of the prover — column-batched passes, lanes-per-row quotient, argument-list combinations, chunk counts,
+    selector compression with idle gates — under shapes nobody tuned it for."""
+    A, L, F, k, lb, idle = shape
+    p, asg, pk, polys = setup(engine, A, L, F, k, lb, seed=0x5EED0000 + 131 * A + k, idle=idle)
+    sh = plonk.Shape(k, A, L, F, lb, idle)
+    opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
+    vk = product_vk(engine, pk, sh)
+    assert vk.fixed_commitments == opk.vk.fixed_commitments
+    assert vk.permutation_commitments == opk.vk.permutation_commitments
+    assert vk.transcript_repr == opk.vk.transcript_repr
+    seed = bytes([k, A & 255, L, F]) * 8
+    for kind in ("blake2b", "evm"):
+        got = engine.prove(pk, polys, seed, KIND[kind])
+        want = prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), kind)
+        assert got == want, (shape, kind)
+        assert plonk.verify(vk, got, kind)
+    for h in polys:
+        h.free()
+    engine.pk_free(pk)
