@@ -8,7 +8,7 @@ import pytest
 
 import webauthn_halo2_amd as zk
 from webauthn_halo2_amd import engine as E
-from zkoracle import cops, curve as C, fastprover as fp, field as F, plonk, serde, srs
+from zkoracle import cops, fastprover as fp, plonk, serde
 from zkoracle.hashes import ChaCha20Rng
 
 pytestmark = pytest.mark.gpu

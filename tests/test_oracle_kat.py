@@ -2,7 +2,6 @@
 and checks the C restatement against the Python one.  CPU only."""
 import random
 
-import numpy as np
 
 from zkoracle import cops, curve as C, field as F, srs
 

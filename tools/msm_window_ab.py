@@ -2,7 +2,7 @@
 scalar, 4096 buckets) against the wide path's 15 / 16 bits (17 / 16 additions, 16384 / 32768 buckets).  HIP-event
 time of the accumulate kernel alone and of the whole head, wall clock of the whole commit (head + reduction tail +
 host finish), for one column and for column batches; uniform scalars and the advice-column mix."""
-import os, random, sys, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import webauthn_halo2_amd as zk

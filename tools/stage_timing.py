@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import webauthn_halo2_amd as zk  # noqa: E402
-from webauthn_halo2_amd import batch, engine as E  # noqa: E402
+from webauthn_halo2_amd import batch  # noqa: E402
 
 
 def main():

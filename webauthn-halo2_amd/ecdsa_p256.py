@@ -31,7 +31,7 @@ import os
 import numpy as np
 
 from . import circuit
-from .engine import ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM, Engine, ZkError
+from .engine import ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM, Engine
 
 _STATE = {}  # (device) -> {"eng": Engine, "k": int, "keys": {path: (params, pk_handle)}}
 
