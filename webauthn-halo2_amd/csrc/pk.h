@@ -102,6 +102,8 @@ struct zk_pk_rec {
     QuotientArgs* d_qargs = nullptr;
     QuotientArgs* h_qargs = nullptr;  // pinned staging of the same
     EvalItem *d_evargs = nullptr, *h_evargs = nullptr;
+    Fr t_inv[4];               // 1 / ((zeta w_ext^i)^n - 1), i < 4 (pk_quotient)
+    bool t_inv_ready = false;
     uint32_t max_evals = 0;
     LcTerm *d_lc_terms = nullptr, *h_lc_terms = nullptr;  // argument lists of the multi-open's long linear combinations
     uint32_t lc_cap = 0, lc_used = 0;                     // slots, and how many this proof has used so far

@@ -26,6 +26,23 @@
 
 using namespace zk;
 
+#ifdef ZK_HOST_TRACE  // host-side stage stamps of the proof's last phases (experiments only: tools/ab_variants.sh ... "-DZK_HOST_TRACE")
+#include <chrono>
+#include <cstdio>
+static std::chrono::steady_clock::time_point& ht_last() {
+    static thread_local std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    return t;
+}
+#define HT(name)                                                                                                  \
+    do {                                                                                                          \
+        const auto ht_now = std::chrono::steady_clock::now();                                                     \
+        fprintf(stderr, "HT %-24s +%7.1f us\n", name, std::chrono::duration<double, std::micro>(ht_now - ht_last()).count()); \
+        ht_last() = ht_now;                                                                                       \
+    } while (0)
+#else
+#define HT(name) do { } while (0)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------- kernels ---
@@ -67,12 +84,16 @@ bool fr_less(const Fr& a_mont, const Fr& b_mont) {
     return false;
 }
 
-std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evals) {
+// The Lagrange basis over `pts` as coefficient vectors: basis[j] = L_j(X) = prod_{i != j} (X - pts_i) / (pts_j - pts_i).  A
+// rotation set's commitments share their points, so this is paid once per set — with ONE field inversion for all the
+// denominators — and a commitment's interpolant is sum_j eval_j L_j (m^2 products): the same field elements
+// halo2's lagrange_interpolate computes per commitment, hence the same bytes.
+std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& pts) {
     const size_t m = pts.size();
-    std::vector<Fr> coeffs(m, Fr::zero());
+    std::vector<std::vector<Fr>> basis(m);
+    std::vector<Fr> den(m, Fr::one()), pre(m);
     for (size_t j = 0; j < m; j++) {
         std::vector<Fr> num(1, Fr::one());
-        Fr den = Fr::one();
         for (size_t i = 0; i < m; i++) {
             if (i == j) continue;
             std::vector<Fr> nn(num.size() + 1, Fr::zero());
@@ -81,25 +102,21 @@ std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& pts, const std::vect
                 nn[t] = fe_sub(nn[t], fe_mul(pts[i], num[t]));
             }
             num.swap(nn);
-            den = fe_mul(den, fe_sub(pts[j], pts[i]));
+            den[j] = fe_mul(den[j], fe_sub(pts[j], pts[i]));
         }
-        const Fr sc = fe_mul(evals[j], fe_inv(den));
-        for (size_t t = 0; t < m; t++) coeffs[t] = fe_add(coeffs[t], fe_mul(num[t], sc));
+        basis[j] = num;
     }
-    return coeffs;
-}
-
-// The Lagrange basis over `pts` as coefficient vectors: basis[j] = L_j(X).  A rotation set's commitments share their points,
-// so the denominators' inversions are paid once per set and a commitment's interpolant is sum_j eval_j L_j (m^2 products) —
-// the same field elements lagrange_interpolate computes, hence the same bytes.
-std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& pts) {
-    const size_t m = pts.size();
-    std::vector<Fr> ones(m, Fr::zero());
-    std::vector<std::vector<Fr>> basis(m);
+    // all 1 / den_j from one inversion (distinct points: no denominator is zero)
+    Fr run = Fr::one();
     for (size_t j = 0; j < m; j++) {
-        std::fill(ones.begin(), ones.end(), Fr::zero());
-        ones[j] = Fr::one();
-        basis[j] = lagrange_interpolate(pts, ones);
+        pre[j] = run;
+        run = fe_mul(run, den[j]);
+    }
+    Fr inv = fe_inv(run);
+    for (size_t j = m; j-- > 0;) {
+        const Fr dj = fe_mul(inv, pre[j]);
+        inv = fe_mul(inv, den[j]);
+        for (Fr& cf : basis[j]) cf = fe_mul(cf, dj);
     }
     return basis;
 }
@@ -492,11 +509,16 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
     // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
     const Fr zn = fe_pow_u64(c->zeta, lay.n);
     const Fr w4 = fe_pow_u64(fr_omega(lay.ext_k), lay.n);
-    Fr cur = zn;
-    for (int i = 0; i < 4; i++) {  // standard form: the product by it also converts the row back (quotient.hip); 1 = no division
-        q.t_inv[i] = divide ? fe_inv(fe_sub(cur, Fr::one())) : Fr::one();
-        cur = fe_mul(cur, w4);
+    if (!pk->t_inv_ready) {  // constants of the key's domain: inverted once, not once per proof
+        Fr cur = zn;
+        for (int i = 0; i < 4; i++) {
+            pk->t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
+            cur = fe_mul(cur, w4);
+        }
+        pk->t_inv_ready = true;
     }
+    // standard form: the product by it also converts the row back (quotient.hip); 1 = no division
+    for (int i = 0; i < 4; i++) q.t_inv[i] = divide ? pk->t_inv[i] : Fr::one();
     q.divide = divide ? 1 : 0;
     q.n_terms = quotient_terms(lay.n_gate, lay.n_chunks, lay.n_lookups);
     if (q.n_terms > MAX_TERMS) return ZK_EINVAL;
@@ -1137,6 +1159,7 @@ struct Prover {
         }
         if (!ok()) return rc;
         const Fr x = tr->squeeze();
+        HT("x squeezed");
 
         // -- 7. evaluations: every opened value in ONE batched launch, then written in transcript order
         // h(X) = sum x^(n i) h_i(X)
@@ -1196,6 +1219,7 @@ struct Prover {
                 hipStreamSynchronize(st) != hipSuccess)
                 return ZK_EHIP;
             for (size_t i = 0; i < ev.size(); i++) ev[i].eval = pk->tail_host[i];
+        HT("evals on host");
         }
         for (size_t i = 0; i < n_written; i++) tr->write_scalar(ev[i].eval);
         // prover query order (== verifier's): advice, perm z (x, wx per chunk; then `last` in reverse), lookups
@@ -1227,6 +1251,7 @@ struct Prover {
 
         // -- 8. multi-open
         pk->lc_used = 0;
+        HT("queries built");
         return scheme == ZK_SCHEME_GWC ? open_gwc(queries, x, max_batch) : open_shplonk(queries, x);
     }
 
@@ -1346,6 +1371,7 @@ struct Prover {
             hit->coms.push_back(&cr);
         }
         std::sort(all_rots.begin(), all_rots.end(), pt_less);
+        HT("grouped");
         const Fr yc = tr->squeeze();
         const Fr v = tr->squeeze();
         std::vector<std::vector<Fr>> low(com.size());
@@ -1377,6 +1403,7 @@ struct Prover {
             // sum_j y^j P_j(X) minus sum_j y^j R_j(X) (degree < |set|: a few low coefficients, known on the host)
             if (pts.size() > 8) return ZK_ESTATE;
             lincomb_many(sbuf[si], terms, false, Fr::zero(), false, &rsum);
+        HT("set lincomb launched");
             max_pts = std::max(max_pts, pts.size());
             set_pts.push_back(pts);
         }
@@ -1400,10 +1427,12 @@ struct Prover {
                 pv = fe_mul(pv, v);
             }
             lincomb_many(hx, terms, false, Fr::zero());
+        HT("hx launched");
         }
         commit_write(hx, n, ZK_BASIS_MONOMIAL);
         if (!ok()) return rc;
         const Fr u = tr->squeeze();
+        HT("u squeezed");
         // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
         std::vector<Term> terms;
         Fr sub = Fr::zero();
@@ -1429,6 +1458,7 @@ struct Prover {
         const Fr zt = vanishing_eval(all_pts, u);
         terms.push_back(Term{hx, fe_neg(zt)});
         lincomb_many(pk->t_a, terms, true, sub);
+        HT("L launched");
         launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
         launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
         commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);

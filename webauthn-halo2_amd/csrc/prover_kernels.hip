@@ -805,8 +805,8 @@ void launch_scatter_rows(const RowEntry* d_entries, uint32_t count, hipStream_t 
 // -0.1 ms per k=19 proof, -0.3 ms at k=15..17)
 static constexpr uint32_t KD_L_MIN = ZK_KD_L;
 static constexpr uint32_t KD_BLK = 256;
-static constexpr uint32_t KD_TOP = 1024;  // blocks the one-workgroup top level scans
-// chunk length of an n-coefficient division: the shortest that keeps the top level within ONE workgroup (8 up to 2^21,
+static constexpr uint32_t KD_TOP = 1024;  // most blocks of a division: every block sums the aggregates above it directly
+// chunk length of an n-coefficient division: the shortest that keeps the number of blocks within KD_TOP (8 up to 2^21,
 // 16 at 2^22, ...)
 __host__ __device__ inline uint32_t kd_len(uint32_t n) {
     uint32_t L = KD_L_MIN;
@@ -823,48 +823,60 @@ struct KdStep {
     Fr step[KD_MAX_BATCH][8];  // Z^(2^j), j = 0..7, Z = z^KD_L
 };
 struct KdTop {
-    Fr top[KD_MAX_BATCH][12];  // (Z^256)^(2^j)
-};
-struct KdZ {
-    Fr Z[KD_MAX_BATCH];
+    Fr top[KD_MAX_BATCH][10];  // (Z^256)^(2^j): exponents below KD_TOP = 2^10
 };
 
-// per-division scratch: cval[m] | suf[m] | agg[nblk] | G[nblk] | zpow[256]
+// per-division scratch: (m unused) | suf[m] | agg[nblk] | tpow[nblk] | zpow[256]
 __host__ __device__ inline uint32_t kd_scratch_elems(uint32_t n) {
     const uint32_t L = kd_len(n), m = (n + L - 1) / L, nblk = (m + KD_BLK - 1) / KD_BLK;
     return 2 * m + 2 * nblk + 256;
 }
 uint32_t kate_division_scratch(uint32_t n) { return kd_scratch_elems(n); }
 
-__global__ void kd_chunk_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
-    const uint32_t KD_L = kd_len(n);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t base = t * KD_L;
-    if (base >= n) return;
-    const Fr* __restrict__ p = a.p[blockIdx.y];
-    const Fr z = a.z[blockIdx.y];
-    Fr* cval = scratch + (size_t)blockIdx.y * kd_scratch_elems(n);
-    const uint32_t top = min(n, base + KD_L);
-    Fr acc = Fr::zero();
-    for (uint32_t i = top; i-- > base;) acc = fe_add(fe_mul(acc, z), fe_load(p + i));
-    fe_store(cval + t, acc);
-}
-
-// Carries between chunks: K_t = sum_{s > t} c_s Z^(s-t-1), Z = z^KD_L.  Two-level suffix
-// scan with KNOWN multipliers (powers of Z), so a Hillis-Steele step is one product:
-//   kd_block_scan  within blocks of 256 chunks: suf[i] = sum_{s >= i, s in block} c_s Z^(s-i);
-//                  block aggregate S_B = suf[first]
-//   kd_top         G_B = S_{B+1} + Z^256 G_{B+1} (carry entering block B from above), one workgroup
-//   kd_apply       K_t = suf[t+1] (same block) + Z^(last_in_block - t) G_B
-__global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(KdStep pw, uint32_t n, Fr* __restrict__ scratch) {
+// Carries between chunks: K_t = sum_{s > t} c_s Z^(s-t-1), Z = z^KD_L.  Two-level suffix scan with KNOWN multipliers (powers
+// of Z), so a Hillis-Steele step is one product.  Two launches per batch of divisions:
+//   kd_scan   workgroup B < nblk: the chunk values c_t of its 256 chunks (Horner over KD_L coefficients each), then the scan
+//             within the block: suf[i] = sum_{s >= i, s in block} c_s Z^(s-i); block aggregate S_B = suf[first].
+//             Workgroup nblk: zpow[i] = Z^i, i < 256.  Workgroups after it: tpow[j] = (Z^256)^j, j < nblk.
+//   kd_apply  workgroup B: the carry entering the block from above, G_B = sum_{B' > B} S_B' (Z^256)^(B'-B-1) (a direct sum over
+//             the at most 1 024 aggregates, reduced through LDS); then K_t = suf[t+1] (same block) + Z^(last_in_block - t) G_B
+//             and the replay of every chunk from its carry.
+__global__ __launch_bounds__(KD_BLK) void kd_scan_kernel(KdPtrs a, KdStep pw, KdTop tw, uint32_t n, Fr* __restrict__ scratch) {
     __shared__ Fr sh[KD_BLK];
     const uint32_t KD_L = kd_len(n);
-    const uint32_t m = (n + KD_L - 1) / KD_L;
-    Fr* cval = scratch + (size_t)blockIdx.y * kd_scratch_elems(n);
-    Fr* suf = cval + m;
+    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
+    Fr* suf = scratch + (size_t)blockIdx.y * kd_scratch_elems(n) + m;
     Fr* agg = suf + m;
+    Fr* tpow = agg + nblk;
+    Fr* zpow = tpow + nblk;
+    if (blockIdx.x >= nblk) {
+        // the tables of powers: Z^i (i < 256) by workgroup nblk, (Z^256)^j (j < nblk) by the ones after it
+        const bool top = blockIdx.x > nblk;
+        const uint32_t e0 = top ? (blockIdx.x - nblk - 1) * KD_BLK + threadIdx.x : threadIdx.x;
+        if (top && e0 >= nblk) return;
+        Fr acc = Fr::one();
+        if (top) {
+            for (uint32_t e = e0, j = 0; e; e >>= 1, j++)
+                if (e & 1) acc = fe_mul(acc, tw.top[blockIdx.y][j]);  // (Z^256)^(2^j)
+            fe_store(tpow + e0, acc);
+        } else {
+            for (uint32_t e = e0, j = 0; e; e >>= 1, j++)
+                if (e & 1) acc = fe_mul(acc, pw.step[blockIdx.y][j]);  // Z^(2^j), j < 8
+            fe_store(zpow + e0, acc);
+        }
+        return;
+    }
     const uint32_t t = blockIdx.x * KD_BLK + threadIdx.x;
-    Fr v = t < m ? fe_load(cval + t) : Fr::zero();
+    Fr v = Fr::zero();
+    {
+        const uint32_t base = t * KD_L;
+        if (base < n) {
+            const Fr* __restrict__ p = a.p[blockIdx.y];
+            const Fr z = a.z[blockIdx.y];
+            const uint32_t top = min(n, base + KD_L);
+            for (uint32_t i = top; i-- > base;) v = fe_add(fe_mul(v, z), fe_load(p + i));
+        }
+    }
     sh[threadIdx.x] = v;
     __syncthreads();
 #pragma unroll 1
@@ -883,69 +895,42 @@ __global__ __launch_bounds__(KD_BLK) void kd_block_scan_kernel(KdStep pw, uint32
     if (threadIdx.x == 0) fe_store(agg + blockIdx.x, v);
 }
 
-// G[B] = sum_{B' > B} S_{B'} (Z^256)^(B'-B-1); nblk <= KD_TOP by the choice of the chunk length.  blockIdx.x = division.
-__global__ __launch_bounds__(KD_TOP) void kd_top_kernel(KdTop pw, uint32_t n, Fr* __restrict__ scratch) {
-    __shared__ Fr sh[KD_TOP];
+__global__ __launch_bounds__(KD_BLK) void kd_apply_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
+    __shared__ Fr sh[KD_BLK];
     const uint32_t KD_L = kd_len(n);
     const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
-    Fr* agg = scratch + (size_t)blockIdx.x * kd_scratch_elems(n) + 2 * m;
-    Fr* G = agg + nblk;
-    // inclusive suffix scan of S with multiplier Z^256, then shift by one
-    Fr v = threadIdx.x < nblk ? fe_load(agg + threadIdx.x) : Fr::zero();
-    sh[threadIdx.x] = v;
+    const Fr* suf = scratch + (size_t)blockIdx.y * kd_scratch_elems(n) + m;
+    const Fr* agg = suf + m;
+    const Fr* tpow = agg + nblk;
+    const Fr* zpow = tpow + nblk;
+    const uint32_t blk = blockIdx.x;
+    // G = sum_{B' > blk} S_B' (Z^256)^(B' - blk - 1)
+    Fr g = Fr::zero();
+    for (uint32_t b = blk + 1 + threadIdx.x; b < nblk; b += KD_BLK) g = fe_add(g, fe_mul(fe_load(agg + b), fe_load(tpow + (b - blk - 1))));
+    sh[threadIdx.x] = g;
     __syncthreads();
-#pragma unroll 1
-    for (uint32_t j = 0, d = 1; d < 1024 && d < nblk; d <<= 1, j++) {
-        Fr o = Fr::zero();
-        const bool has = threadIdx.x + d < nblk;
-        if (has) o = sh[threadIdx.x + d];
-        __syncthreads();
-        if (has) {
-            v = fe_add(v, fe_mul(o, pw.top[blockIdx.x][j]));
-            sh[threadIdx.x] = v;
-        }
+    for (uint32_t d = KD_BLK / 2; d; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + d]);
         __syncthreads();
     }
-    if (threadIdx.x < nblk) fe_store(G + threadIdx.x, threadIdx.x + 1 < nblk ? sh[threadIdx.x + 1] : Fr::zero());
-}
-
-__global__ void kd_apply_kernel(KdPtrs a, uint32_t n, Fr* __restrict__ scratch) {
-    const uint32_t KD_L = kd_len(n);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const Fr G = sh[0];
+    const uint32_t t = blk * KD_BLK + threadIdx.x;
     const uint32_t base = t * KD_L;
     if (base >= n) return;
-    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
     const Fr* __restrict__ p = a.p[blockIdx.y];
     Fr* __restrict__ q = a.q[blockIdx.y];
     const Fr z = a.z[blockIdx.y];
-    const Fr* suf = scratch + (size_t)blockIdx.y * kd_scratch_elems(n) + m;
-    const Fr* G = suf + m + nblk;
-    const Fr* zpow = G + nblk;
     const uint32_t top = min(n, base + KD_L);
     // carry into chunk t: chunks above it in the same block + everything above the block
-    const uint32_t blk = t / KD_BLK;
     const uint32_t last = min(m, (blk + 1) * KD_BLK) - 1;
     Fr run = (t < last) ? fe_load(suf + t + 1) : Fr::zero();
-    run = fe_add(run, fe_mul(fe_load(zpow + (last - t)), fe_load(G + blk)));
+    run = fe_add(run, fe_mul(fe_load(zpow + (last - t)), G));
     // run = q[top - 1]; walk down: q[i-1] = p[i] + z q[i]  (p[i] is read before q[i] is written: q may be p)
     for (uint32_t i = top; i-- > base;) {
         const Fr pi = fe_load(p + i);
         fe_store(q + i, run);
         run = fe_add(fe_mul(run, z), pi);
     }
-}
-
-// zpow[i] = Z^i, i < 256 (one workgroup per division)
-__global__ __launch_bounds__(256) void kd_zpow_kernel(KdZ zz, uint32_t n, Fr* __restrict__ scratch) {
-    const uint32_t KD_L = kd_len(n);
-    const uint32_t m = (n + KD_L - 1) / KD_L, nblk = (m + KD_BLK - 1) / KD_BLK;
-    Fr* zpow = scratch + (size_t)blockIdx.x * kd_scratch_elems(n) + 2 * m + 2 * nblk;
-    Fr acc = Fr::one(), base = zz.Z[blockIdx.x];
-    for (uint32_t e = threadIdx.x; e; e >>= 1) {
-        if (e & 1) acc = fe_mul(acc, base);
-        base = fe_sqr(base);
-    }
-    fe_store(zpow + threadIdx.x, acc);
 }
 
 // `count` <= KD_MAX_BATCH divisions q[i] = (p[i] - p[i](z[i])) / (X - z[i]); scratch: count * kate_division_scratch(n)
@@ -957,34 +942,28 @@ void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, u
     KdPtrs pt;
     KdStep stp;
     KdTop tp;
-    KdZ zz;
     memset(&pt, 0, sizeof(pt));
     memset(&stp, 0, sizeof(stp));
     memset(&tp, 0, sizeof(tp));
-    memset(&zz, 0, sizeof(zz));
     for (uint32_t b = 0; b < count; b++) {
         pt.p[b] = p[b];
         pt.q[b] = q[b];
         pt.z[b] = z[b];
         Fr Z = z[b];
         for (uint32_t i = 1; i < KD_L; i <<= 1) Z = fe_sqr(Z);  // z^KD_L
-        zz.Z[b] = Z;
         Fr cur = Z;
         for (int j = 0; j < 8; j++) {
             stp.step[b][j] = cur;
             cur = fe_sqr(cur);
         }
         // cur = Z^256
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < 10; j++) {
             tp.top[b][j] = cur;
             cur = fe_sqr(cur);
         }
     }
-    hipLaunchKernelGGL(kd_chunk_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st, pt, n, scratch);
-    hipLaunchKernelGGL(kd_zpow_kernel, dim3(count), dim3(256), 0, st, zz, n, scratch);
-    hipLaunchKernelGGL(kd_block_scan_kernel, dim3(nblk, count), dim3(KD_BLK), 0, st, stp, n, scratch);
-    hipLaunchKernelGGL(kd_top_kernel, dim3(count), dim3(KD_TOP), 0, st, tp, n, scratch);
-    hipLaunchKernelGGL(kd_apply_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st, pt, n, scratch);
+    hipLaunchKernelGGL(kd_scan_kernel, dim3(nblk + 1 + (nblk + KD_BLK - 1) / KD_BLK, count), dim3(KD_BLK), 0, st, pt, stp, tp, n, scratch);
+    hipLaunchKernelGGL(kd_apply_kernel, dim3(nblk, count), dim3(KD_BLK), 0, st, pt, n, scratch);
 }
 
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* scratch, hipStream_t st) {
