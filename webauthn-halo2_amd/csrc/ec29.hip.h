@@ -212,34 +212,36 @@ __device__ __forceinline__ void g1x29_dbl_rare(G1X29& p) {
 
 // acc += b, both XYZZ partial sums in internal form (add-2008-s), all special cases handled; the products are inlined,
 // so a kernel should have ONE call site (3 300 instructions).  Bounds in and out as in the header (X < 9p, Y < 5p).
+// SER: the products' multiply-adds as one serial chain (field29.hip.h) — false in the kernels that run one wave per SIMD.
+template <bool SER = MUL29_SER>
 __device__ __forceinline__ void g1x29_add(G1X29& acc, const G1X29& b) {
     if (b.inf) return;
     if (acc.inf) {
         acc = b;
         return;
     }
-    const Fq29 u1 = mul29(acc.x, b.zz);                                    // 18
-    const Fq29 u2 = mul29(b.x, acc.zz);
-    const Fq29 s1 = mul29(acc.y, b.zzz);                                   // 10
-    const Fq29 s2 = mul29(b.y, acc.zzz);
+    const Fq29 u1 = mul29<FqParams, SER>(acc.x, b.zz);                                    // 18
+    const Fq29 u2 = mul29<FqParams, SER>(b.x, acc.zz);
+    const Fq29 s1 = mul29<FqParams, SER>(acc.y, b.zzz);                                   // 10
+    const Fq29 s2 = mul29<FqParams, SER>(b.y, acc.zzz);
     const Fq29 p = norm29(sub29<3, 29>(u2, u1));                           // (5 ; 29)
     const Fq29 r = norm29(sub29<3, 29>(s2, s1));                           // (5 ; 29)
-    const Fq29 pp = sqr29(p);                                              // 25
-    const Fq29 rr = sqr29(r);                                              // 25
+    const Fq29 pp = sqr29<FqParams, SER>(p);                                              // 25
+    const Fq29 rr = sqr29<FqParams, SER>(r);                                              // 25
     if (is_zero29(pp)) {                                                   // same x: doubling or cancellation
         if (is_zero29(rr)) g1x29_dbl_rare(acc);
         else acc = g1x29_identity();
         return;
     }
-    const Fq29 ppp = mul29(p, pp);                                         // 10
-    const Fq29 q = mul29(u1, pp);                                          // 4
+    const Fq29 ppp = mul29<FqParams, SER>(p, pp);                                         // 10
+    const Fq29 q = mul29<FqParams, SER>(u1, pp);                                          // 4
     const Fq29 t = add29(ppp, add29(q, q));                                // (6 ; < 3 * 2^29)
     const Fq29 x3 = norm29(sub29<7, 31>(rr, t));                           // (9 ; 29)
     const Fq29 v = sub29<10, 29>(q, x3);                                   // (12 ; 30.6)
-    acc.y = mul2add29(r, v, s1, sub29<3, 29>(zero29(), ppp));              // 5 * 12 + 2 * 3 = 66: (2 ; 29)
+    acc.y = mul2add29<FqParams, SER>(r, v, s1, sub29<3, 29>(zero29(), ppp));              // 5 * 12 + 2 * 3 = 66: (2 ; 29)
     acc.x = x3;
-    acc.zz = mul29(mul29(acc.zz, b.zz), pp);
-    acc.zzz = mul29(mul29(acc.zzz, b.zzz), ppp);
+    acc.zz = mul29<FqParams, SER>(mul29<FqParams, SER>(acc.zz, b.zz), pp);
+    acc.zzz = mul29<FqParams, SER>(mul29<FqParams, SER>(acc.zzz, b.zzz), ppp);
 }
 
 // The point held by lane (lane + off) mod 64.  One source address for all 37 words and raw ds_bpermute, so that the

@@ -119,20 +119,30 @@ __device__ __forceinline__ Fe<PRM> from29(const Fe29<PRM>& a) {
 #ifndef ZK_MUL29_ASM
 #define ZK_MUL29_ASM 0
 #endif
-#if ZK_MUL29_ASM && defined(__HIP_DEVICE_COMPILE__)
+// The products take the choice as a template parameter SER (default: the file's ZK_MUL29_ASM): kernels that run ONE wave per
+// SIMD — the reduction tails of the MSM — are bound by the latency of that serial chain, not by issue slots, and want the
+// compiler's form (msm_wrowcol / msm_wbits: -22 % with SER = false in a file whose accumulation kernels need SER = true).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <bool SER>
 __device__ __forceinline__ void mad29(uint64_t& acc, uint32_t a, uint32_t b) {
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    if constexpr (SER) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    else acc += (uint64_t)a * b;
 }
+template <bool SER>
 __device__ __forceinline__ void mad29c(uint64_t& acc, uint32_t a, uint32_t c) {
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(c) : "vcc");
+    if constexpr (SER) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(c) : "vcc");
+    else acc += (uint64_t)a * c;
 }
 #else
+template <bool SER>
 __device__ __forceinline__ void mad29(uint64_t& acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
+template <bool SER>
 __device__ __forceinline__ void mad29c(uint64_t& acc, uint32_t a, uint32_t c) { acc += (uint64_t)a * c; }
 #endif
+static constexpr bool MUL29_SER = ZK_MUL29_ASM != 0;
 
 // a * b * 2^-261 mod p, lazily: result limbs < 2^29, value < p * (1 + k_a k_b / 169.4)
-template <class PRM>
+template <class PRM, bool SER = MUL29_SER>
 __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& b) {
     uint32_t m[9];
     Fe29<PRM> r;
@@ -140,19 +150,19 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) mad29(acc, a.l[i], b.l[k - i]);
+        for (int i = 0; i <= k; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = 0; i < k; i++) mad29c(acc, m[i], Lim29<PRM>::P[k - i]);
+        for (int i = 0; i < k; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
         m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
-        mad29c(acc, m[k], Lim29<PRM>::P[0]);
+        mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29(acc, a.l[i], b.l[k - i]);
+        for (int i = k - 8; i < 9; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29c(acc, m[i], Lim29<PRM>::P[k - i]);
+        for (int i = k - 8; i < 9; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
         r.l[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
@@ -164,7 +174,7 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
 // m * p terms (243 instead of 324 multiply-adds).  All four operands need limbs <= ~2^30 so that a column
 // (9 + 9 products + 9 reduction terms) stays below 2^64: a_i b_j + c_i d_j < 2^60.6 each side is too much — callers pass
 // normalised (29-bit) a, c and b, d with limbs < 2^30.7.  Value bounds: k_a k_b + k_c k_d <= 168.
-template <class PRM>
+template <class PRM, bool SER = MUL29_SER>
 __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PRM>& b, const Fe29<PRM>& c, const Fe29<PRM>& d) {
     uint32_t m[9];
     Fe29<PRM> r;
@@ -172,23 +182,23 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) mad29(acc, a.l[i], b.l[k - i]);
+        for (int i = 0; i <= k; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = 0; i <= k; i++) mad29(acc, c.l[i], d.l[k - i]);
+        for (int i = 0; i <= k; i++) mad29<SER>(acc, c.l[i], d.l[k - i]);
 #pragma unroll
-        for (int i = 0; i < k; i++) mad29c(acc, m[i], Lim29<PRM>::P[k - i]);
+        for (int i = 0; i < k; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
         m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
-        mad29c(acc, m[k], Lim29<PRM>::P[0]);
+        mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29(acc, a.l[i], b.l[k - i]);
+        for (int i = k - 8; i < 9; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29(acc, c.l[i], d.l[k - i]);
+        for (int i = k - 8; i < 9; i++) mad29<SER>(acc, c.l[i], d.l[k - i]);
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29c(acc, m[i], Lim29<PRM>::P[k - i]);
+        for (int i = k - 8; i < 9; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
         r.l[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
@@ -197,7 +207,7 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
 }
 
 // a * a * 2^-261 mod p: the 36 cross products are taken once against the doubled operand (45 instead of 81 products of a * a)
-template <class PRM>
+template <class PRM, bool SER = MUL29_SER>
 __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
     uint32_t m[9], a2[9];
 #pragma unroll
@@ -208,16 +218,16 @@ __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
     for (int k = 0; k < 17; k++) {
         // sum_{i + j = k, i < j} (2 a_i) a_j + [k even] a_{k/2}^2
 #pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) mad29(acc, a2[i], a.l[k - i]);
-        if ((k & 1) == 0) mad29(acc, a.l[k / 2], a.l[k / 2]);
+        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) mad29<SER>(acc, a2[i], a.l[k - i]);
+        if ((k & 1) == 0) mad29<SER>(acc, a.l[k / 2], a.l[k / 2]);
         if (k < 9) {
 #pragma unroll
-            for (int i = 0; i < k; i++) mad29c(acc, m[i], Lim29<PRM>::P[k - i]);
+            for (int i = 0; i < k; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
             m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
-            mad29c(acc, m[k], Lim29<PRM>::P[0]);
+            mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         } else {
 #pragma unroll
-            for (int i = k - 8; i < 9; i++) mad29c(acc, m[i], Lim29<PRM>::P[k - i]);
+            for (int i = k - 8; i < 9; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
             r.l[k - 9] = (uint32_t)acc & M29;
         }
         acc >>= 29;
@@ -229,7 +239,7 @@ __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
 // sum_{j < K} a[j] * b[j] * 2^-261 mod p with ONE Montgomery reduction (81 (K + 1) instead of 162 K multiply-adds).
 // All operands normalised (limbs < 2^29): a column is at most 9 K + 9 products < 2^58, so K <= 5.  Value bounds:
 // sum_j k_a[j] k_b[j] <= 168 for a result < 2p.
-template <int K, class PRM>
+template <int K, class PRM, bool SER = MUL29_SER>
 __device__ __forceinline__ Fe29<PRM> mulKadd29(const Fe29<PRM> (&a)[K], const Fe29<PRM> (&b)[K]) {
     static_assert(K >= 1 && K <= 5, "a column of 9 K + 9 products of 58 bits must fit 64 bits");
     uint32_t m[9];

@@ -40,6 +40,12 @@
 #ifndef ZK_MUL29_ASM
 #define ZK_MUL29_ASM 1
 #endif
+// ... except in the reduction kernels, which run about one wave per SIMD: their additions wait on that serial chain, not on
+// issue slots, and take the compiler's form (g1x29_add<false>; tools/tail_times.sh, per lone k = 19 proof: msm_wrowcol
+// 1.19 -> 0.98 ms, msm_wbits 1.00 -> 0.59, k = 15: msm_bitsum 1.02 -> 0.75, msm_gather 0.75 -> 0.64; msm_wparts unchanged)
+#ifndef ZK_TAIL_SER
+#define ZK_TAIL_SER false
+#endif
 #include "ec29.hip.h"
 #include "engine.h"
 
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X29S* __restric
 #pragma unroll 1
     for (uint32_t k = 1; k < GA; k++) {
         const G1X29 v = g1x29_load(src + k);
-        g1x29_add(acc, v);
+        g1x29_add<ZK_TAIL_SER>(acc, v);
     }
     g1x29_store(partial + t, acc);
 }
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restr
             have = (int)lane < off;
             off >>= 1;
         }
-        if (have) g1x29_add(acc, v);
+        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
     }
     ZK_STAMP(10);
     ZK_WG_STAMP(2);
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
                 have = (threadIdx.x & (lanes - 1)) < (uint32_t)off;
                 off >>= 1;
             }
-            if (have) g1x29_add(acc, v);
+            if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
         }
         ZK_STAMP(3 + 2 * stage);
         if (THREADS == 64 || stage == 1) break;
@@ -1335,7 +1341,7 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
             v = g1x29_shfl_down(acc, off);
             off <<= 1;
         }
-        if (have) g1x29_add(acc, v);
+        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
     }
     const uint32_t prev = (uint32_t)__shfl_up((int)b, 1);
     if (active && (lane == 0 || prev != b)) g1x29_store(part_all + (size_t)col * part_stride + g, acc);
@@ -1389,7 +1395,7 @@ __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restric
             have = (int)lane < off;
             off >>= 1;
         }
-        if (have) g1x29_add(acc, v);
+        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
     }
     if (lane == 0) g1x29_store(rc_all + (size_t)col * (rows + 256) + r, acc);
 }
@@ -1423,7 +1429,7 @@ __global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict_
             have = (int)lane < off;
             off >>= 1;
         }
-        if (have) g1x29_add(acc, v);
+        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
     }
     if (lane == 0) {
         G1X r = G1X::identity();
