@@ -1,28 +1,69 @@
 #!/usr/bin/env python3
-"""Bug hunt: proofs of randomly drawn circuit shapes, device against the plain-Python oracle (the committed test
-tests/test_gpu_prover.py::test_random_shapes_byte_identical_to_oracle runs ten of them; this draws as many as asked).
-usage: shape_sweep.py <seed> <count>"""
+"""Bug hunt: proofs of randomly drawn circuit shapes, device against the oracle.
+  shape_sweep.py <seed> <count>          small shapes (k 6..9) against the plain-Python oracle — the committed test
+                                         tests/test_gpu_prover.py::test_random_shapes_byte_identical_to_oracle runs ten of them
+  shape_sweep.py <seed> <count> mid      k 10..14 with up to ~90 columns against the oracle's numpy + C prover (fastprover)"""
 import os
+import random
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import test_gpu_prover as t  # noqa: E402
+from zkoracle import fastprover as fp  # noqa: E402
+
+
+def mid_shapes(count, seed):
+    pr = random.Random(seed)
+    out = []
+    while len(out) < count:
+        k = pr.choice([10, 11, 12, 13, 14])
+        A = pr.choice([1, 2, 3, 4, 8, 17, 34, 68])
+        if A * (1 << k) > 68 << 12:      # bound the oracle's time
+            continue
+        L = 1 if A == 1 else pr.choice([1, 2, max(1, A // 6), max(1, A // 4)])
+        F = pr.choice([1, 1, 2, 4])
+        lb = pr.randrange(k - 4, k)
+        idle = pr.choice([0, 0, 0, 1, 3]) if A >= 4 else 0
+        out.append((A, L, F, k, lb, idle))
+    return out
+
+
+def check_mid(eng, shape):
+    A, L, F, k, lb, idle = shape
+    p, asg, pk, polys = t.setup(eng, A, L, F, k, lb, seed=0x5EED1000 + 131 * A + k, idle=idle)
+    sh = t.plonk.Shape(k, A, L, F, lb, idle)
+    fpk = fp.keygen(sh, asg.fixed, asg.copies)
+    vk = t.product_vk(eng, pk, sh)
+    assert vk.fixed_commitments == fpk.vk.fixed_commitments and vk.permutation_commitments == fpk.vk.permutation_commitments
+    assert vk.transcript_repr == fpk.vk.transcript_repr
+    seed = bytes([k, A & 255, L, F]) * 8
+    for kind in ("blake2b", "evm"):
+        got = eng.prove(pk, polys, seed, t.KIND[kind])
+        want = fp.create_proof(fpk, asg.advice, t.ChaCha20Rng(seed), kind)
+        assert got == want, (shape, kind)
+    for h in polys:
+        h.free()
+    eng.pk_free(pk)
 
 
 def main():
     seed, count = int(sys.argv[1], 0), int(sys.argv[2])
+    mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
     eng = t.zk.Engine(0)
     bad = 0
-    for shape in t._random_shapes(count, seed):
+    shapes = mid_shapes(count, seed) if mid else t._random_shapes(count, seed)
+    for shape in shapes:
+        t0 = time.time()
         try:
-            t.test_random_shapes_byte_identical_to_oracle(eng, shape)
-            print("ok  ", shape, flush=True)
+            (check_mid if mid else t.test_random_shapes_byte_identical_to_oracle)(eng, shape)
+            print("ok  ", shape, "%.1f s" % (time.time() - t0), flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
-            print("FAIL", shape, repr(e)[:200], flush=True)
+            print("FAIL", shape, repr(e)[:300], flush=True)
     print("shapes", count, "failures", bad)
     return 1 if bad else 0
 
