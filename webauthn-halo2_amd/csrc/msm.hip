@@ -84,6 +84,7 @@ struct MsmWorkspace {
     uint32_t max_batch;         // columns per fixed-base launch this workspace is sized for
     uint32_t c, nwin, nb;       // window bits, windows, buckets per window
     uint32_t parts_fixed, parts_generic;
+    size_t slot_elems;          // elements of slot_pt
     int16_t* digits;            // [nwin][max_n]  (|digit| <= 2^(c-1) <= 8192)
     uint32_t* totals;           // [nwin*nb + 1]
     uint32_t* bucket_start;     // [nwin*nb + 1]
@@ -1572,6 +1573,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
         MSM_TRY(hipMalloc(&ws->cursor, (size_t)max_batch * ws->nb * sizeof(uint32_t)));
     }
     MSM_TRY(hipMalloc(&ws->redo, threads * sizeof(uint32_t)));
+    ws->slot_elems = threads;
     MSM_TRY(hipMalloc(&ws->slot_pt, threads * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X29S)));
@@ -1643,6 +1645,11 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     *nwin_out = batch;
     *c_out = c;
     hipError_t e;
+#ifdef ZK_MSM_POISON  // debug: a slot / part / row-column sum read without having been written by THIS pass shows
+    hipMemsetAsync(ws->slot_pt, 0xA5, ws->slot_elems * sizeof(G1X29S), st);
+    hipMemsetAsync(ws->w_part, 0xA5, (size_t)ws->max_batch * ws->w_part_stride * sizeof(G1X29S), st);
+    hipMemsetAsync(ws->w_rc, 0xA5, (size_t)ws->max_batch * ((ws->nb >> 8) + 256) * sizeof(G1X29S), st);
+#endif
     {
         uint32_t m = nbt + 1;
         if (batch * CBINS_MAX > m) m = batch * CBINS_MAX;
