@@ -68,7 +68,7 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
 /* tuning options (measurement tools, tests); value 0 restores the built-in choice.  The engine reads no
  * environment variables. */
 #define ZK_OPT_MSM_WINDOW 1          /* signed window bits of the fixed-base MSM, 9..16; takes effect at the next SRS load */
-#define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..64 */
+#define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..256 */
 #define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..11 (clamped to the tile) */
 #define ZK_OPT_GP_BATCH_INVERT 4     /* 1: grand products always take halo2's batch_invert form (the fallback path) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
@@ -182,9 +182,11 @@ typedef uint64_t zk_pk; /* opaque: proving key + verifying key + prover workspac
 int zk_keygen(zk_ctx* ctx, const zk_circuit_params* params, const uint64_t* fixed_canonical /* n_fixed_columns x n x 4 */,
               size_t n_fixed_columns /* must equal the shape's fixed-column count: ZK_EINVAL otherwise */,
               const uint32_t* copies, size_t n_copies, zk_pk* out);
-/* the vk digest every transcript starts with (halo2 `vk.transcript_repr`, a Blake2b hash of the pinned vk's Debug
- * form that only the Rust host can compute): zk_keygen stamps a stand-in; the host sets the real value here
- * (Montgomery image).  zk_pk_read / zk_vk_read take it from the key file's vk instead. */
+/* the vk digest every transcript starts with (halo2 `vk.transcript_repr`: Blake2b-512 of the pinned vk's Debug rendering,
+ * reduced mod r): zk_keygen / zk_pk_read compute halo2's own value (csrc/vkrepr.h; pinned by the reference's k = 17 literal,
+ * proving-server/P256Verifier.yul:34) for every shape without never-enabled gate columns, and a stand-in hash for those
+ * (bench_ecdsa.config rows k <= 13, whose selector compression is not restated).  A host that knows better sets its value
+ * here (Montgomery image). */
 int zk_pk_set_transcript_repr(zk_ctx* ctx, zk_pk pk, const uint64_t transcript_repr_mont[4]);
 int zk_pk_free(zk_ctx* ctx, zk_pk pk);
 /* the VerifyingKey half: commitments (affine Montgomery) and transcript_repr; counts = {n_fixed, n_perm} */
@@ -201,7 +203,7 @@ int zk_vk_load(zk_ctx* ctx, zk_pk pk, const uint8_t* vk_bytes, size_t len, int f
 int zk_pk_write(zk_ctx* ctx, zk_pk pk, int format, uint8_t* out, size_t cap, size_t* len);
 /* replaces ProvingKey::read::<_, ECDSACircuit<Fr>> (ecdsa_p256.rs:339-343, 389-393 — on every request there, once
  * here): the key material comes from the file image, the column shape from `params` (what `ECDSACircuit::configure`
- * tells halo2), transcript_repr from the caller (NULL: the stand-in).  Needs the SRS of params->k. */
+ * tells halo2), transcript_repr from the caller (NULL: computed as zk_keygen does).  Needs the SRS of params->k. */
 int zk_pk_read(zk_ctx* ctx, const zk_circuit_params* params, const uint8_t* bytes, size_t len, int format,
                const uint64_t transcript_repr_mont[4], zk_pk* out);
 /* the column shape of a key, for a host that drives the phases itself:

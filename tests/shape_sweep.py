@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Bug hunt: proofs of randomly drawn circuit shapes, device against the oracle.
+"""Bug hunt (test infrastructure: it uses the oracle, so it lives under tests/): proofs of randomly drawn circuit shapes,
+device against the oracle.
   shape_sweep.py <seed> <count>          small shapes (k 6..9) against the plain-Python oracle — the committed test
                                          tests/test_gpu_prover.py::test_random_shapes_byte_identical_to_oracle runs ten of them
   shape_sweep.py <seed> <count> mid      k 10..14 with up to ~90 columns against the oracle's numpy + C prover (fastprover)"""
@@ -10,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this directory: the suite's helpers
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import test_gpu_prover as t  # noqa: E402
 from zkoracle import fastprover as fp  # noqa: E402
