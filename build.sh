@@ -19,3 +19,7 @@ done
 for p in $pids; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
 echo "built $(pwd)/$OUT"
+# the C++ host example of the same ABI (examples/prove_host.cpp): plain g++, linked against the library above
+cd ..
+g++ -O2 -std=c++17 -Wall -Iinclude examples/prove_host.cpp -Lwebauthn-halo2_amd -lzkmi355 -Wl,-rpath,'$ORIGIN/../webauthn-halo2_amd' -o examples/prove_host
+echo "built $(pwd)/examples/prove_host"
