@@ -3,7 +3,8 @@
 device against the oracle.
   shape_sweep.py <seed> <count>          small shapes (k 6..9) against the plain-Python oracle — the committed test
                                          tests/test_gpu_prover.py::test_random_shapes_byte_identical_to_oracle runs ten of them
-  shape_sweep.py <seed> <count> mid      k 10..14 with up to ~90 columns against the oracle's numpy + C prover (fastprover)"""
+  shape_sweep.py <seed> <count> mid      k 10..14 with up to ~90 columns against the oracle's numpy + C prover (fastprover)
+  shape_sweep.py <seed> <count> full     the bench_ecdsa.config rows k = 16..19 at full size, `count` witness seeds each"""
 import os
 import random
 import sys
@@ -33,9 +34,9 @@ def mid_shapes(count, seed):
     return out
 
 
-def check_mid(eng, shape):
+def check_mid(eng, shape, wseed=None):
     A, L, F, k, lb, idle = shape
-    p, asg, pk, polys = t.setup(eng, A, L, F, k, lb, seed=0x5EED1000 + 131 * A + k, idle=idle)
+    p, asg, pk, polys = t.setup(eng, A, L, F, k, lb, seed=wseed if wseed is not None else 0x5EED1000 + 131 * A + k, idle=idle)
     sh = t.plonk.Shape(k, A, L, F, lb, idle)
     fpk = fp.keygen(sh, asg.fixed, asg.copies)
     vk = t.product_vk(eng, pk, sh)
@@ -56,6 +57,18 @@ def main():
     mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
     eng = t.zk.Engine(0)
     bad = 0
+    if len(sys.argv) > 3 and sys.argv[3] == "full":
+        for shape in ((1, 1, 1, 19, 18, 0), (2, 1, 1, 18, 17, 0), (4, 1, 1, 17, 16, 0), (8, 2, 1, 16, 15, 0)):
+            for i in range(count):
+                t0 = time.time()
+                try:
+                    check_mid(eng, shape, wseed=seed + 1000 * shape[3] + i)
+                    print("ok  ", shape, "witness", i, "%.1f s" % (time.time() - t0), flush=True)
+                except Exception as e:  # noqa: BLE001
+                    bad += 1
+                    print("FAIL", shape, i, repr(e)[:300], flush=True)
+        print("failures", bad)
+        return 1 if bad else 0
     shapes = mid_shapes(count, seed) if mid else t._random_shapes(count, seed)
     for shape in shapes:
         t0 = time.time()
