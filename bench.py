@@ -98,8 +98,7 @@ class ProofWorkload:
             try:
                 pl = self.pipes[q]
                 for j in jobs[q::len(self.pipes)]:
-                    pl.unload(j)
-                    pl.load(j, self.wit[j])
+                    pl.reload(j, self.wit[j])  # into the job's resident buffers: no allocation in the loop
                     out[j] = pl.prove(j, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
             except Exception as e:
                 errs.append(e)
@@ -127,9 +126,8 @@ class ProofWorkload:
         """The same with the request's advice column shipped inside the clock (16 MiB H2D + the canonical -> Montgomery
         conversion on the device): what a host that hands over host buffers per request sees.  Never `value`."""
         pl, j = self.pipes[0], self.jobs[0]
-        pl.unload(j)
         t1 = time.perf_counter()
-        pl.load(j, self.host_cols)
+        pl.reload(j, self.host_cols)
         pl.prove(j, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
         self.engs[0].sync()
         return (time.perf_counter() - t1) * 1e3

@@ -102,6 +102,16 @@ class Pipeline:
             polys.append(h)
         self.resident[job] = polys
 
+    def reload(self, job, columns):
+        """The per-request H2D into the job's EXISTING device buffers (a host that keeps its request slots: no hipMalloc /
+        hipFree — the latter waits for the whole device — between proofs); falls back to `load` for a job not yet resident."""
+        polys = self.resident.get(job)
+        if polys is None or len(polys) != len(columns):
+            self.unload(job)
+            return self.load(job, columns)
+        for h, col in zip(polys, columns):
+            self.eng.upload_canonical(h, col)
+
     def loader(self):
         """A loader context beside this pipeline (shared SRS, own stream): `stage` uploads a job's columns on it — from another
         host thread, while this pipeline proves — and `adopt` hands them over between two proofs."""
