@@ -27,13 +27,15 @@ What the scope of this repository imposes, stated where a caller
 """
 import hashlib
 import os
+import threading
 
 import numpy as np
 
 from . import circuit
 from .engine import ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM, Engine
 
-_STATE = {}  # (device) -> {"eng": Engine, "k": int, "keys": {path: (params, pk_handle)}}
+_STATE = {}  # (device) -> {"eng": Engine, "k": int, "keys": {path: (params, pk_handle)}, "slots": {columns: [[Poly]]}}
+_SLOTS_LOCK = threading.Lock()
 
 
 def _config_for(degree: int) -> circuit.CircuitParams:
@@ -53,13 +55,19 @@ def _config_for(degree: int) -> circuit.CircuitParams:
 
 def gen_srs(degree: int, device: int = 0) -> Engine:
     """halo2-base `gen_srs(k)`: ParamsKZG::setup(k, ChaCha20Rng::from_seed([0; 32])), kept resident."""
-    st = _STATE.setdefault(device, {"eng": None, "k": None, "keys": {}})
+    st = _STATE.setdefault(device, {"eng": None, "k": None, "keys": {}, "slots": {}})
     if st["eng"] is None:
         st["eng"] = Engine(device)
     if st["k"] != degree:
         for _, pk in st["keys"].values():
             st["eng"].pk_free(pk)
         st["keys"].clear()
+        with _SLOTS_LOCK:
+            for sets in st["slots"].values():
+                for polys in sets:
+                    for h in polys:
+                        h.free()
+            st["slots"].clear()
         st["eng"].srs_setup(degree, bytes(32))
         st["k"] = degree
     return st["eng"]
@@ -103,20 +111,32 @@ def create_proof_from_advice(advice_columns, proving_key_path, degree, transcrip
     little-endian limbs, one per advice column of the key's shape."""
     eng, p, pk = _resident_key(proving_key_path, degree, device)
     n = 1 << degree
-    polys = []
+    cols = []
+    for col in advice_columns:
+        col = np.ascontiguousarray(col, dtype=np.uint64)
+        if col.shape != (n, 4):
+            raise ValueError("an advice column must be an (n, 4) array of canonical limbs")
+        cols.append(col)
+    # request slots: the columns' device buffers are kept between requests (a hipFree per request would wait for the whole
+    # device, i.e. for every other request in flight on it); concurrent requests each take a set of their own
+    slots = _STATE[device]["slots"]
+    with _SLOTS_LOCK:
+        free = slots.setdefault(len(cols), [])
+        polys = free.pop() if free else None
+    if polys is None:
+        polys = [eng.poly(n) for _ in cols]
     try:
-        for col in advice_columns:
-            col = np.ascontiguousarray(col, dtype=np.uint64)
-            if col.shape != (n, 4):
-                raise ValueError("an advice column must be an (n, 4) array of canonical limbs")
-            h = eng.poly(n)
-            polys.append(h)
+        for h, col in zip(polys, cols):
             eng.upload_canonical(h, col)
         seed = rng_seed if rng_seed is not None else os.urandom(32)  # the reference draws from OsRng (ecdsa_p256.rs:362)
         return eng.prove(pk, polys, seed, transcript)
     finally:
-        for h in polys:
-            h.free()
+        with _SLOTS_LOCK:
+            if _STATE[device]["k"] == degree:
+                slots.setdefault(len(cols), []).append(polys)
+            else:  # the SRS was replaced meanwhile: these buffers belong to the old size
+                for h in polys:
+                    h.free()
 
 
 # ---- ES256 (secp256r1 ECDSA) request validation, host side -------------------------------------------
