@@ -91,13 +91,14 @@ class Pipeline:
             fixed, copies = structure(params)
         self.pk = self.eng.keygen(params, fixed, copies)
         self.resident = {}  # job -> [Poly]
+        self._spare = []    # buffers of finished jobs, reused by the next load
 
     def load(self, job, columns):
         """Ship a job's advice columns to the device (the per-request H2D of a real host)."""
         n = 1 << self.params.degree
         polys = []
         for col in columns:
-            h = self.eng.poly(n)
+            h = self._spare.pop() if self._spare else self.eng.poly(n)  # a finished job's buffer, if there is one
             self.eng.upload_canonical(h, col)
             polys.append(h)
         self.resident[job] = polys
@@ -145,12 +146,20 @@ class Pipeline:
         return proof
 
     def unload(self, job):
-        for p in self.resident.pop(job, []):
+        """The job's buffers go to the pipeline's spare list, not back to the device allocator: hipFree waits for the whole
+        device — for the other pipelines' kernels too — so a drain that freed per job would stall everybody per proof."""
+        polys = self.resident.pop(job, [])
+        room = max(0, 4 * max(1, len(polys)) - len(self._spare))  # a few request slots, not an ever-growing list
+        self._spare.extend(polys[:room])
+        for p in polys[room:]:
             p.free()
 
     def close(self):
         for job in list(self.resident):
             self.unload(job)
+        for p in self._spare:
+            p.free()
+        self._spare = []
         if getattr(self, "_loader", None) is not None:
             self._loader.close()
         self.eng.close()
