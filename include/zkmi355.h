@@ -123,6 +123,9 @@ int zk_srs_set_g2(zk_ctx* ctx, const uint64_t g2[16], const uint64_t s_g2[16]);
 
 /* ---- resident polynomials -------------------------------------------------- */
 int zk_poly_alloc(zk_ctx* ctx, size_t n, zk_poly* out);
+/* the handle dies; the memory is parked in the context (a few vectors, at most 2 GiB) for the next zk_poly_alloc of the same
+ * length, because hipFree waits for the whole device — a host that allocates and frees around every request would otherwise
+ * stall every other context of the GPU once per request */
 int zk_poly_free(zk_ctx* ctx, zk_poly p);
 /* Hand-over of a resident vector between two contexts of one device, no copy and no cross-context lock: the owner detaches
  * (its stream is drained first; the handle dies, a process-wide token is returned), the new owner attaches (new handle).  A

@@ -85,6 +85,12 @@ struct zk_ctx {
     Fr* host_small = nullptr;  // pinned, 8 elements
     // polys
     std::unordered_map<uint64_t, PolyRec> polys;
+    // vectors given back by zk_poly_free, handed out again by zk_poly_alloc for the same length: hipFree waits for the whole
+    // device (for every other context's kernels too), so a host that allocates and frees its request's columns around every
+    // proof would stall all pipelines of the GPU per request.  At most POLY_SPARE_MAX vectors / POLY_SPARE_BYTES bytes.
+    static constexpr size_t POLY_SPARE_MAX = 16, POLY_SPARE_BYTES = (size_t)2 << 30;
+    std::vector<PolyRec> poly_spare;
+    size_t poly_spare_bytes = 0;
     uint64_t next_handle = 1;
     // constants
     Fr zeta, zeta2;

@@ -354,6 +354,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (auto& kv : c->coset_points) hipFree(kv.second);
     pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
+    for (auto& r : c->poly_spare) hipFree(r.ptr);
     c->srs.reset();  // frees the bases and tables unless another context shares them
     for (int i = 0; i < zk_ctx::MSM_LANES; i++) {
         zk_ctx::MsmLane& L = c->lanes[i];
@@ -757,7 +758,21 @@ ZK_API(zk_poly_alloc, (zk_ctx* c, size_t n, zk_poly* out), (c, n, out)) {
     int rc = ctx_bind(c);
     if (rc) return rc;
     Fr* p = nullptr;
-    if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    for (size_t i = 0; i < c->poly_spare.size(); i++)
+        if (c->poly_spare[i].n == n) {  // a vector of this length given back earlier (contents undefined, as hipMalloc's)
+            p = c->poly_spare[i].ptr;
+            c->poly_spare_bytes -= n * sizeof(Fr);
+            c->poly_spare.erase(c->poly_spare.begin() + i);
+            break;
+        }
+    if (!p && hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
+        // out of memory with vectors parked: let them go and try once more
+        for (auto& r : c->poly_spare) hipFree(r.ptr);
+        c->poly_spare.clear();
+        c->poly_spare_bytes = 0;
+        (void)hipGetLastError();
+        if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    }
     const uint64_t h = c->next_handle++;
     c->polys[h] = PolyRec{p, n};
     *out = h;
@@ -770,8 +785,14 @@ ZK_API(zk_poly_free, (zk_ctx* c, zk_poly h), (c, h)) {
     PolyRec* r = find_poly(c, h);
     if (!r) return ZK_EINVAL;
     ctx_bind(c);
-    hipStreamSynchronize(c->stream);
-    hipFree(r->ptr);
+    hipStreamSynchronize(c->stream);  // nothing of this context still uses it
+    const size_t bytes = r->n * sizeof(Fr);
+    if (c->poly_spare.size() < zk_ctx::POLY_SPARE_MAX && c->poly_spare_bytes + bytes <= zk_ctx::POLY_SPARE_BYTES) {
+        c->poly_spare.push_back(*r);
+        c->poly_spare_bytes += bytes;
+    } else {
+        hipFree(r->ptr);
+    }
     c->polys.erase(h);
     return ZK_OK;
 }
