@@ -21,7 +21,10 @@ HOST = os.path.join(ROOT, "examples", "prove_host")
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["blake2b", "evm"])
 def test_cpp_host_proves_what_the_binding_proves(tmp_path, kind):
-    assert os.path.exists(HOST), "examples/prove_host is built by build.sh / __graft_entry__.build()"
+    if not os.path.exists(HOST):  # normally built by build.sh / __graft_entry__.build(); plain g++, seconds
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "prove_host.cpp"),
+                               "-L" + os.path.join(ROOT, "webauthn-halo2_amd"), "-lzkmi355",
+                               "-Wl,-rpath," + os.path.join(ROOT, "webauthn-halo2_amd"), "-o", HOST])
     k, A, L, F, lb = 10, 3, 2, 1, 8
     p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
     asg = zk.circuit.synthesize(p, 0x5EED0019)
