@@ -163,3 +163,22 @@ def test_wide_commit_at_the_24_bit_index_boundary(windowed):
     assert (eng.commit(p, 1) == eng.commit(q, 0)).all()
     p.free()
     q.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [1, 1000, (1 << 16) - 3])
+def test_wide_partial_length_msm_srs(windowed, m):
+    """zk_msm_srs with fewer scalars than the SRS has points (ParamsKZG::commit of a short polynomial) on the wide path: the
+    same point as the zero-padded full-length commitment (window tables strided by the SRS size, lanes and parts by m)."""
+    from webauthn_halo2_amd import engine as E
+    eng = windowed(16)
+    k = 16
+    n = 1 << k
+    eng.srs_setup(k)
+    a = rand_col(np.random.default_rng(77 + m), n)
+    padded = a.copy()
+    padded[m:] = 0
+    want = eng.commit(eng.poly(n, padded), E.ZK_BASIS_MONOMIAL)
+    got = cops.jac_to_affine_ints(eng.msm_srs(a[:m], E.ZK_BASIS_MONOMIAL))
+    assert got == cops.affine_arr_to_ints(want.reshape(1, 8))[0]
+    assert cops.affine_arr_to_ints(want.reshape(1, 8))[0] == tau_commit(padded)
