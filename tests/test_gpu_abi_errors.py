@@ -92,6 +92,61 @@ def test_two_contexts_two_threads():
         assert all(r == want for r in res[i])
 
 
+def test_one_context_many_threads():
+    """The ABI promises that calls on ONE context from several host threads are serialised by the context (the Rust shim keeps
+    a context per worker thread, but nothing forbids sharing one): four threads commit, transform, evaluate and prove on the
+    same context at once; every result equals the one a lone thread gets."""
+    import threading
+
+    from webauthn_halo2_amd import engine as E
+
+    k = 10
+    n = 1 << k
+    eng = zk.Engine(0)
+    eng.srs_setup(k)
+    p = zk.circuit.CircuitParams(degree=k, num_advice=2, num_lookup_advice=1, num_fixed=1, lookup_bits=8)
+    asg = zk.circuit.synthesize(p, 0x5EED0019)
+    pk = eng.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)
+    cols = [asg.to_limbs(c) for c in asg.advice]
+
+    def job(i):
+        a = cops.fr_mont([(j * (i + 3) + 1) % F.R for j in range(n)])
+        h = eng.poly(n, a)
+        out = [eng.commit(h, E.ZK_BASIS_LAGRANGE).tobytes()]
+        eng.lagrange_to_coeff(h)
+        out.append(eng.commit(h, E.ZK_BASIS_MONOMIAL).tobytes())
+        out.append(eng.eval(h, cops.fr_mont([i + 5])[0]).tobytes())
+        polys = []
+        for col in cols:
+            q = eng.poly(n)
+            eng.upload_canonical(q, col)
+            polys.append(q)
+        out.append(eng.prove(pk, polys, bytes([i]) * 32, E.ZK_TRANSCRIPT_EVM))
+        for q in polys + [h]:
+            q.free()
+        return out
+
+    want = [job(i) for i in range(4)]
+    got, errs = {}, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = job(i)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert [got[i] for i in range(4)] == want
+    assert want[0][0] == want[0][1]  # commit_lagrange(v) == commit(iNTT(v))
+    eng.close()
+
+
 def test_resident_srs_seam_is_explicit():
     """zk_msm_srs (ParamsKZG::commit / commit_lagrange of a Rust host) multiplies host scalars against the RESIDENT
     basis; zk_msm_bn254 never guesses which basis it was given and always uploads its bases — so an array the host
