@@ -384,7 +384,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes(),
                 "traffic_source": "NOT measured in this run: per-launch FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes of "
-                                  "this same command (latest profiles/*proof_k19_pmc_hbm.csv); hardware counters cannot be read in-process",
+                                  "this same command (latest profiles/*proof_k19_pmc_hbm.csv); hardware counters cannot be read in-process. "
+                                  "Calibration on the kernel's own access pattern (MI355X_MICROARCH.md, HBM): `traffic_expected` = one 64-byte "
+                                  "table gather + one 4-byte entry per bucket addition (68 B x 16 x 2^19) + one 144-byte partial sum per lane and "
+                                  "bucket, per column; the counters report ~88 % of it (part of the 512 MiB table stays in the 256 MiB Infinity "
+                                  "Cache) — 64-byte gathers are counted at full size, the 2x correction of wide streaming reads does not apply",
+                "traffic_expected": (68.0 * 16 * n + 144.0 * (n + 32768)) * cols_per_launch,
                 "avg_launch_ms": accum_ms,
                 "launches": int(acc_n),
                 "columns_per_launch": cols_per_launch,
