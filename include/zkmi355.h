@@ -133,6 +133,9 @@ int zk_poly_free(zk_ctx* ctx, zk_poly p);
  * zk_prove.  A detached vector belongs to nobody until it is attached (ZK_EINVAL: unknown token, or another device). */
 int zk_poly_detach(zk_ctx* ctx, zk_poly p, uint64_t* token);
 int zk_poly_attach(zk_ctx* ctx, uint64_t token, zk_poly* out);
+/* Frees a detached vector that will never be attached (the loader failed between staging and adoption, the target context
+ * is gone): a token that is neither attached nor discarded keeps its device memory for the life of the process. */
+int zk_poly_discard(uint64_t token);
 int zk_poly_len(zk_ctx* ctx, zk_poly p, size_t* out);
 int zk_poly_upload(zk_ctx* ctx, zk_poly p, const uint64_t* host_mont, size_t n);
 int zk_poly_download(zk_ctx* ctx, zk_poly p, uint64_t* host_mont, size_t n);

@@ -70,18 +70,24 @@ def calibrate(k=16):
     s = cops.fr_powers(TAU, n)
     bases = cops.fixed_base_g1(s)
 
-    def best(fn):
+    sweep = {}
+
+    def best(name, fn):
         res = []
         for nt in opts:
-            t0 = time.time()
-            fn(nt)
-            res.append((time.time() - t0, nt))
+            ts = []
+            for _ in range(2):  # best of two: the first call of a team size pays thread start-up
+                t0 = time.time()
+                fn(nt)
+                ts.append(time.time() - t0)
+            res.append((min(ts), nt))
+        sweep[name] = {str(nt): round(t * 1e3, 2) for t, nt in res}  # ms per call at every thread count tried: the evidence
         return min(res)[1]
 
-    NT_MSM = best(lambda nt: cops.msm(s, bases, nt))
-    NT_FFT = best(lambda nt: cops.ntt(s, omega(k), k, nt))
+    NT_MSM = best("msm_2^%d_ms" % k, lambda nt: cops.msm(s, bases, nt))
+    NT_FFT = best("fft_2^%d_ms" % k, lambda nt: cops.ntt(s, omega(k), k, nt))
     NT = min(cores, 64)
-    return {"msm_threads": NT_MSM, "fft_threads": NT_FFT, "vector_threads": NT, "host_cores": cores}
+    return {"msm_threads": NT_MSM, "fft_threads": NT_FFT, "vector_threads": NT, "host_cores": cores, "sweep": sweep}
 
 
 def m1(x):
@@ -638,7 +644,7 @@ def cpu_baseline(k, budget_s=30.0):
         return T
 
     cores = os.cpu_count() or 1
-    cal = calibrate()
+    cal = calibrate(18)  # at (nearly) the workload's size: the best team size depends on the chunk length
     t17 = one(17) if k > 17 else None
     scale = 4.0 * (k + 2) / 19.0 if k == 19 else float(1 << (k - 17))
     if t17 is None or t17["total"] * scale <= budget_s:
@@ -652,7 +658,11 @@ def cpu_baseline(k, budget_s=30.0):
     return {
         "value": 1.0 / total,
         "unit": "proofs/s",
-        "cores": max(cal["msm_threads"], cal["fft_threads"], cal["vector_threads"]),  # threads actually used (host has `host_cores`)
+        # threads actually used, per leg (the MSM leg is ~55 % of the proof's time); `cores` = the largest team.  The host has
+        # `host_cores`; `threads.sweep` holds the measured time of each leg at every team size tried ({all cores, 64, 32, 16}),
+        # i.e. why fewer than all cores are used where they are (thread-chunked Pippenger loses window efficiency on small chunks)
+        "cores": max(cal["msm_threads"], cal["fft_threads"], cal["vector_threads"]),
+        "cores_per_leg": {"msm": cal["msm_threads"], "fft": cal["fft_threads"], "vector_ops": cal["vector_threads"]},
         "threads": cal,
         "kind": "port",
         "proof_s": total,

@@ -182,3 +182,22 @@ def test_wide_partial_length_msm_srs(windowed, m):
     got = cops.jac_to_affine_ints(eng.msm_srs(a[:m], E.ZK_BASIS_MONOMIAL))
     assert got == cops.affine_arr_to_ints(want.reshape(1, 8))[0]
     assert cops.affine_arr_to_ints(want.reshape(1, 8))[0] == tau_commit(padded)
+
+
+@pytest.mark.parametrize("bits", [15, 16])
+@pytest.mark.parametrize("k", [7, 9])
+def test_window_override_below_the_workspace_floor(windowed, bits, k):
+    """A 15 / 16-bit override on an SRS shorter than the 1024-scalar workspace floor (the table builder and the
+    runner decided 'wide path' by different rules there): the override is clamped, commitments stay exact, batches work."""
+    eng = windowed(bits)
+    n = 1 << k
+    eng.srs_setup(k)
+    assert eng.srs_msm_plan()[0] <= 14
+    rng = np.random.default_rng(77 * bits + k)
+    cols = [rand_col(rng, n) for _ in range(3)]
+    polys = [eng.poly(n, c) for c in cols]
+    got = cops.affine_arr_to_ints(eng.commit_batch(polys, 0))
+    for c, g, p in zip(cols, got, polys):
+        assert g == tau_commit(c)
+        assert cops.affine_arr_to_ints(eng.commit(p, 0))[0] == g
+        p.free()

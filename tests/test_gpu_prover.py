@@ -638,6 +638,16 @@ def test_poly_detach_attach_and_staged_loading():
     assert np.array_equal(pl.eng.download(got), pl.eng.download(direct))
     got.free()
     direct.free()
+    # a staged column nobody adopts is discarded (zk_poly_discard): its token dies with it; a failed stage() discards the
+    # columns it had already detached
+    staged = pl.stage(wit[1])
+    pl.discard(staged)
+    with pytest.raises(zk.ZkError):
+        pl.eng.poly_attach(staged[0])
+    with pytest.raises(zk.ZkError):
+        ld.poly_discard(staged[0])
+    with pytest.raises(Exception):
+        pl.stage([wit[1][0], np.zeros(((1 << k) + 1, 4), dtype=np.uint64)])  # the second upload is refused (too long)
     pl.adopt(0, pl.stage(wit[0]))
     assert pl.prove(0, E.ZK_TRANSCRIPT_BLAKE2B) == want[0]
     # overlapped: a thread stages job i+1 while job i is proved

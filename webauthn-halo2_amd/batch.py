@@ -126,11 +126,26 @@ class Pipeline:
         ld = self.loader()
         n = 1 << self.params.degree
         staged = []
-        for col in columns:
-            h = ld.poly(n)
-            ld.upload_canonical(h, col)
-            staged.append(ld.poly_detach(h))
+        h = None
+        try:
+            for col in columns:
+                h = ld.poly(n)
+                ld.upload_canonical(h, col)
+                staged.append(ld.poly_detach(h))
+                h = None
+        except Exception:
+            # a later column failed: nobody will ever attach the ones already detached — give their memory back
+            if h is not None and h.h:
+                h.free()
+            for d in staged:
+                ld.poly_discard(d)
+            raise
         return staged
+
+    def discard(self, staged):
+        """Drop staged columns that will not be adopted (the request was cancelled, the pipeline is closing)."""
+        for d in staged:
+            self.loader().poly_discard(d)
 
     def adopt(self, job, staged):
         """Make staged columns this pipeline's resident advice of `job` (no copy)."""

@@ -131,6 +131,7 @@ struct zk_ctx {
 
 
 int ctx_bind(zk_ctx* c);
+void ctx_release_spares(zk_ctx* c);  // frees the vectors zk_poly_free parked (caller holds c->mu, device bound)
 int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);
 int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out);

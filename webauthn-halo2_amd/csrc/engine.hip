@@ -159,6 +159,11 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     if (!slot) {
         hipError_t e;
         slot = msm_workspace_create(want, cw, &e, table_window ? batch_for(c, want) : 1u);
+        if (!slot && e != hipErrorInvalidValue && !c->poly_spare.empty()) {
+            ctx_release_spares(c);
+            (void)hipGetLastError();
+            slot = msm_workspace_create(want, cw, &e, table_window ? batch_for(c, want) : 1u);
+        }
         if (!slot) {
             c->last_hip = (int)e;
             return e == hipErrorInvalidValue ? ZK_EINVAL : ZK_ENOMEM;
@@ -630,6 +635,7 @@ ZK_API(zk_srs_setup, (zk_ctx* c, uint32_t k, const uint8_t seed[32]), (c, k, see
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
     if (rc) return rc;
+    ctx_release_spares(c);  // parked vectors are reclaimable: give them back before the big allocations
     if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
     const uint32_t n = 1u << k;
     ChaCha20Rng rng(seed);
@@ -713,6 +719,7 @@ ZK_API(zk_srs_load, (zk_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
     if (rc) return rc;
+    ctx_release_spares(c);
     if ((rc = srs_alloc(c, k)) != ZK_OK) return rc;
     const size_t bytes = ((size_t)1 << k) * sizeof(G1Affine);
     HIPCHK(c, hipMemcpy(c->g, g, bytes, hipMemcpyHostToDevice));
@@ -747,6 +754,15 @@ ZK_API(zk_srs_msm_plan, (const zk_ctx* c, uint32_t* window_bits, uint32_t* windo
 
 // ---- resident polynomials ----------------------------------------------------
 
+// Vectors parked by zk_poly_free (up to POLY_SPARE_BYTES per context) are reclaimable memory: the large allocators
+// (zk_keygen, zk_srs_setup / load / read, zk_pk_read, the MSM workspaces) release them up front instead of failing with
+// ZK_ENOMEM while they sit idle.  Caller holds c->mu and has bound the device.
+void ctx_release_spares(zk_ctx* c) {
+    for (auto& r : c->poly_spare) hipFree(r.ptr);
+    c->poly_spare.clear();
+    c->poly_spare_bytes = 0;
+}
+
 static PolyRec* find_poly(zk_ctx* c, zk_poly h) {
     auto it = c->polys.find(h);
     return it == c->polys.end() ? nullptr : &it->second;
@@ -767,9 +783,7 @@ ZK_API(zk_poly_alloc, (zk_ctx* c, size_t n, zk_poly* out), (c, n, out)) {
         }
     if (!p && hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
         // out of memory with vectors parked: let them go and try once more
-        for (auto& r : c->poly_spare) hipFree(r.ptr);
-        c->poly_spare.clear();
-        c->poly_spare_bytes = 0;
+        ctx_release_spares(c);
         (void)hipGetLastError();
         if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     }
@@ -843,6 +857,25 @@ ZK_API(zk_poly_attach, (zk_ctx* c, uint64_t token, zk_poly* out), (c, token, out
     c->polys[nh] = d.rec;
     *out = nh;
     return ZK_OK;
+}
+
+// A detached vector that will never be attached (the loader failed between stage and adopt, the target context is gone):
+// without this the record — and its device memory — would stay in the process-wide table for the life of the process.
+ZK_API(zk_poly_discard, (uint64_t token), (token)) {
+    Detached d;
+    {
+        std::lock_guard<std::mutex> lg(g_detached_mu);
+        auto it = g_detached.find(token);
+        if (it == g_detached.end()) return ZK_EINVAL;
+        d = it->second;
+        g_detached.erase(it);
+    }
+    int prev = -1;
+    hipGetDevice(&prev);
+    if (hipSetDevice(d.device) != hipSuccess) return ZK_EHIP;
+    const hipError_t e = hipFree(d.rec.ptr);  // hipFree waits for the device: nothing still uses the vector
+    if (prev >= 0) hipSetDevice(prev);
+    return e == hipSuccess ? ZK_OK : ZK_EHIP;
 }
 
 ZK_API(zk_poly_len, (zk_ctx* c, zk_poly h, size_t* out), (c, h, out)) {

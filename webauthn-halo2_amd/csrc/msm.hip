@@ -134,6 +134,9 @@ uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     if (c < 9) c = 9;
     if (c > 16) c = 16;  // digits are int16
     if (c == 16 && !msm_wide_applies(c, n)) c = 15;  // 16-bit digits exist on the wide path only
+    // the MSM workspaces are at least 1024 scalars long (get_msm_ws), the wide path needs table stride == workspace length:
+    // below that a 15 / 16-bit override would build internal-form tables that msm_run reads on the standard path
+    if (c >= 15 && n < 1024) c = 14;
     return (uint32_t)c;
 }
 
@@ -1500,7 +1503,8 @@ __global__ void msm_table_internal_kernel(G1Affine* __restrict__ t, size_t count
     fe_store(&t[i].y, p.y);
 }
 
-bool msm_table_is_internal(uint32_t c, size_t n) { return msm_wide_applies(c, n); }
+// the same rule msm_run applies (wide workspace && table stride == workspace length; workspaces are >= 1024 long)
+bool msm_table_is_internal(uint32_t c, size_t n) { return msm_wide_applies(c, n) && n >= 1024; }
 
 hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st) {
     const uint32_t nwin = nwin_for(c);

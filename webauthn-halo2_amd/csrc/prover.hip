@@ -285,6 +285,7 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
     if (rc) return rc;
+    ctx_release_spares(c);  // parked vectors are reclaimable: give them back before the key and its workspace are allocated
     Layout lay;
     if (!lay.init(*params)) return ZK_EINVAL;
     if (n_fixed_columns != lay.n_fix) return ZK_EINVAL;  // fixed_canonical holds n_fixed_columns x n x 4 limbs

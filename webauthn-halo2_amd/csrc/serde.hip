@@ -486,6 +486,7 @@ ZK_API(zk_srs_read, (zk_ctx* c, const uint8_t* bytes, size_t len, int format), (
     if (!host_g2_read(bytes + 4 + 2 * n * gs, format, g2) || !host_g2_read(bytes + 4 + 2 * n * gs + g2_size(format), format, s_g2)) return ZK_EINVAL;
     int rc = ctx_bind(c);
     if (rc) return rc;
+    ctx_release_spares(c);  // the old SRS, its tables and the new bases are alive together below: parked vectors go first
     // decode and validate into fresh buffers: a malformed file leaves the resident SRS, its tables and the keys made under
     // it as they were (they are replaced only once every point has been accepted)
     G1Affine* fresh[2] = {nullptr, nullptr};
@@ -741,6 +742,7 @@ ZK_API(zk_pk_read, (zk_ctx* c, const zk_circuit_params* params, const uint8_t* b
         std::lock_guard<std::mutex> lk(c->mu);
         int rc = ctx_bind(c);
         if (rc) return rc;
+        ctx_release_spares(c);
         Layout lay;
         if (!lay.init(*params)) return ZK_EINVAL;
         if (c->srs_k != (int)lay.k) return ZK_ESTATE;

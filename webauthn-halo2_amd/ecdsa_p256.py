@@ -36,6 +36,7 @@ from .engine import ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM, Engine
 
 _STATE = {}  # (device) -> {"eng": Engine, "k": int, "keys": {path: (params, pk_handle)}, "slots": {columns: [[Poly]]}}
 _SLOTS_LOCK = threading.Lock()
+_MAX_SLOT_SETS = 4  # parked request-slot sets per column count: the server's usual number of requests in flight per device
 
 
 def _config_for(degree: int) -> circuit.CircuitParams:
@@ -124,7 +125,14 @@ def create_proof_from_advice(advice_columns, proving_key_path, degree, transcrip
         free = slots.setdefault(len(cols), [])
         polys = free.pop() if free else None
     if polys is None:
-        polys = [eng.poly(n) for _ in cols]
+        polys = []
+        try:
+            for _ in cols:
+                polys.append(eng.poly(n))
+        except Exception:  # a partial allocation must not leak the handles already made
+            for h in polys:
+                h.free()
+            raise
     try:
         for h, col in zip(polys, cols):
             eng.upload_canonical(h, col)
@@ -132,9 +140,12 @@ def create_proof_from_advice(advice_columns, proving_key_path, degree, transcrip
         return eng.prove(pk, polys, seed, transcript)
     finally:
         with _SLOTS_LOCK:
-            if _STATE[device]["k"] == degree:
-                slots.setdefault(len(cols), []).append(polys)
-            else:  # the SRS was replaced meanwhile: these buffers belong to the old size
+            keep = slots.setdefault(len(cols), [])
+            # at most _MAX_SLOT_SETS parked sets per column count (a set is GBs at k = 19 with many columns): more
+            # concurrent requests than that allocate and free their own
+            if _STATE[device]["k"] == degree and len(keep) < _MAX_SLOT_SETS:
+                keep.append(polys)
+            else:  # the SRS was replaced meanwhile (these buffers belong to the old size), or enough sets are parked
                 for h in polys:
                     h.free()
 

@@ -76,6 +76,7 @@ def load_library():
         "zk_poly_free": ([vp, ctypes.c_uint64], ctypes.c_int),
         "zk_poly_detach": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_poly_attach": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_poly_discard": ([ctypes.c_uint64], ctypes.c_int),
         "zk_poly_len": ([vp, ctypes.c_uint64, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_poly_upload": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
         "zk_poly_download": ([vp, ctypes.c_uint64, u64p, sz], ctypes.c_int),
@@ -331,6 +332,10 @@ class Engine:
         h = ctypes.c_uint64()
         self._chk(self.L.zk_poly_attach(self.ctx, token, ctypes.byref(h)), "zk_poly_attach")
         return Poly(self, h.value, n)
+
+    def poly_discard(self, detached):
+        """Free a detached vector that will not be attached after all (error paths of a staged load)."""
+        self._chk(self.L.zk_poly_discard(detached[0]), "zk_poly_discard")
 
     def kate_division(self, p, z_mont, q=None):
         """arithmetic::kate_division: q = (p - p(z)) / (X - z), same length as p (top coefficient 0); in place by default."""
