@@ -67,7 +67,7 @@ int zk_last_hip_error(const zk_ctx* ctx); /* raw hipError_t of the last ZK_EHIP 
 int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 /* tuning options (measurement tools, tests); value 0 restores the built-in choice.  The engine reads no
  * environment variables. */
-#define ZK_OPT_MSM_WINDOW 1          /* signed window bits of the fixed-base MSM, 9..16; takes effect at the next SRS load */
+#define ZK_OPT_MSM_WINDOW 1          /* signed window bits of the fixed-base MSM, 9..17; takes effect at the next SRS load */
 #define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..256 */
 #define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..11 (clamped to the tile) */
 #define ZK_OPT_GP_BATCH_INVERT 4     /* 1: grand products always take halo2's batch_invert form (the fallback path) */

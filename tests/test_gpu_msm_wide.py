@@ -34,7 +34,7 @@ def tau_commit(a):
     return srs.g1_of_scalar(srs.commit_scalar_monomial(cops.fr_ints(a)))
 
 
-@pytest.mark.parametrize("bits", [15, 16])
+@pytest.mark.parametrize("bits", [15, 16, 17])
 @pytest.mark.parametrize("k", [10, 13, 16])
 def test_wide_commit_matches_tau_oracle(windowed, bits, k):
     eng = windowed(bits)
@@ -83,11 +83,12 @@ def test_wide_commit_matches_tau_oracle(windowed, bits, k):
         p.free()
 
 
+@pytest.mark.parametrize("bits", [16, 17])
 @pytest.mark.parametrize("with_identity", [False, True])
-def test_wide_commit_over_degenerate_srs(windowed, with_identity):
+def test_wide_commit_over_degenerate_srs(windowed, with_identity, bits):
     """Equal points with equal scalars (doublings inside a segment), P / -P (cancellation), an SRS with the identity:
     the unchecked accumulation + redo kernel and the checked one, on the wide path's column regions."""
-    eng = windowed(16)
+    eng = windowed(bits)
     k = 10
     n = 1 << k
     rng = random.Random(4321)
@@ -103,7 +104,7 @@ def test_wide_commit_over_degenerate_srs(windowed, with_identity):
         g[700] = 0
     gl = g[::-1].copy()
     eng.srs_load(k, g, gl)
-    assert eng.srs_msm_plan()[0] == 16
+    assert eng.srs_msm_plan()[0] == bits
     s = [rng.randrange(F.R) for _ in range(n)]
     s[20] = s[21] = s[22] = 5
     for i in range(40, 60):
@@ -121,7 +122,7 @@ def test_wide_commit_over_degenerate_srs(windowed, with_identity):
     q.free()
 
 
-@pytest.mark.parametrize("bits", [15, 16])
+@pytest.mark.parametrize("bits", [15, 16, 17])
 def test_wide_commit_tau_oracle_k19(windowed, bits):
     """BASELINE size: MSM(s, SRS) == [sum s_i tau^i] G1 at 2^19, one column and a three-column pass."""
     eng = windowed(bits)
@@ -147,13 +148,15 @@ def test_wide_commit_tau_oracle_k19(windowed, bits):
         p.free()
 
 
-def test_wide_commit_at_the_24_bit_index_boundary(windowed):
-    """k = 20 is the largest SRS of the wide path: 16 windows x 2^20 points = 2^24 table entries, the index field of an entry."""
-    eng = windowed(0)
+@pytest.mark.parametrize("bits", [0, 15])
+def test_wide_commit_at_the_24_bit_index_boundary(windowed, bits):
+    """k = 20: 16 windows x 2^20 points = 2^24 table entries fill the 24-bit index field of an entry exactly (the default
+    plan there), 17 windows of 15 bits need the 25-bit layout."""
+    eng = windowed(bits)
     k = 20
     n = 1 << k
     eng.srs_setup(k)
-    assert eng.srs_msm_plan() == (16, 16)
+    assert eng.srs_msm_plan() == ((15, 17) if bits else (16, 16))
     a = rand_col(np.random.default_rng(20), n)
     a[n - 5:] = np.array([0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0x0FFFFFFFFFFFFFFF], dtype=np.uint64)  # the last points, every window
     p = eng.poly(n, a)
@@ -201,3 +204,25 @@ def test_window_override_below_the_workspace_floor(windowed, bits, k):
         assert g == tau_commit(c)
         assert cops.affine_arr_to_ints(eng.commit(p, 0))[0] == g
         p.free()
+
+
+def test_wide_commit_with_25_bit_table_indexes(windowed):
+    """k = 21 (BASELINE configs[4]): 16 windows x 2^21 points need 25 index bits per entry, which leaves 6 for the fine key
+    (64 buckets per coarse bin, 512 bins) and 5 for the distance field — the wide path's second entry layout.  Random
+    scalars, a column of 18-bit values (hot low buckets, most first-of-bucket entries escape) and the last points."""
+    eng = windowed(0)
+    k = 21
+    n = 1 << k
+    eng.srs_setup(k)
+    assert eng.srs_msm_plan() == (16, 16)
+    rng = np.random.default_rng(0x5EED0021)
+    a = rand_col(rng, n)
+    a[n - 3:] = np.array([0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0x0FFFFFFFFFFFFFFF], dtype=np.uint64)
+    b = rand_col(rng, n)
+    b[:, 1:] = 0
+    b[:, 0] &= 0x3FFFF
+    pa, pb = eng.poly(n, a), eng.poly(n, b)
+    assert cops.affine_arr_to_ints(eng.commit(pa, 0))[0] == tau_commit(a)
+    assert cops.affine_arr_to_ints(eng.commit(pb, 0))[0] == tau_commit(b)
+    pa.free()
+    pb.free()

@@ -43,6 +43,7 @@ struct zk_ctx {
     std::map<uint32_t, Fr*> twiddles;      // log_n -> w_{2^log_n}^i table (standard form: quotient, permutation kernels)
     std::map<uint32_t, Fr*> coset_points;  // zeta * w^i (standard form): the x of the quotient's permutation terms
     std::map<uint32_t, Fr*> twiddles_ntt;  // the same powers in the NTT's internal form (x 2^261, ntt.hip)
+    std::map<uint32_t, Fr*> twiddles_ninv; // w^i / 2^log_n (standard form): the last pass of an inverse transform (ntt.hip NTT_FOLD)
     // SRS (the pointers below alias the members of `srs`, the owner)
     std::shared_ptr<SrsBlock> srs;
     int srs_k = -1;
@@ -135,6 +136,7 @@ void ctx_release_spares(zk_ctx* c);  // frees the vectors zk_poly_free parked (c
 int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);
 int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out);
+int ctx_get_twiddles_ninv(zk_ctx* c, uint32_t log_n, const Fr** out);
 int ctx_get_coset_points(zk_ctx* c, uint32_t log_n, const Fr** out);  // zeta * w^i: the points of the extended coset
 // MSM of device-resident scalars against device-resident bases -> Jacobian on host (synchronises)
 int ctx_msm_device(zk_ctx* c, const Fr* d_scalars, const G1Affine* d_bases, size_t n, G1Jac* out);

@@ -21,6 +21,10 @@ struct NttJob {
     const Fr* srcs[NTT_MAX_BATCH];
     Fr* dsts[NTT_MAX_BATCH];
     const Fr* tw;       // twiddle table in the NTT's internal form: w^i * 2^261 mod p, i < 2^log_n (launch_twiddles_internal)
+    // optional: c * w^i in the STANDARD form (c = 1, or post[0] when tw_last_has_post): lets the last pass of a multi-pass
+    // transform fold the final conversion (and a uniform output scaling) into its inter-pass twiddles (ntt.hip NTT_FOLD)
+    const Fr* tw_last;
+    uint32_t tw_last_has_post;
     uint32_t log_n;
     uint32_t inverse;   // use w^-1
     uint32_t n_in, n_out;
@@ -30,6 +34,7 @@ struct NttJob {
 };
 hipError_t ntt_run(const NttJob& job, hipStream_t st);
 void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);           // w^i, standard Montgomery form
+void launch_twiddles_scaled(Fr* tw, const Fr& w, const Fr& scale, uint32_t n, hipStream_t st);  // scale * w^i, standard form
 void launch_twiddles_internal(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);  // w^i * 2^261 (plain words): ntt.hip's own form
 int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
 

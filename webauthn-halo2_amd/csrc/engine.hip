@@ -84,6 +84,22 @@ int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out) {
     return ZK_OK;
 }
 
+int ctx_get_twiddles_ninv(zk_ctx* c, uint32_t log_n, const Fr** out) {
+    auto it = c->twiddles_ninv.find(log_n);
+    if (it != c->twiddles_ninv.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    if (log_n > 28) return ZK_EINVAL;
+    Fr* tw = nullptr;
+    const size_t n = (size_t)1 << log_n;
+    if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    launch_twiddles_scaled(tw, fr_omega(log_n), fe_inv(fr_from_u64(n)), (uint32_t)n, c->stream);
+    c->twiddles_ninv[log_n] = tw;
+    *out = tw;
+    return ZK_OK;
+}
+
 namespace zk {
 void launch_scale(Fr* a, const Fr& c, uint32_t n, hipStream_t st);
 }
@@ -356,6 +372,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
+    for (auto& kv : c->twiddles_ninv) hipFree(kv.second);
     for (auto& kv : c->coset_points) hipFree(kv.second);
     pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
@@ -439,7 +456,7 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
     std::lock_guard<std::mutex> lk(c->mu);
     switch (option) {
         case ZK_OPT_MSM_WINDOW:
-            if (value && (value < 9 || value > 16)) return ZK_EINVAL;
+            if (value && (value < 9 || value > 17)) return ZK_EINVAL;
             c->opt_msm_window = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_MSM_BATCH:
@@ -550,7 +567,8 @@ ZK_API(zk_ntt_bn254_fr, (zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32
     job.inverse = inverse;
     job.n_in = job.n_out = (uint32_t)n;
     job.max_log_r = c->opt_ntt_max_r;
-    if (hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
+    if (!own_tw && log_n > 7) rc = ctx_get_twiddles(c, log_n, &job.tw_last);  // best_fft does not scale: c = 1 in both directions
+    if (rc == ZK_OK && hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     if (rc == ZK_OK) {
         hipEventRecord(c->ev[ZK_T_NTT][0], c->stream);
         hipError_t e = ntt_run(job, c->stream);
@@ -1006,6 +1024,16 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
     job.n_in = (uint32_t)(src_n < N ? src_n : N);
     job.n_out = (uint32_t)n_out;
     job.max_log_r = c->opt_ntt_max_r;
+    if (log_n > 7) {
+        // two or more passes: the last one folds the conversion to the standard form (and the 1/N of a plain inverse
+        // transform) into its inter-pass twiddles, read from a standard-form table (ntt.hip NTT_FOLD)
+        if (!inverse) rc = ctx_get_twiddles(c, log_n, &job.tw_last);
+        else if (!coset) {
+            rc = ctx_get_twiddles_ninv(c, log_n, &job.tw_last);
+            job.tw_last_has_post = 1;
+        }
+        if (rc) return rc;
+    }
     if (!inverse && coset) {  // coeff_to_extended: a_i *= zeta^(i mod 3)
         job.has_pre = 1;
         job.pre[0] = Fr::one();

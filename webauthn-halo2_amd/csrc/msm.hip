@@ -54,7 +54,7 @@ namespace zk {
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t SKIP_ENTRY = 0xffffffffu;  // padding entry (no base)
 // wide path: an entry is sign << 31 | first-of-bucket << 30 | delta << 24 | table index (24 bits)
-static constexpr uint32_t WIDE_FLAG = 0x40000000u, WIDE_IDX = 0x00ffffffu, WIDE_ESC = 63;
+static constexpr uint32_t WIDE_FLAG = 0x40000000u;  // index bits ib = 24 .. 26 (WideGeo): delta field [ib, 30), escape = all ones
 static constexpr uint32_t CHUNK = 16384;  // scalars per histogram / scatter workgroup
 static constexpr uint32_t SORT_LDS_BUCKETS = 8192;  // 32 KiB of LDS counters per sort workgroup
 #ifndef ZK_SEG0  // build-time tuning knobs (tools/ab_variants.sh)
@@ -104,6 +104,8 @@ struct MsmWorkspace {
     G1X* bit_sum;               // [nwin * c]
     // wide path (15 / 16-bit windows, fixed-base mode): per-column regions
     bool wide;
+    bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
+    uint32_t w_ib, w_fb;        // entry layout: table index bits, fine key bits (msm_wide_shape)
     size_t w_ent_stride;        // entries per column region (multiple of 64)
     uint32_t w_lane_stride;     // accumulation lanes per column region
     uint32_t w_slot_stride;     // slots per column region: lanes + buckets
@@ -118,10 +120,29 @@ struct MsmWorkspace {
 };
 
 static inline uint32_t nwin_for(uint32_t c) { return 254 / c + 1; }
-// the wide path (below): 15 / 16-bit windows over a resident basis whose window table indexes fit 24 bits
-static bool msm_wide_applies(uint32_t c, size_t table_stride) {
-    return c >= 15 && c <= 16 && (uint64_t)nwin_for(c) * table_stride <= (1u << 24);
+// smallest log2(n) that takes 17-bit windows by default.  99 = never: measured end to end (round 4, tools/bench_ab.sh, same box,
+// new head in both): 17 bits make the accumulation 6 % shorter (0.627 against 0.666 ms per launch: 15 additions per scalar
+// instead of 16) and the proof NOT faster — 94.2 / 94.7 proofs/s against 95.7 / 95.5 at 16 bits, single proof 12.3 against 12.0 ms:
+// twice the buckets (65 536) double the row / column sums and the parts of the reduction tail, which run at one or two waves per
+// SIMD.  The 17-bit plan stays selectable (ZK_OPT_MSM_WINDOW = 17) and tested.
+#ifndef ZK_W17_MIN_LG
+#define ZK_W17_MIN_LG 99
+#endif
+// the wide path (below): 15 / 16 / 17-bit windows over a resident basis.  An entry holds the table index in ib = 24 .. 26 bits
+// and a fine key of fb = 31 - ib bits (at most 7); the buckets / 2^fb coarse bins must not exceed 512
+static bool msm_wide_shape(uint32_t c, size_t table_stride, uint32_t* ib_out, uint32_t* fb_out) {
+    if (c < 15 || c > 17 || table_stride == 0) return false;
+    const uint64_t idx = (uint64_t)nwin_for(c) * table_stride;
+    uint32_t ib = 24;
+    while (((uint64_t)1 << ib) < idx) ib++;
+    if (ib > 26) return false;
+    const uint32_t fb = 31 - ib > 7 ? 7 : 31 - ib;
+    if (((1u << (c - 1)) >> fb) > 512) return false;
+    if (ib_out) *ib_out = ib;
+    if (fb_out) *fb_out = fb;
+    return true;
 }
+static bool msm_wide_applies(uint32_t c, size_t table_stride) { return msm_wide_shape(c, table_stride, nullptr, nullptr); }
 uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -129,11 +150,12 @@ uint32_t msm_auto_window(size_t n, uint32_t override_c) {
     // windows at 2^16 .. 2^20 (16 bucket additions per scalar instead of 20 / 22: k = 19 single proof 13.7 -> 12.3 ms, k = 18
     // 10.3 -> 9.2, k = 17 7.5 -> 6.95 ms and 160 -> 169 proofs/s, k = 16 7.4 -> 7.0); below, lg - 5 bits on the 13-bit plan (k = 15:
     // 7.0 ms against 7.6 / 7.9 with 15 / 16 bits); 2^21 and up (window table indexes beyond 24 bits) 15 bits on the swept sort
-    int c = lg >= 21 ? 15 : (lg >= 16 ? 16 : (int)lg - 5);
+    // round 4: 16 bits also at 2^21 (table indexes of 25 bits; was: 15 bits on the swept sort); 17 bits only on request (below)
+    int c = lg >= 22 ? 15 : (lg == 21 ? 16 : (lg >= ZK_W17_MIN_LG ? 17 : (lg >= 16 ? 16 : (int)lg - 5)));
     if (override_c) c = (int)override_c;  // zk_ctx_set_option(ZK_OPT_MSM_WINDOW)
     if (c < 9) c = 9;
-    if (c > 16) c = 16;  // digits are int16
-    if (c == 16 && !msm_wide_applies(c, n)) c = 15;  // 16-bit digits exist on the wide path only
+    if (c > 17) c = 17;
+    while (c > 15 && !msm_wide_applies(c, n)) c--;  // 16 / 17-bit digits exist on the wide path only
     // the MSM workspaces are at least 1024 scalars long (get_msm_ws), the wide path needs table stride == workspace length:
     // below that a 15 / 16-bit override would build internal-form tables that msm_run reads on the standard path
     if (c >= 15 && n < 1024) c = 14;
@@ -963,8 +985,6 @@ __global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __res
 //     [rows = nb / 256][256] is summed along its rows and along its columns, one wave each —
 //     sum_b (b + 1) B_b = 256 sum_h h R_h + sum_l (l + 1) C_l — and (T3) the short weighted sums over h and l + 1 are
 //     taken bit by bit (log2(rows) + 9 tree reductions per column); the host runs the 16-step Horner.
-static constexpr uint32_t WIDE_FB = 7;    // fine key bits: 128 buckets per coarse bin
-static constexpr uint32_t WIDE_KEYS = 1u << WIDE_FB;
 // slots per part (T1's serial run), a per-pass parameter.  8 everywhere: lane-serial additions are the cheap ones (every lane
 // busy); shorter runs for a lone column — whose tail is exposed latency — were measured (tools/single_ab.py, k = 19 single
 // proof): 8: 12.37-12.41 ms, 4: 12.41-12.49, 2: 12.55-12.60 (more waves and more tree levels cost what the shorter chain saves)
@@ -976,7 +996,7 @@ static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = ZK_WCAP_BATCH;  // WCAP_MIN
 #define ZK_WCAP_ONE 8
 #endif
 static inline uint32_t wcap_for(uint32_t batch) { return batch == 1 ? (uint32_t)ZK_WCAP_ONE : WCAP_BATCH; }
-static constexpr uint32_t WIDE_SUMS = 16; // bit sums per column handed to the host: 9 column bits, then up to 7 row bits
+static constexpr uint32_t WIDE_SUMS = 20; // bit sums per column handed to the host: 9 column bits, then up to 8 row bits (65 536 buckets)
 #ifndef ZK_WL
 #define ZK_WL 16
 #endif
@@ -988,133 +1008,200 @@ static constexpr uint32_t WL = ZK_WL;
 // slots of a bucket whose cnt > 0 entries start at position s of the column's entry list: one per lane that holds some of them
 __device__ __forceinline__ uint32_t wide_slot_count(uint32_t s, uint32_t cnt) { return cnt ? (s + cnt - 1) / WL - s / WL + 1 : 0; }
 
-// signed digits in [-half, half): the 16-bit window's digits fit int16 (the last window never carries: a scalar is < 2^254)
-__device__ __forceinline__ void msm_digits_wide(const uint32_t* L, uint32_t c, uint32_t nwin, uint32_t i, uint32_t stride,
-                                                int16_t* __restrict__ digits, uint32_t* hist) {
-    const uint32_t half = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < nwin; w++) {
-        const uint32_t bit = w * c, word = bit >> 5, off = bit & 31;
-        uint32_t raw = 0;
-        if (word < 8) {
-            const uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
-            raw = (uint32_t)(two >> off) & mask;
-        }
-        raw += carry;
-        int32_t d;
-        if (raw >= half) {
-            d = (int32_t)raw - (int32_t)(1u << c);
-            carry = 1;
-        } else {
-            d = (int32_t)raw;
-            carry = 0;
-        }
-        digits[(size_t)w * stride + i] = (int16_t)d;
-        if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1) >> WIDE_FB], 1u);
+// ---- the wide path's head (round 4): digits in registers, windows of 15 / 16 / 17 bits, table indexes of 24 .. 26 bits ----
+// What changed against the round-3 head (digit planes in int16, a kernel per scan):
+//   * signed digits without a carry chain: with K = sum_w 2^(c - 1 + w c) the unsigned windows u_w of s + K give
+//     d_w = u_w - 2^(c-1) in [-2^(c-1), 2^(c-1)) with sum_w d_w 2^(w c) = s — the same digits as the carry recoding (the
+//     expansion with all digits in that range is unique), but window w needs nothing from window w - 1.  So the digits are
+//     recomputed from the scalar wherever they are needed and the int16 digit planes (and their 16-bit limit) are gone;
+//   * 17-bit windows: 15 bucket additions per scalar instead of 16 (65 536 buckets per column, 512 coarse bins);
+//   * an entry's table index takes ib = 24 .. 26 bits (16 windows x 2^21 points need 25), the fine key / distance fields
+//     the rest: fb = 31 - ib fine bits (128 / 64 / 32 buckets per coarse bin), 30 - ib distance bits;
+//   * the coarse scan is the prologue of the first scatter (every workgroup scans the <= 512 bin totals itself, workgroup
+//     0 publishes the header), the reset of the counters is the epilogue of the last tail kernel.
+static constexpr uint32_t WCB = 512;                  // coarse bins at most (65 536 buckets / 128, or 32 768 / 64)
+static constexpr uint32_t WHDR = 5 * (WCB + 1);       // per column: bin starts, chunk prefix, append cursors, (unused), part regions
+static constexpr uint32_t WSUB = 256 * 17;            // entries of a scatter sub-round: 256 scalars x all their windows (<= 17)
+
+struct WideGeo {
+    uint32_t c, nwin, nb;   // window bits, windows, buckets per column
+    uint32_t ib, fb, bins;  // table index bits, fine key bits, coarse bins = nb >> fb
+    uint32_t K[8];          // the recoding bias sum_w 2^(c - 1 + w c)
+};
+
+// u = (s + K) as 9 words (canonical s: the Montgomery image is taken off here)
+__device__ __forceinline__ void wide_biased(const Fr& mont, const WideGeo& g, uint32_t (&u)[9]) {
+    const Fr s = fe_from_mont(mont);
+    uint64_t cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        cy += (uint64_t)s.v[k] + g.K[k];
+        u[k] = (uint32_t)cy;
+        cy >>= 32;
     }
+    u[8] = (uint32_t)cy;  // 0: s + K < 2^256 (see msm_wide_geo)
+}
+// digit w of the biased scalar: C, w compile-time -> static register indexing
+template <uint32_t C>
+__device__ __forceinline__ int32_t wide_digit(const uint32_t (&u)[9], uint32_t w) {
+    const uint32_t bit = w * C, word = bit >> 5, off = bit & 31;
+    const uint64_t two = (uint64_t)u[word] | ((uint64_t)u[word + 1] << 32);
+    return (int32_t)((uint32_t)(two >> off) & ((1u << C) - 1)) - (int32_t)(1u << (C - 1));
 }
 
-// digits + the workgroup's coarse histogram (bucket >> 7): its range inside every coarse bin of `inter` is reserved with one
-// returning atomic per bin on the append cursors, which end up holding the bins' totals.  The per-bucket totals are counted
-// later, bin by bin, from the sorted intermediate list (msm_binscan_kernel): 32768 counters per workgroup here would cost
-// 6.7 M global atomics per 2^19 column (measured: 117 us for this kernel against 31 us at 4096 buckets).
-__global__ __launch_bounds__(256) void msm_recode_coarse_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c, uint32_t nwin,
-                                                                uint32_t nb, int16_t* __restrict__ digits_all,
-                                                                uint32_t* __restrict__ coarse_all, uint32_t coarse_stride) {
-    __shared__ uint32_t hist[CBINS_MAX];
-    __shared__ uint32_t limbs[256 * 9];
+// exclusive scan of f(in[k]), k < bins <= 512, by ONE wave (eight consecutive bins per lane): out[k], out[bins] = total
+template <class F>
+__device__ __forceinline__ void wide_wave_scan(const uint32_t* in, uint32_t bins, uint32_t* out, F f) {
+    const uint32_t lane = threadIdx.x & 63, k0 = lane * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v[j] = k0 + j < bins ? f(in[k0 + j]) : 0;
+        s += v[j];
+    }
+    uint32_t x = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if ((int)lane >= off) x += y;
+    }
+    uint32_t run = x - s;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (k0 + j < bins) out[k0 + j] = run;
+        run += v[j];
+    }
+    if (lane == 63) out[bins] = x;
+}
+
+// H1: coarse histogram of a workgroup's FCHUNK scalars (all windows) and the reservation of its range inside every coarse
+// bin of `inter`: one returning atomic per non-empty bin on the append cursors, which end up holding the bins' totals
+template <uint32_t C>
+__global__ __launch_bounds__(256) void msm_whist_kernel(MsmBatch batch, uint32_t n, WideGeo g, uint32_t* __restrict__ coarse_all,
+                                                        uint32_t coarse_stride) {
+    __shared__ uint32_t hist[WCB];
+    constexpr uint32_t NWIN = 254 / C + 1;
     const uint32_t col = blockIdx.y;
     const Fr* __restrict__ scalars = batch.s[col];
-    int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
     uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    uint32_t* L = limbs + threadIdx.x * 9;
-    hist[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < g.bins; b += 256) hist[b] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const Fr s = fe_from_mont(fe_load(scalars + i));
+        uint32_t u[9];
+        wide_biased(fe_load(scalars + i), g, u);
 #pragma unroll
-        for (int k = 0; k < 8; k++) L[k] = s.v[k];
-        L[8] = 0;
-        msm_digits_wide(L, c, nwin, i, stride, digits, hist);
+        for (uint32_t w = 0; w < NWIN; w++) {
+            const int32_t d = wide_digit<C>(u, w);
+            if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1) >> g.fb], 1u);
+        }
     }
     __syncthreads();
-    if (threadIdx.x < (nb >> WIDE_FB)) {
-        const uint32_t sum = hist[threadIdx.x];
-        chdr[COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX + threadIdx.x] = sum ? atomicAdd(&chdr[2 * (CBINS_MAX + 1) + threadIdx.x], sum) : 0;
+    for (uint32_t b = threadIdx.x; b < g.bins; b += 256) {
+        const uint32_t sum = hist[b];
+        chdr[WHDR + (size_t)blockIdx.x * WCB + b] = sum ? atomicAdd(&chdr[2 * (WCB + 1) + b], sum) : 0;
     }
 }
 
-// per column (blockIdx.x), from the bins' totals (the append cursors): the bins' places in `inter` — and in the final entry
-// list, which is as dense —, the chunk prefix of the second sort level, and the bins' REGIONS of the part list, sized for
-// the worst case (every bucket of a bin one slot and one part more than its share) — the parts inside a region are laid out
-// by msm_binscan_kernel once the per-bucket totals are known.  counts[4 col] = entries, counts[4 col + 2] = the end of the
-// last part region.
-__global__ __launch_bounds__(64) void msm_scan_coarse_wide_kernel(uint32_t* __restrict__ coarse_all, uint32_t coarse_stride,
-                                                                  uint32_t bins, uint32_t* __restrict__ counts, uint32_t WCAP) {
-    constexpr uint32_t CB = CBINS_MAX + 1;
-    uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
-    // one wave, four consecutive bins per lane: exclusive scans of three quantities
-    const uint32_t k0 = threadIdx.x * 4;
-    uint32_t v[4][3];  // [bin][entries, chunks, part region]
-    uint32_t s3[3] = {0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t t = k0 + j < bins ? c[2 * CB + k0 + j] : 0;
-        v[j][0] = t;
-        v[j][1] = (t + SUB - 1) / SUB;
-        v[j][2] = t ? (t / WL + 2 * WIDE_KEYS + WCAP - 1) / WCAP + WIDE_KEYS : 0;
-#pragma unroll
-        for (int q = 0; q < 3; q++) s3[q] += v[j][q];
-    }
-    uint32_t x[3] = {s3[0], s3[1], s3[2]};
-    for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const uint32_t y = __shfl_up(x[q], off);
-            if ((int)threadIdx.x >= off) x[q] += y;
+struct WSortLds {
+    uint32_t cnt[WCB], lstart[WCB + 1], gbase[WCB];
+    uint32_t sorted[WSUB];
+    uint16_t kid[WSUB];
+};
+
+// H2: level 1 of the sort.  Prologue: the bins' places in `inter` from the totals H1 left in the append cursors (every
+// workgroup scans them itself; workgroup 0 of a column also publishes the header the later kernels read: bin starts, the
+// chunk prefix of level 2, the bins' part regions — sized for the worst case, every bucket of a bin one slot and one part
+// more than its share — and counts[4 col] = entries, counts[4 col + 2] = the end of the last part region).  Then, 256
+// scalars at a time: digits in registers, entries sorted in LDS by coarse bin, runs appended to the workgroup's ranges.
+template <uint32_t C>
+__global__ __launch_bounds__(256) void msm_wscatter1_kernel(MsmBatch batch, uint32_t n, WideGeo g, uint32_t table_stride,
+                                                            uint32_t* __restrict__ coarse_all, uint32_t coarse_stride,
+                                                            uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                            uint32_t* __restrict__ counts, uint32_t WCAP) {
+    __shared__ WSortLds S;
+    constexpr uint32_t NWIN = 254 / C + 1;
+    constexpr uint32_t CB = WCB + 1;
+    const uint32_t col = blockIdx.y;
+    const Fr* __restrict__ scalars = batch.s[col];
+    uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    const uint32_t* __restrict__ cbase = chdr + WHDR + (size_t)blockIdx.x * WCB;
+    uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
+    const uint32_t bins = g.bins, keys = 1u << g.fb;
+    const uint32_t* __restrict__ tot = chdr + 2 * CB;
+    if (threadIdx.x < 64) {
+        wide_wave_scan(tot, bins, S.lstart, [](uint32_t t) { return t; });
+        if (blockIdx.x == 0) {
+            wide_wave_scan(tot, bins, chdr, [](uint32_t t) { return t; });
+            wide_wave_scan(tot, bins, chdr + CB, [](uint32_t t) { return (t + SUB - 1) / SUB; });
+            wide_wave_scan(tot, bins, chdr + 4 * CB, [&](uint32_t t) { return t ? (t / WL + 2 * keys + WCAP - 1) / WCAP + keys : 0u; });
         }
     }
-    uint32_t run[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) run[q] = x[q] - s3[q];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (k0 + j < bins) {
-            c[k0 + j] = run[0];
-            c[CB + k0 + j] = run[1];
-            c[4 * CB + k0 + j] = run[2];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) run[q] += v[j][q];
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) S.gbase[b] = S.lstart[b] + cbase[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counts[4 * col] = S.lstart[bins];
+        counts[4 * col + 2] = chdr[4 * CB + bins];  // written by this wave above (same lane 63 -> memory; read back after the barrier)
     }
-    if (threadIdx.x == 63) {
-        c[bins] = x[0];
-        c[CB + bins] = x[1];
-        c[4 * CB + bins] = x[2];
-        counts[4 * blockIdx.x] = x[0];
-        counts[4 * blockIdx.x + 2] = x[2];
+    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
+        __syncthreads();  // gbase / the previous round's lstart, kid, sorted are free
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) S.cnt[b] = 0;
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t ent[NWIN], meta[NWIN];  // meta = key << 16 | rank, 0xffffffff = no entry
+#pragma unroll
+        for (uint32_t w = 0; w < NWIN; w++) meta[w] = 0xffffffffu;
+        if (i < hi) {
+            uint32_t u[9];
+            wide_biased(fe_load(scalars + i), g, u);
+#pragma unroll
+            for (uint32_t w = 0; w < NWIN; w++) {
+                const int32_t d = wide_digit<C>(u, w);
+                if (d != 0) {
+                    const uint32_t bkt = (uint32_t)(d < 0 ? -d : d) - 1;
+                    const uint32_t key = bkt >> g.fb;
+                    ent[w] = (w * table_stride + i) | ((bkt & (keys - 1)) << g.ib) | (d < 0 ? SIGN_BIT : 0);
+                    meta[w] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) wide_wave_scan(S.cnt, bins, S.lstart, [](uint32_t t) { return t; });
+        __syncthreads();
+#pragma unroll
+        for (uint32_t w = 0; w < NWIN; w++)
+            if (meta[w] != 0xffffffffu) {
+                const uint32_t key = meta[w] >> 16, pos = S.lstart[key] + (meta[w] & 0xffffu);
+                S.sorted[pos] = ent[w];
+                S.kid[pos] = (uint16_t)key;
+            }
+        __syncthreads();
+        const uint32_t total = S.lstart[bins];
+        for (uint32_t q = threadIdx.x; q < total; q += 256) {
+            const uint32_t key = S.kid[q];
+            inter[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) S.gbase[b] += S.cnt[b];
     }
 }
 
 // per-bucket totals from the sorted intermediate list: one workgroup per chunk (<= SUB entries) of a coarse bin — the
-// decomposition of the second sort level — counts its entries per fine key in LDS and adds the 128 counts to totals[]
-// (zeroed by the clear kernel).  Chunks, not whole bins: witness-like columns put most of their entries into a few bins
+// decomposition of the second sort level — counts its entries per fine key in LDS and adds the counts to totals[]
+// (zero at the start of a pass).  Chunks, not whole bins: witness-like columns put most of their entries into a few bins
 // (a permuted lookup column at k = 19: 400 K entries in bin 0 — one workgroup needed 200 us for them).
-__global__ __launch_bounds__(256) void msm_finehist_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                           const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
-                                                           uint32_t* __restrict__ totals_all) {
-    __shared__ uint32_t hist[WIDE_KEYS];
+__global__ __launch_bounds__(256) void msm_wfinehist_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                            const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
+                                                            uint32_t* __restrict__ totals_all) {
+    __shared__ uint32_t hist[128];
     __shared__ uint32_t s_bin, s_chunk;
-    const uint32_t col = blockIdx.y;
+    const uint32_t col = blockIdx.y, keys = 1u << g.fb;
     const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    const uint32_t bins = nb >> WIDE_FB;
-    const uint32_t* cpre = chdr + (CBINS_MAX + 1);
-    if (blockIdx.x >= cpre[bins]) return;  // the grid is sized for the worst case
+    const uint32_t* cpre = chdr + (WCB + 1);
+    if (blockIdx.x >= cpre[g.bins]) return;  // the grid is sized for the worst case
     if (threadIdx.x == 0) {
-        uint32_t lo = 0, hi = bins;  // the bin whose chunk range holds blockIdx.x
+        uint32_t lo = 0, hi = g.bins;  // the bin whose chunk range holds blockIdx.x
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (cpre[mid] <= blockIdx.x) lo = mid;
@@ -1123,39 +1210,44 @@ __global__ __launch_bounds__(256) void msm_finehist_kernel(const uint32_t* __res
         s_bin = lo;
         s_chunk = blockIdx.x - cpre[lo];
     }
-    if (threadIdx.x < WIDE_KEYS) hist[threadIdx.x] = 0;
+    if (threadIdx.x < keys) hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t bin = s_bin;
     const uint32_t beg = chdr[bin] + s_chunk * SUB;
     const uint32_t end = min(chdr[bin + 1], beg + SUB);
-    for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&hist[(inter[p] >> 24) & (WIDE_KEYS - 1)], 1u);
+    for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&hist[(inter[p] >> g.ib) & (keys - 1)], 1u);
     __syncthreads();
-    if (threadIdx.x < WIDE_KEYS) {
+    if (threadIdx.x < keys) {
         const uint32_t cnt = hist[threadIdx.x];
-        if (cnt) atomicAdd(&totals_all[(size_t)col * nb + bin * WIDE_KEYS + threadIdx.x], cnt);
+        if (cnt) atomicAdd(&totals_all[(size_t)col * g.nb + bin * keys + threadIdx.x], cnt);
     }
 }
 
-// one workgroup (two waves: a lane per bucket) per (coarse bin, column): the bin-local scans of the per-bucket totals:
-// bstart[b] (the bucket's place in the column's dense entry list), delta[b] (distance from the previous non-empty bucket of
-// the bin minus one, WIDE_ESC for a bin's first one or a longer gap: what the bucket's first entry tells the lane that runs
-// into it), lane_b[] (the bucket a lane starts in), pstart[b] / pbucket[] (the bucket's parts of at most WCAP slots, T1) and
-// the no-part markers at the end of the bin's part region.
-__global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
-                                                          const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
-                                                          uint8_t* __restrict__ delta_all, uint32_t* __restrict__ lane_b_all,
-                                                          uint32_t lane_stride, uint32_t* __restrict__ pstart_all,
-                                                          uint32_t* __restrict__ pbucket_all, uint32_t part_stride, uint32_t WCAP) {
+// one workgroup (a lane per bucket: 128 / 64 / 32 lanes) per (coarse bin, column): the bin-local scans of the per-bucket
+// totals: bstart[b] (the bucket's place in the column's dense entry list), delta[b] (distance from the previous non-empty
+// bucket of the bin minus one, `esc` for a bin's first one or a longer gap: what the bucket's first entry tells the lane that
+// runs into it), lane_b[] (the bucket a lane starts in), pstart[b] / pbucket[] (the bucket's parts of at most WCAP slots, T1)
+// and the no-part markers at the end of the bin's part region.
+__global__ __launch_bounds__(128) void msm_wbinscan_kernel(const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
+                                                           const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
+                                                           uint8_t* __restrict__ delta_all, uint32_t* __restrict__ lane_b_all,
+                                                           uint32_t lane_stride, uint32_t* __restrict__ pstart_all,
+                                                           uint32_t* __restrict__ pbucket_all, uint32_t part_stride, uint32_t WCAP) {
     __shared__ uint32_t wsum[4];
     __shared__ int wlast[2];
-    constexpr uint32_t CB = CBINS_MAX + 1;
-    const uint32_t col = blockIdx.y, bin = blockIdx.x;
+    constexpr uint32_t CB = WCB + 1;
+    const uint32_t col = blockIdx.y, bin = blockIdx.x, nb = g.nb, keys = blockDim.x;  // blockDim.x = 1 << fb
+    const uint32_t esc = (1u << (30 - g.ib)) - 1;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     uint32_t* __restrict__ pbucket = pbucket_all + (size_t)col * part_stride;
     uint32_t* __restrict__ lane_b = lane_b_all + (size_t)col * lane_stride;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t b = bin * WIDE_KEYS + threadIdx.x;
+    const uint32_t top = min(63u, keys - 1);  // the last lane of a wave of this workgroup
+    const uint32_t b = bin * keys + threadIdx.x;
     const uint32_t cnt = totals_all[(size_t)col * nb + b];
+    if (threadIdx.x < 4) wsum[threadIdx.x] = 0;
+    if (threadIdx.x < 2) wlast[threadIdx.x] = -1;
+    __syncthreads();
     // exclusive scan of the counts -> place in the entry list
     uint32_t xe = cnt;
     int last = cnt ? (int)threadIdx.x : -1;  // inclusive running maximum: the last non-empty bucket up to this one
@@ -1167,7 +1259,7 @@ __global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __rest
             last = max(last, yl);
         }
     }
-    if (lane == 63) {
+    if (lane == top) {
         wsum[2 * wave] = xe;
         wlast[wave] = last;
     }
@@ -1185,7 +1277,7 @@ __global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __rest
         const uint32_t yp = __shfl_up(xp, off);
         if ((int)lane >= off) xp += yp;
     }
-    if (lane == 63) wsum[2 * wave + 1] = xp;
+    if (lane == top) wsum[2 * wave + 1] = xp;
     __syncthreads();
     const uint32_t pbase = chdr[4 * CB + bin], pend = chdr[4 * CB + bin + 1];
     const uint32_t p_used = wsum[1] + wsum[3];
@@ -1193,13 +1285,97 @@ __global__ __launch_bounds__(128) void msm_binscan_kernel(const uint32_t* __rest
     bstart_all[(size_t)col * nb + b] = s;
     pstart_all[(size_t)col * nb + b] = p0;
     if (cnt) {
-        const uint32_t gap = prev < 0 ? WIDE_ESC : (uint32_t)((int)threadIdx.x - prev - 1);
-        delta_all[(size_t)col * nb + b] = (uint8_t)(gap < WIDE_ESC ? gap : WIDE_ESC);
+        const uint32_t gap = prev < 0 ? esc : (uint32_t)((int)threadIdx.x - prev - 1);
+        delta_all[(size_t)col * nb + b] = (uint8_t)(gap < esc ? gap : esc);
         // lanes whose first entry lies in this bucket
         for (uint32_t t = (s + WL - 1) / WL; t * WL < s + cnt; t++) lane_b[t] = b;
     }
     for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
-    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 128) pbucket[q] = 0xffffffffu;
+    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += keys) pbucket[q] = 0xffffffffu;
+}
+
+// level 2 of the sort: one chunk (<= SUB entries) of one coarse bin into its buckets, dense (no padding): the first entry of
+// every bucket carries WIDE_FLAG and the bucket's distance from the previous non-empty one in its spare bits
+__global__ __launch_bounds__(256) void msm_wscatter2_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
+                                                            const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
+                                                            const uint32_t* __restrict__ bstart_all, uint32_t* __restrict__ cursor_all,
+                                                            uint32_t* __restrict__ entries_all, size_t ent_stride,
+                                                            const uint8_t* __restrict__ delta_all) {
+    __shared__ SortLds S;
+    __shared__ uint32_t s_bin, s_chunk;
+    __shared__ uint32_t s_mark[128];  // flag bits of a key's first entry when this chunk holds the bucket's first
+    const uint32_t col = blockIdx.y, nb = g.nb, keys = 1u << g.fb;
+    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
+    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    const uint32_t* __restrict__ bstart = bstart_all + (size_t)col * nb;
+    uint32_t* __restrict__ cursor = cursor_all + (size_t)col * nb;
+    uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
+    const uint32_t* cpre = chdr + (WCB + 1);
+    if (blockIdx.x >= cpre[g.bins]) return;  // the grid is sized for the worst case
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = g.bins;  // the bin whose chunk range holds blockIdx.x
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cpre[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        s_bin = lo;
+        s_chunk = blockIdx.x - cpre[lo];
+    }
+    if (threadIdx.x < keys) S.cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    const uint32_t beg = chdr[bin] + s_chunk * SUB;
+    const uint32_t end = min(chdr[bin + 1], beg + SUB);
+    constexpr uint32_t PER = SUB / 256;
+    uint32_t ent[PER], meta[PER];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t p = beg + threadIdx.x + q * 256;
+        meta[q] = 0xffffffffu;
+        if (p < end) {
+            const uint32_t e = inter[p];
+            const uint32_t key = (e >> g.ib) & (keys - 1);
+            ent[q] = e & ~((keys - 1) << g.ib);
+            meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
+        }
+    }
+    __syncthreads();
+    sort_scan(S, keys);
+    if (threadIdx.x < keys) {
+        const uint32_t cnt = S.cnt[threadIdx.x], b = bin * keys + threadIdx.x;
+        const uint32_t before = cnt ? atomicAdd(&cursor[b], cnt) : 0;
+        S.gbase[threadIdx.x] = bstart[b] + before;
+        s_mark[threadIdx.x] = (cnt && before == 0) ? (WIDE_FLAG | ((uint32_t)delta_all[(size_t)col * nb + b] << g.ib)) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++)
+        if (meta[q] != 0xffffffffu) {
+            const uint32_t key = meta[q] >> 16, pos = S.lstart[key] + (meta[q] & 0xffffu);
+            S.sorted[pos] = ent[q];
+            S.kid[pos] = (uint8_t)key;
+        }
+    __syncthreads();
+    const uint32_t total = end - beg;
+    for (uint32_t q = threadIdx.x; q < total; q += 256) {
+        const uint32_t key = S.kid[q];
+        entries[S.gbase[key] + q - S.lstart[key]] = S.sorted[q] | (q == S.lstart[key] ? s_mark[key] : 0u);
+    }
+}
+
+// the counters a pass of the wide path expects to be zero: per-bucket totals and level-2 cursors, the append cursors of the
+// coarse bins, counts[].  Launched only when the workspace is not known to be clean (first pass, after an error or after the
+// 13-bit plan used the workspace): every pass leaves them clean (msm_wbits_kernel's epilogue)
+__global__ void msm_wclear_kernel(uint32_t* __restrict__ totals, uint32_t* __restrict__ cursor, uint32_t nbt,
+                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nbt) {
+        totals[i] = 0;
+        cursor[i] = 0;
+    }
+    if (i < 4 * (MSM_MAX_BATCH + 1)) counts[i] = 0;
+    if (i < ncols * WCB) coarse[(size_t)(i / WCB) * coarse_stride + 2 * (WCB + 1) + (i % WCB)] = 0;
 }
 
 // the bucket of the entry at position `pos` of a column (the escape of a first-of-bucket entry whose distance field is
@@ -1221,20 +1397,21 @@ __device__ __noinline__ uint32_t wide_bucket_at(const uint32_t* __restrict__ bst
 template <bool SAFE>
 __device__ __forceinline__ bool wide_accumulate_lane(const uint32_t* __restrict__ e, uint32_t count, uint32_t pos0, uint32_t t, uint32_t b,
                                                      const uint32_t* __restrict__ bstart, uint32_t nb,
-                                                     const G1Affine* __restrict__ table, G1X29S* __restrict__ slots) {
+                                                     const G1Affine* __restrict__ table, G1X29S* __restrict__ slots, uint32_t ib) {
     G1X29 acc;
     acc.inf = true;
     bool suspicious = false;
+    const uint32_t idx_mask = (1u << ib) - 1, esc = (1u << (30 - ib)) - 1;
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t y = e[k];
         if ((y & WIDE_FLAG) && k) {  // a new bucket begins inside the lane's run
             if (!SAFE && !acc.inf && is_zero29(acc.zz)) suspicious = true;
             g1x29_store(slots + t + b, acc);
             acc.inf = true;
-            const uint32_t d = (y >> 24) & 63u;
-            b = d < WIDE_ESC ? b + 1 + d : wide_bucket_at(bstart, nb, pos0 + k);
+            const uint32_t d = (y >> ib) & esc;
+            b = d < esc ? b + 1 + d : wide_bucket_at(bstart, nb, pos0 + k);
         }
-        G1Affine p = affine_load(table + (y & WIDE_IDX));
+        G1Affine p = affine_load(table + (y & idx_mask));
         if (SAFE && affine_is_identity(p)) continue;
         if (y & SIGN_BIT) p.y = fe_neg(p.y);
         if (!g1x29_add_affine<SAFE, true>(acc, p.x, p.y)) {
@@ -1258,13 +1435,13 @@ __global__ __launch_bounds__(64) void msm_wacc_kernel(const uint32_t* __restrict
                                                       const G1Affine* __restrict__ table, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
                                                       const uint32_t* __restrict__ bstart_all, uint32_t nb,
-                                                      G1X29S* __restrict__ slot_all, uint32_t slot_stride) {
+                                                      G1X29S* __restrict__ slot_all, uint32_t slot_stride, uint32_t ib) {
     const uint32_t col = blockIdx.y, total = counts[4 * col];
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t * WL >= total) return;
     wide_accumulate_lane<true>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
                                lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
-                               slot_all + (size_t)col * slot_stride);
+                               slot_all + (size_t)col * slot_stride, ib);
 }
 #if ZK_ACC_WAVES
 __attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
@@ -1273,26 +1450,28 @@ __global__ __launch_bounds__(64) void msm_wacc_fast_kernel(const uint32_t* __res
                                                            const G1Affine* __restrict__ table, uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
                                                            const uint32_t* __restrict__ bstart_all, uint32_t nb,
-                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, uint32_t* __restrict__ redo) {
+                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, uint32_t* __restrict__ redo,
+                                                           uint32_t ib) {
     const uint32_t col = blockIdx.y, total = counts[4 * col];
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t * WL >= total) return;
     if (wide_accumulate_lane<false>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
                                     lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
-                                    slot_all + (size_t)col * slot_stride))
+                                    slot_all + (size_t)col * slot_stride, ib))
         redo[atomicAdd(&counts[1], 1u)] = col * lane_stride + t;  // at most one entry per lane: redo[] has one word each
 }
 __global__ __launch_bounds__(64) void msm_wacc_redo_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
                                                            const G1Affine* __restrict__ table, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
                                                            const uint32_t* __restrict__ bstart_all, uint32_t nb,
-                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, const uint32_t* __restrict__ redo) {
+                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, const uint32_t* __restrict__ redo,
+                                                           uint32_t ib) {
     const uint32_t m = counts[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const uint32_t col = redo[i] / lane_stride, t = redo[i] - col * lane_stride, total = counts[4 * col];
         wide_accumulate_lane<true>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
                                    lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
-                                   slot_all + (size_t)col * slot_stride);
+                                   slot_all + (size_t)col * slot_stride, ib);
     }
 }
 
@@ -1406,8 +1585,24 @@ __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restric
 
 // T3: blockIdx.x = t < 9: sum of the column sums C_l with bit t of (l + 1) set; t >= 9: sum of the row sums R_h with bit
 // t - 9 of h set.  One wave each; lane 0 hands the sum over in the standard form.  out[col][WIDE_SUMS]
-__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out) {
+__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out,
+                                                       uint32_t* __restrict__ totals_all, uint32_t* __restrict__ cursor_all,
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ coarse_all,
+                                                       uint32_t coarse_stride) {
     const uint32_t col = blockIdx.y, rows = nb >> 8, t = blockIdx.x, lane = threadIdx.x;
+    {
+        // epilogue of the PASS (nothing after this kernel reads them): the column's counters go back to zero, shared among the
+        // kernel's waves.  The next pass on this workspace starts after the host has waited for this kernel.
+        const uint32_t step = gridDim.x * 64, first = t * 64 + lane;
+        for (uint32_t i = first; i < nb; i += step) {
+            totals_all[(size_t)col * nb + i] = 0;
+            cursor_all[(size_t)col * nb + i] = 0;
+        }
+        uint32_t* cur = coarse_all + (size_t)col * coarse_stride + 2 * (WCB + 1);
+        for (uint32_t i = first; i < WCB; i += step) cur[i] = 0;
+        if (col == 0)
+            for (uint32_t i = first; i < 4 * (gridDim.y + 1); i += step) counts[i] = 0;
+    }
     const G1X29S* __restrict__ rc = rc_all + (size_t)col * (rows + 256);
     const bool cols = t < 9;
     const uint32_t items = cols ? 256u : rows;
@@ -1537,7 +1732,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     if (err) *err = hipSuccess;
     if (c == 0) c = msm_auto_window(max_n);
     if (max_batch == 0) max_batch = 1;
-    if (c < 9 || c > 16 || (c == 16 && !msm_wide_applies(c, max_n)) || max_n == 0 || max_n > ((size_t)1 << 26) || max_batch > MSM_MAX_BATCH) {
+    if (c < 9 || c > 17 || (c >= 16 && !msm_wide_applies(c, max_n)) || max_n == 0 || max_n > ((size_t)1 << 26) || max_batch > MSM_MAX_BATCH) {
         if (err) *err = hipErrorInvalidValue;
         return nullptr;
     }
@@ -1571,7 +1766,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     {
         const size_t nblk_max = (max_n + FCHUNK - 1) / FCHUNK;
         ws->inter_stride = max_n * ws->nwin;
-        ws->coarse_stride = (uint32_t)(COARSE_WORDS + nblk_max * CBINS_MAX);
+        ws->coarse_stride = (uint32_t)(WHDR + nblk_max * WCB);  // the wide path's layout (512 bins) covers the 13-bit plan's (256)
         MSM_TRY(hipMalloc(&ws->inter, (size_t)max_batch * ws->inter_stride * sizeof(uint32_t)));
         MSM_TRY(hipMalloc(&ws->coarse, (size_t)max_batch * ws->coarse_stride * sizeof(uint32_t)));
         MSM_TRY(hipMalloc(&ws->cursor, (size_t)max_batch * ws->nb * sizeof(uint32_t)));
@@ -1582,7 +1777,8 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
     MSM_TRY(hipMalloc(&ws->partial, (threads / GA + 2) * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->part, part_n * sizeof(G1X29S)));
     MSM_TRY(hipMalloc(&ws->bit_sum, slices * c * BITSUM_MAX_SPLIT * sizeof(G1X)));
-    ws->wide = msm_wide_applies(c, max_n);
+    ws->wide = msm_wide_shape(c, max_n, &ws->w_ib, &ws->w_fb);
+    ws->w_clean = false;
     if (ws->wide) {
         ws->w_ent_stride = (max_n * ws->nwin + 63) & ~(size_t)63;
         if (ws->w_ent_stride * max_batch > ent) {  // cannot happen: the dense list is padded to 64 per bucket
@@ -1592,7 +1788,7 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
         }
         ws->w_lane_stride = (uint32_t)(ws->w_ent_stride / WL) + 64;
         ws->w_slot_stride = ws->w_lane_stride + ws->nb + 64;
-        ws->w_part_stride = ((ws->w_lane_stride + 2 * ws->nb) / WCAP_MIN + ws->nb + 2 * (ws->nb >> WIDE_FB) + 127) & ~63u;
+        ws->w_part_stride = ((ws->w_lane_stride + 2 * ws->nb) / WCAP_MIN + ws->nb + 2 * (ws->nb >> ws->w_fb) + 127) & ~63u;
         if ((size_t)max_batch * ws->w_slot_stride > threads) {  // cannot happen: sized for 16-entry segments
             if (err) *err = hipErrorInvalidValue;
             msm_workspace_destroy(ws);
@@ -1642,58 +1838,78 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
                                const G1Affine* table, uint32_t table_stride, hipStream_t tail_st, hipEvent_t head_done,
                                bool bases_may_be_identity) {
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
-    const uint32_t nbt = batch * nb, rows = nb >> 8;
+    const uint32_t rows = nb >> 8;
     const uint32_t WCAP = wcap_for(batch);
     uint32_t row_bits = 0;
     while ((1u << row_bits) < rows) row_bits++;
     *nwin_out = batch;
     *c_out = c;
     hipError_t e;
+    WideGeo g;
+    memset(&g, 0, sizeof(g));
+    g.c = c;
+    g.nwin = nwin;
+    g.nb = nb;
+    g.ib = ws->w_ib;
+    g.fb = ws->w_fb;
+    g.bins = nb >> g.fb;
+    for (uint32_t w = 0; w < nwin; w++) {  // the recoding bias: s + K < 2^254 + 2^(nwin c - 1) (1 + 2^-c + ..) < 2^256
+        const uint32_t bit = c - 1 + w * c;
+        g.K[bit >> 5] |= 1u << (bit & 31);
+    }
 #ifdef ZK_MSM_POISON  // debug: a slot / part / row-column sum read without having been written by THIS pass shows
     hipMemsetAsync(ws->slot_pt, 0xA5, ws->slot_elems * sizeof(G1X29S), st);
     hipMemsetAsync(ws->w_part, 0xA5, (size_t)ws->max_batch * ws->w_part_stride * sizeof(G1X29S), st);
     hipMemsetAsync(ws->w_rc, 0xA5, (size_t)ws->max_batch * ((ws->nb >> 8) + 256) * sizeof(G1X29S), st);
 #endif
-    {
-        uint32_t m = nbt + 1;
-        if (batch * CBINS_MAX > m) m = batch * CBINS_MAX;
-        hipLaunchKernelGGL(msm_clear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->part, 0u, ws->totals, nbt + 1, ws->counts,
-                           ws->cursor, nbt, ws->coarse, ws->coarse_stride, batch);
+    if (!ws->w_clean) {
+        // first pass on this workspace (or the previous one did not finish): every later pass finds the counters zeroed by
+        // the last tail kernel of the pass before
+        const uint32_t all = ws->max_batch * nb;
+        uint32_t m = all;
+        if (ws->max_batch * WCB > m) m = ws->max_batch * WCB;
+        if (4 * (MSM_MAX_BATCH + 1) > m) m = 4 * (MSM_MAX_BATCH + 1);
+        hipLaunchKernelGGL(msm_wclear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->totals, ws->cursor, all, ws->counts, ws->coarse,
+                           ws->coarse_stride, ws->max_batch);
     }
+    ws->w_clean = false;
     const uint32_t n32 = (uint32_t)n;
-    const uint32_t stride = (uint32_t)ws->max_n;
     const uint32_t lanes = (uint32_t)(((size_t)n * nwin + WL - 1) / WL);  // accumulation lanes of one column at most
     if (n > 0) {
         const uint32_t nblk = (n32 + FCHUNK - 1) / FCHUNK;
         MsmBatch mb;
         memset(&mb, 0, sizeof(mb));
         for (uint32_t q = 0; q < batch; q++) mb.s[q] = scalars_list[q];
-        hipLaunchKernelGGL(msm_recode_coarse_kernel, dim3(nblk, batch), dim3(256), 0, st, mb, n32, stride, c, nwin, nb, ws->digits,
-                           ws->coarse, ws->coarse_stride);
-        hipLaunchKernelGGL(msm_scan_coarse_wide_kernel, dim3(batch), dim3(64), 0, st, ws->coarse, ws->coarse_stride, nb >> WIDE_FB,
-                           ws->counts, WCAP);
-        hipLaunchKernelGGL(msm_scatter1_kernel, dim3(nblk, batch), dim3(256), 0, st, ws->digits, n32, stride, nwin, nb, table_stride,
-                           ws->coarse, ws->coarse_stride, ws->inter, ws->inter_stride, WIDE_FB);
-        const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + (nb >> WIDE_FB);
-        hipLaunchKernelGGL(msm_finehist_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, nb, ws->totals);
-        hipLaunchKernelGGL(msm_binscan_kernel, dim3(nb >> WIDE_FB, batch), dim3(128), 0, st, ws->coarse, ws->coarse_stride, nb, ws->totals,
+        const dim3 gh(nblk, batch);
+        if (c == 17) {
+            hipLaunchKernelGGL(msm_whist_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_wscatter1_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
+                               ws->inter, ws->inter_stride, ws->counts, WCAP);
+        } else if (c == 16) {
+            hipLaunchKernelGGL(msm_whist_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_wscatter1_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
+                               ws->inter, ws->inter_stride, ws->counts, WCAP);
+        } else {
+            hipLaunchKernelGGL(msm_whist_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_wscatter1_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
+                               ws->inter, ws->inter_stride, ws->counts, WCAP);
+        }
+        const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + g.bins;
+        hipLaunchKernelGGL(msm_wfinehist_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, g, ws->totals);
+        hipLaunchKernelGGL(msm_wbinscan_kernel, dim3(g.bins, batch), dim3(1u << g.fb), 0, st, ws->coarse, ws->coarse_stride, g, ws->totals,
                            ws->w_bstart, ws->w_delta, ws->w_lane_b, ws->w_lane_stride, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, WCAP);
-        hipLaunchKernelGGL(msm_scatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, nb, ws->totals, ws->w_bstart, ws->cursor, ws->entries, WIDE_FB, 1u, ws->w_ent_stride,
-                           (const uint8_t*)ws->w_delta);
+        hipLaunchKernelGGL(msm_wscatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, g, ws->w_bstart, ws->cursor, ws->entries, ws->w_ent_stride, (const uint8_t*)ws->w_delta);
         if (accum_events) hipEventRecord(accum_events[0], st);
         if (bases_may_be_identity) {
             hipLaunchKernelGGL(msm_wacc_kernel, dim3((lanes + 63) / 64, batch), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts,
-                               ws->w_lane_b, ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride);
+                               ws->w_lane_b, ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, g.ib);
         } else {
             hipLaunchKernelGGL(msm_wacc_fast_kernel, dim3((lanes + 63) / 64, batch), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table,
-                               ws->counts, ws->w_lane_b, ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo);
+                               ws->counts, ws->w_lane_b, ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo, g.ib);
         }
         if (accum_events) hipEventRecord(accum_events[1], st);
-        if (!bases_may_be_identity)
-            hipLaunchKernelGGL(msm_wacc_redo_kernel, dim3(256), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts, ws->w_lane_b,
-                               ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo);
     }
     hipStream_t ts = st;
     if (tail_st && tail_st != st) {
@@ -1702,16 +1918,26 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         ts = tail_st;
     }
     if (n > 0) {
-        // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_scan_coarse_wide_kernel)
-        const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * (nb >> WIDE_FB) + 64;
+        // the checked re-run of the lanes the unchecked accumulation reported (almost always none) opens the TAIL: on the main
+        // stream this launch — a no-op — queued behind the other pipeline's accumulation for ~50 us per pass
+        if (!bases_may_be_identity)
+            hipLaunchKernelGGL(msm_wacc_redo_kernel, dim3(256), dim3(64), 0, ts, ws->entries, ws->w_ent_stride, table, ws->counts, ws->w_lane_b,
+                               ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo, g.ib);
+        // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_wscatter1_kernel)
+        const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * g.bins + 64;
         hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, ws->totals,
                            ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
     }
     hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, ws->totals, ws->w_bstart,
                        ws->w_pstart, nb, ws->w_rc, WCAP);
-    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum);
+    // T3; its epilogue zeroes this pass's counters (totals, cursors, append cursors, counts) for the next pass on this workspace
+    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum, ws->totals, ws->cursor,
+                       ws->counts, ws->coarse, ws->coarse_stride);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts);
+    if ((e = hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts)) != hipSuccess)
+        return e;
+    ws->w_clean = true;
+    return hipSuccess;
 }
 
 // `table` != nullptr selects the fixed-base mode: table[w * table_stride + i] = 2^(c w) P_i.
@@ -1728,7 +1954,8 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     if (fixed && ws->wide && table_stride == ws->max_n)
         return msm_run_wide(ws, scalars_list, batch, n, st, host_window_sums, nwin_out, c_out, accum_events, table, table_stride, tail_st,
                             head_done, bases_may_be_identity);
-    if (c > 15) return hipErrorInvalidValue;  // 16-bit digits exist on the wide path only
+    if (c > 15) return hipErrorInvalidValue;  // 16 / 17-bit digits exist on the wide path only
+    ws->w_clean = false;                       // this plan shares totals / cursors / counts with the wide path and leaves them used
     const bool fused = fixed && nb <= SORT_LDS_BUCKETS;  // one-kernel digits + histogram; 15-bit windows take the swept sort
     if (!fused && batch != 1) return hipErrorInvalidValue;  // columns are batched on the fused fixed-base path only
     const Fr* scalars = scalars_list[0];

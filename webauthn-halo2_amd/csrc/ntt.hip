@@ -52,6 +52,8 @@ struct NttPassArgs {
     const Fr* in[NTT_MAX_BATCH];   // one vector per blockIdx.y
     Fr* out[NTT_MAX_BATCH];
     const Fr* tw;        // w_N^i * 2^261 mod p (canonical words), i in [0, N)
+    const Fr* tw_last;   // FOLD passes: c * w_N^i * 2^256 (standard form, c = 1 or 1/N): the inter-pass twiddle of the LAST pass
+                         // also carries the conversion internal -> standard (and 1/N), so that the store needs no product
     uint32_t log_n;
     uint32_t log_r;      // this pass's radix
     uint32_t log_ns;     // product of radices of earlier passes (0: first pass, input in standard form)
@@ -126,6 +128,30 @@ __device__ __forceinline__ Fr29 reduce_below_2_256(const Fr29& a) {
     return r;
 }
 
+// a normalised (limbs < 2^29), value < 160 p  ->  the canonical representative as 8 words.  q = floor(a / p) is estimated
+// from the top limb: T = floor(a / 2^232) < 2^29.4, P8 = floor(p / 2^232) (22 bits); qe = floor(T / (P8 + 1)) is q or q - 1
+// (T / (P8 + 1) <= a / p < (T + 1) / P8, the two differ by < 2^-13), taken as a multiplication by M = floor(2^53 / (P8 + 1))
+// (error < T / 2^53): 0 <= a - qe p < 2 p, then one conditional subtraction
+__device__ __forceinline__ Fr reduce_canonical(const Fr29& a) {
+    constexpr uint32_t P8 = Lim29<FrParams>::P[8];
+    constexpr uint64_t M = ((uint64_t)1 << 53) / (P8 + 1);  // < 2^32
+    static_assert(M < ((uint64_t)1 << 32), "M must fit a word");
+    const uint32_t qe = (uint32_t)(((uint64_t)a.l[8] * (uint32_t)M) >> 53);
+    Fr29 r;
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        acc += (int64_t)a.l[i] - (int64_t)((uint64_t)qe * Lim29<FrParams>::P[i]);
+        r.l[i] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    acc += (int64_t)a.l[8] - (int64_t)((uint64_t)qe * Lim29<FrParams>::P[8]);
+    r.l[8] = (uint32_t)acc;
+    Fr o = from29(r);
+    reduce_once(o);
+    return o;
+}
+
 // decimation-in-time butterflies.  Bounds (value as a multiple of p ; limb bits), "fresh" = product output (< 2p ; 29):
 //   bfly_mul    t = v w fresh;  u' = u + t (k_u + 2),  v' = u - t + 3p (k_u + 3)
 //   bfly_plain  trivial twiddle, v bounded by KV:  u' = u + v,  v' = u - v + (KV + 1) p
@@ -152,7 +178,16 @@ __device__ __forceinline__ void round0(Fr29& e0, Fr29& e1, Fr29& e2, Fr29& e3, c
     bfly_mul(e1, e3, w4);                     // <= 2 KIN + 4
 }
 
-template <uint32_t KIN>
+// MODE 0: the general pass.
+// MODE 1 (FOLD): the last pass of a transform of two or more passes whose output scaling is uniform (none, or 1/N): every
+//   loaded element is multiplied by tw_last[.] = c w^e 2^256 — the inter-pass twiddle, the conversion internal -> standard
+//   and c in ONE product (the trivial twiddles w^0 included: tw_last[0] = c 2^256) — and the store only reduces to the
+//   canonical representative (reduce_canonical: ~85 instructions instead of a product + conversion, ~300).
+// MODE 2 (ZQ): the first pass of a transform whose input is at least three quarters zeros (coeff_to_extended: n_in <= N/4):
+//   only r < R/4 is loaded, into a compact array; positions brev(r) = 0 mod 4 are the only non-zero ones, so stages 0 and 1
+//   (groups of four adjacent positions) just copy x to all four — round 0 is skipped, round 1 reads the compact array.
+enum { NTT_GENERAL = 0, NTT_FOLD = 1, NTT_ZQ = 2 };
+template <uint32_t KIN, int MODE>
 #ifndef ZK_NTT_WAVES
 #define ZK_NTT_WAVES 0
 #endif
@@ -193,10 +228,13 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
         const uint32_t ex = (r * ((j0 + t) & ns_mask)) << tw_shift;
         return a.inverse ? ((N - ex) & nmask) : ex;  // 0 <=> trivial twiddle
     };
+    const Fr* __restrict__ twl = MODE == NTT_FOLD ? a.tw_last : a.tw;  // inter-pass twiddles of this pass
     auto place = [&](uint32_t t, uint32_t r, uint32_t idx, const Fr& v, const Fr& w, uint32_t ti) {
         Fr29 x;
         if (idx < a.n_in) {
-            if (a.log_ns == 0) {
+            if (MODE == NTT_FOLD) {
+                x = mul29(to29(v), to29(w));  // every element, w^0 too: the product also converts (and scales)
+            } else if (a.log_ns == 0) {
                 // first pass: standard form in.  32 v is a valid internal form (bound 32 p); the coset factor's
                 // constant carries 2^266 so that the product lands in internal form
                 const uint32_t m = a.has_pre ? idx % 3 : 0;
@@ -213,7 +251,23 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
         tile_store(lds, tile, row, pos, t, a.log_t, x);
     };
     constexpr uint32_t EPT = (1u << NTT_TILE_LOG) / NTT_THREADS;  // elements per lane of a full tile
-    if (tile == (1u << NTT_TILE_LOG)) {
+    uint32_t* cq = wr + (R >> 1) * 9;  // ZQ: the compact array [R / 4][T] of the non-zero quarter (same row pitch as the tile)
+    if (MODE == NTT_ZQ) {
+        // (host side: full tile, log_r >= 4, n_in <= N / 4, first pass)  one element per lane: r < R / 4 only
+        const uint32_t e = threadIdx.x;
+        const uint32_t t = e & (T - 1), r = e >> a.log_t;
+        const uint32_t idx = j0 + t + r * col_stride;
+        Fr29 x;
+        if (idx < a.n_in) {
+            const Fr v = fe_load(vin + idx);
+            const uint32_t m = a.has_pre ? idx % 3 : 0;
+            x = m ? mul29(to29(v), to29(a.pre[m])) : to29_x32(v);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; i++) x.l[i] = 0;
+        }
+        tile_store(cq, tile >> 2, row, __brev(r) >> (brev_shift + 2), t, a.log_t, x);
+    } else if (tile == (1u << NTT_TILE_LOG)) {
         // full tile: the lane's loads (data and inter-pass twiddles) are all issued before the first product
         Fr v[EPT], w[EPT];
         uint32_t tt[EPT], rr[EPT], ii[EPT], ti[EPT];
@@ -222,7 +276,7 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             ii[k] = src_index(threadIdx.x + k * NTT_THREADS, tt[k], rr[k]);
             ti[k] = a.log_ns ? tw_index(tt[k], rr[k]) : 0;
             v[k] = ii[k] < a.n_in ? fe_load(vin + ii[k]) : Fr::zero();
-            w[k] = ti[k] ? fe_load(a.tw + ti[k]) : Fr::zero();
+            w[k] = (ti[k] || MODE == NTT_FOLD) ? fe_load(twl + ti[k]) : Fr::zero();
         }
 #pragma unroll
         for (uint32_t k = 0; k < EPT; k++) place(tt[k], rr[k], ii[k], v[k], w[k], ti[k]);
@@ -232,7 +286,7 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             const uint32_t idx = src_index(e, t, r);
             const uint32_t ti = a.log_ns ? tw_index(t, r) : 0;
             const Fr v = idx < a.n_in ? fe_load(vin + idx) : Fr::zero();
-            const Fr w = ti ? fe_load(a.tw + ti) : Fr::zero();
+            const Fr w = (ti || MODE == NTT_FOLD) ? fe_load(twl + ti) : Fr::zero();
             place(t, r, idx, v, w, ti);
         }
     }
@@ -245,7 +299,9 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
     Fr29 keep[4];
     (void)keep;
     uint32_t s = 0;
-    if (a.log_r >= 2) {
+    if (MODE == NTT_ZQ) {
+        s = 2;  // stages 0 and 1 copy the one non-zero element of every group of four: nothing to compute
+    } else if (a.log_r >= 2) {
         // stages 0 and 1: groups of four adjacent positions
         const Fr29 w4 = lds_load29(wr + (R >> 2) * 9);  // w_R^(R/4)
         for (uint32_t q = threadIdx.x; q < (tile >> 2); q += NTT_THREADS) {
@@ -277,8 +333,15 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
 #if ZK_NTT_EXP_NOLDS
             Fr29 e0 = keep[0], e1 = keep[1], e2 = keep[2], e3 = keep[3];
 #else
-            Fr29 e0 = tile_load(lds, tile, row, base, t, a.log_t), e1 = tile_load(lds, tile, row, base + h, t, a.log_t),
-                 e2 = tile_load(lds, tile, row, base + 2 * h, t, a.log_t), e3 = tile_load(lds, tile, row, base + 3 * h, t, a.log_t);
+            Fr29 e0, e1, e2, e3;
+            if (MODE == NTT_ZQ && s == 2) {  // positions base + 4 i all hold the compact element (base >> 2) + i
+                const uint32_t cb = (g >> 2) << 2;
+                e0 = tile_load(cq, tile >> 2, row, cb, t, a.log_t), e1 = tile_load(cq, tile >> 2, row, cb + 1, t, a.log_t);
+                e2 = tile_load(cq, tile >> 2, row, cb + 2, t, a.log_t), e3 = tile_load(cq, tile >> 2, row, cb + 3, t, a.log_t);
+            } else {
+                e0 = tile_load(lds, tile, row, base, t, a.log_t), e1 = tile_load(lds, tile, row, base + h, t, a.log_t);
+                e2 = tile_load(lds, tile, row, base + 2 * h, t, a.log_t), e3 = tile_load(lds, tile, row, base + 3 * h, t, a.log_t);
+            }
 #endif
             {
                 const Fr29 w1 = lds_load29(wr + (lo << (a.log_r - s - 1)) * 9);   // w_{2h}^lo
@@ -336,7 +399,9 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
         if (dst < a.n_out) {
             const Fr29 x = tile_load(lds, tile, row, r, t, a.log_t);
             Fr o;
-            if (a.last) {
+            if (MODE == NTT_FOLD) {
+                o = reduce_canonical(x);
+            } else if (a.last) {
                 o = from29(mul29(x, a.has_post ? to29(a.post[dst % 3]) : one_std));
                 reduce_once(o);
             } else {
@@ -371,6 +436,11 @@ void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st) {
     hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, tw, w, Fr::one(), n);
 }
 
+void launch_twiddles_scaled(Fr* tw, const Fr& w, const Fr& scale, uint32_t n, hipStream_t st) {
+    const uint32_t threads = (n + 63) / 64;
+    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, tw, w, scale, n);
+}
+
 static Fr fr_small_mont(uint32_t x) {
     Fr a = Fr::zero();
     a.v[0] = x;
@@ -381,6 +451,14 @@ void launch_twiddles_internal(Fr* tw, const Fr& w, uint32_t n, hipStream_t st) {
     const uint32_t threads = (n + 63) / 64;
     hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, tw, w, fr_small_mont(32), n);
 }
+
+#ifndef ZK_NTT_FOLD  // build-time switches for A/B runs (tools/ab_variants.sh)
+#define ZK_NTT_FOLD 1
+#endif
+#ifndef ZK_NTT_ZQ
+#define ZK_NTT_ZQ 1
+#endif
+static constexpr bool FOLD_ON = ZK_NTT_FOLD != 0, ZQ_ON = ZK_NTT_ZQ != 0;
 
 // Plan the passes of a 2^log_n transform: radices as even as possible, each <= max_log_r.
 int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]) {
@@ -450,6 +528,7 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
             a.out[b] = which ? job.tmp + (size_t)b * N : dsts[b];
         }
         a.tw = job.tw;
+        a.tw_last = job.tw_last;
         a.log_n = log_n;
         a.log_r = bits[p];
         a.log_ns = log_ns;
@@ -460,19 +539,27 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         a.last = p == np - 1;
         a.n_in = (p == 0) ? job.n_in : N;
         a.n_out = (p == np - 1) ? job.n_out : N;
+        // the last of several passes takes its conversion (and a uniform output scaling) from tw_last: no final product
+        const bool fold = FOLD_ON && np >= 2 && p == np - 1 && job.tw_last != nullptr && (!job.has_post || job.tw_last_has_post);
+        // the first pass of a transform over an input that is >= 3/4 zeros skips its first two stages
+        const bool zq = ZQ_ON && p == 0 && (uint64_t)job.n_in * 4 <= N && a.log_r >= 4 && a.log_r + log_t == (uint32_t)NTT_TILE_LOG;
         a.has_pre = (p == 0) ? job.has_pre : 0;
-        a.has_post = (p == np - 1) ? job.has_post : 0;
+        a.has_post = (p == np - 1 && !fold) ? job.has_post : 0;
         for (int i = 0; i < 3; i++) {
             a.pre[i] = pre266[i];
             a.post[i] = job.post[i];
         }
         const uint32_t blocks = N >> (a.log_r + a.log_t);
-        const size_t lds = (ZK_NTT_SOA ? ((size_t)36 << (a.log_t + a.log_r)) : (((size_t)9 << a.log_t) + ZK_NTT_PAD) * ((size_t)4 << a.log_r)) +
-                           ((size_t)36 << a.log_r) / 2;
-        if (p == 0)
-            hipLaunchKernelGGL(ntt_pass_kernel<32>, dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        const size_t row_bytes = ZK_NTT_SOA ? ((size_t)36 << a.log_t) : (((size_t)9 << a.log_t) + ZK_NTT_PAD) * 4;
+        const size_t lds = (row_bytes << a.log_r) + ((size_t)36 << a.log_r) / 2 + (zq ? (row_bytes << (a.log_r - 2)) : 0);
+        if (zq)
+            hipLaunchKernelGGL((ntt_pass_kernel<32, NTT_ZQ>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        else if (p == 0)
+            hipLaunchKernelGGL((ntt_pass_kernel<32, NTT_GENERAL>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        else if (fold)
+            hipLaunchKernelGGL((ntt_pass_kernel<6, NTT_FOLD>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
         else
-            hipLaunchKernelGGL(ntt_pass_kernel<6>, dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+            hipLaunchKernelGGL((ntt_pass_kernel<6, NTT_GENERAL>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
         for (uint32_t b = 0; b < batch; b++) cur_in[b] = a.out[b];
         which ^= 1;
         log_ns += bits[p];
