@@ -170,8 +170,9 @@ typedef struct {
     uint32_t num_lookup_advice;
     uint32_t num_fixed;
     uint32_t lookup_bits;
-    uint32_t num_idle_gate_columns; /* trailing gate columns whose selector is never enabled: halo2's selector
-                                       compression gives them no fixed column (their gate keeps its y-slot) */
+    uint32_t num_idle_gate_columns; /* trailing gate columns whose selector is never enabled (at most half of num_advice):
+                                       halo2's selector compression puts the t-th such selector into the fixed column of
+                                       gate t — no column of its own — and replaces the pair by q (2 - q) / q (1 - q) */
 } zk_circuit_params;
 typedef uint64_t zk_pk; /* opaque: proving key + verifying key + prover workspace, device resident */
 
@@ -190,9 +191,9 @@ int zk_keygen(zk_ctx* ctx, const zk_circuit_params* params, const uint64_t* fixe
               const uint32_t* copies, size_t n_copies, zk_pk* out);
 /* the vk digest every transcript starts with (halo2 `vk.transcript_repr`: Blake2b-512 of the pinned vk's Debug rendering,
  * reduced mod r): zk_keygen / zk_pk_read compute halo2's own value (csrc/vkrepr.h; pinned by the reference's k = 17 literal,
- * proving-server/P256Verifier.yul:34) for every shape without never-enabled gate columns, and a stand-in hash for those
- * (bench_ecdsa.config rows k <= 13, whose selector compression is not restated).  A host that knows better sets its value
- * here (Montgomery image). */
+ * proving-server/P256Verifier.yul:34) for every shape, never-enabled gate columns included (bench_ecdsa.config rows k <= 13:
+ * their combined selectors are rendered as compress_selectors builds them; no known answer exists for those rows).  A host
+ * that knows better sets its value here (Montgomery image). */
 int zk_pk_set_transcript_repr(zk_ctx* ctx, zk_pk pk, const uint64_t transcript_repr_mont[4]);
 int zk_pk_free(zk_ctx* ctx, zk_pk pk);
 /* the VerifyingKey half: commitments (affine Montgomery) and transcript_repr; counts = {n_fixed, n_perm} */

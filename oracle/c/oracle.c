@@ -632,12 +632,20 @@ static void quot_job(void *p, size_t tid, size_t lo, size_t hi) {
 #define PUSH(e) do { fe_mul(&acc, &acc, &a->y, &FR); fe_add(&acc, &acc, (e), &FR); } while (0)
         fe t, u, v;
         for (uint32_t j = 0; j < a->n_gate; j++) {
-            if (a->fx_sel[j] < 0) { memset(&t, 0, sizeof(t)); PUSH(&t); continue; }
+            /* fx_sel[j] = fixed column | form << 24: the gate's selector after halo2's compress_selectors
+             * (zkoracle/plonk.py Shape.gate_sel): form 0: q, 1: q (2 - q), 2: q (1 - q) */
             const fe *c = a->adv[j];
+            const fe *q = &a->fix[a->fx_sel[j] & 0xffffff][i];
+            const int form = a->fx_sel[j] >> 24;
             fe_mul(&t, &c[ROT(1)], &c[ROT(2)], &FR);
             fe_add(&t, &t, &c[i], &FR);
             fe_sub(&t, &t, &c[ROT(3)], &FR);
-            fe_mul(&t, &t, &a->fix[a->fx_sel[j]][i], &FR);
+            fe_mul(&t, &t, q, &FR);
+            if (form) {
+                fe_sub(&u, &FR.one, q, &FR);
+                if (form == 1) fe_add(&u, &u, &FR.one, &FR);
+                fe_mul(&t, &t, &u, &FR);
+            }
             PUSH(&t);
         }
         const fe *l0 = &a->l0[i], *ll = &a->l_last[i];

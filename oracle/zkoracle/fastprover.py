@@ -308,7 +308,7 @@ def evaluate_h(pk, adv_e, z_e, lk_e, beta, gamma, y, divide=True):
     sh = pk.shape
     k, n, ext_k = sh.k, sh.n, sh.ext_k
     N = 1 << ext_k
-    fx_sel = (ctypes.c_int32 * sh.n_gate)(*[-1 if s is None else s for s in sh.fx_sel])
+    fx_sel = (ctypes.c_int32 * sh.n_gate)(*[col | (form << 24) for col, form in sh.gate_sel])  # oracle.c quot_job
     perm_val = [(pk.fix_e[c[1]] if c[0] == "fixed" else adv_e[c[1]]) for c in sh.perm_cols]
     delta_pow = arr([pow(DELTA, p, R) for p in range(len(sh.perm_cols))])
     step = 1 << (ext_k - k)

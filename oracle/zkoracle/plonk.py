@@ -25,6 +25,16 @@ from .srs import TAU
 
 BLINDING_FACTORS = 6  # max(3, 4 queries of a gate column) + 2; l_last = row n-7 (P256Verifier.yul:308,773)
 
+# forms of a gate's selector expression after halo2's compress_selectors (Shape.gate_sel)
+SEL_PLAIN, SEL_FIRST_OF_TWO, SEL_SECOND_OF_TWO = 0, 1, 2
+
+
+def selector_value(form, q):
+    """The selector expression of a gate evaluated where its fixed column is q: q, q (2 - q) or q (1 - q)."""
+    if form == SEL_PLAIN:
+        return q % R
+    return q * ((2 if form == SEL_FIRST_OF_TWO else 1) - q) % R
+
 
 # ------------------------------------------------------------------ shape ---
 
@@ -37,10 +47,15 @@ class Shape:
     num_lookup_advice: int     # L
     num_fixed: int             # F: constant columns
     lookup_bits: int = 0
-    # gate columns (the last ones) whose selector is never enabled: halo2's selector compression replaces a
-    # never-enabled selector by the constant 0, so it has no fixed column; the gate keeps its slot in the
-    # y-combination.  [RECALLED plonk/circuit/compress_selectors; explains the published sizes of the
-    # k <= 13 rows, halo2-circuits/src/results/ecdsa_bench.csv:8-10, SURVEY.md App. A.1]
+    # gate columns (the last ones) whose selector is never enabled.  halo2's selector compression
+    # (plonk/circuit/compress_selectors.rs `process` [RECALLED]) combines simple selectors that are never enabled on the
+    # same row into ONE fixed column as long as the degree allows: with gate degree 3 and constraint-system degree 4 a
+    # combination holds two selectors.  Used gate columns all start at row 0 and exclude each other; an all-false selector
+    # excludes nobody, so the greedy pass puts the t-th never-enabled selector into the column of gate t: no fixed column
+    # of its own (this is what makes the published proofs of the k <= 13 rows 1 / 2 / 3 evaluations shorter,
+    # halo2-circuits/src/results/ecdsa_bench.csv:8-10) — and both gates of the pair change their
+    # selector EXPRESSION: q (2 - q) for the used one (value 1 where q = 1), q (1 - q) for the never-enabled one (zero on
+    # the domain, not as a polynomial: it contributes to h(X)).  `gate_sel[j]` = (fixed column, form).
     idle_gate_columns: int = 0
 
     def __post_init__(self):
@@ -65,6 +80,12 @@ class Shape:
             self.fx_sel = [F + 1 + j for j in range(A - U)] + [None] * U
             self.fx_qlookup = None
             self.n_fix = F + 1 + A - U
+            assert 2 * U <= A, "more never-enabled selectors than used ones: they would pair up in columns of their own"
+        # selector of gate j after compression: (fixed column, form); form 0: q, 1: q (2 - q), 2: q (1 - q)
+        self.gate_sel = [(c, SEL_PLAIN) for c in self.fx_sel]
+        for t in range(U):
+            self.gate_sel[t] = (self.fx_sel[t], SEL_FIRST_OF_TWO)
+            self.gate_sel[A - U + t] = (self.fx_sel[t], SEL_SECOND_OF_TWO)
         self.advice_queries = [(j, r) for j in range(A) for r in range(4)] + [(A + l, 0) for l in range(self.n_lookup_cols)]
         self.fixed_queries = [(f, 0) for f in range(self.n_fix)]
         self.perm_cols = [("fixed", f) for f in self.fx_const] + [("advice", j) for j in range(self.n_adv)]
@@ -370,7 +391,8 @@ def expected_h_eval(vk, pf):
     # gates: q_j * (a + b*c - d)
     for j in range(sh.n_gate):
         a, b, c, d = (adv[(j, r)] for r in range(4))
-        exprs.append(0 if sh.fx_sel[j] is None else fix[sh.fx_sel[j]] * ((a + b * c - d) % R) % R)
+        col, form = sh.gate_sel[j]
+        exprs.append(selector_value(form, fix[col]) * ((a + b * c - d) % R) % R)
     # permutation argument
     col_eval = lambda col: fix[col[1]] if col[0] == "fixed" else adv[(col[1], 0)]
     pe = pf.perm_evals

@@ -22,7 +22,7 @@ import hashlib
 
 from . import curve as C
 from .field import DELTA, R, ZETA, batch_inv, inv, omega
-from .plonk import BLINDING_FACTORS, Shape, VerifyingKey, make_transcript
+from .plonk import BLINDING_FACTORS, Shape, VerifyingKey, make_transcript, selector_value
 from .srs import TAU, lagrange_at
 
 
@@ -141,19 +141,10 @@ def build_sigma(shape: Shape, copies):
 
 def transcript_repr(shape: Shape, fixed_commitments, permutation_commitments):
     """halo2's vk.transcript_repr: the Blake2b hash of the pinned verifying key's Debug rendering (zkoracle/vkrepr.py,
-    pinned by the reference's k = 17 value, P256Verifier.yul:34).  Shapes with never-enabled gate columns (whose
-    selector compression is not restated) keep a stand-in: blake2b-512 over the shape and the vk commitments."""
+    pinned by the reference's k = 17 value, P256Verifier.yul:34), for every shape — never-enabled gate columns included
+    (their combined selectors are rendered as compress_selectors builds them)."""
     from . import vkrepr
-    if vkrepr.supported(shape):
-        return vkrepr.transcript_repr(shape, fixed_commitments, permutation_commitments)
-    h = hashlib.blake2b(digest_size=64, person=b"zkmi355-vk-repr")
-    for v in (shape.k, shape.num_advice, shape.num_lookup_advice, shape.num_fixed, shape.lookup_bits,
-              shape.idle_gate_columns):
-        h.update(int(v).to_bytes(2, "little"))
-    for p in list(fixed_commitments) + list(permutation_commitments):
-        p = (0, 0) if p is None else p
-        h.update(p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little"))
-    return int.from_bytes(h.digest(), "little") % R
+    return vkrepr.transcript_repr(shape, fixed_commitments, permutation_commitments)
 
 
 class ProvingKey:
@@ -327,7 +318,8 @@ def create_proof(pk: ProvingKey, advice, rng, kind="evm", scheme=None, trace=Non
         active = (1 - ll - lb) % R
         for j in range(sh.n_gate):
             a, b, c, d4 = (rot(adv_e[j], i, r) for r in range(4))
-            push(0 if sh.fx_sel[j] is None else fix_e[sh.fx_sel[j]][i] * ((a + b * c - d4) % R) % R)
+            col, form = sh.gate_sel[j]
+            push(selector_value(form, fix_e[col][i]) * ((a + b * c - d4) % R) % R)
         push(l0 * (1 - z_e[0][i]) % R)
         zl = z_e[-1][i]
         push(ll * ((zl * zl - zl) % R) % R)

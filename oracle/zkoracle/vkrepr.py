@@ -19,7 +19,12 @@ FpConfig::configure):
     num_advice == 1  a complex selector q_lookup and ONE lookup (q_lookup * a, table)
     keygen           compress_selectors: selectors that occur in no gate (the complex one) get their fixed columns
                      first, then the simple ones in index order (densely used gate columns exclude each other: one
-                     column each); every selector becomes a fixed-column query at rotation 0
+                     column each); every selector becomes a fixed-column query at rotation 0.  A NEVER-ENABLED simple
+                     selector excludes nobody: the greedy pass (`process`: for selector i, the first later selectors
+                     that conflict with none of the combination join it while degree + members <= the constraint
+                     system's degree: 2 + 2 <= 4) puts the t-th never-enabled one into gate t's column, and the two
+                     selectors of that column are replaced by  q * (2 - q)  (assigned root 1) and  q * (1 - q)  (root 2):
+                     `Product(q, Sum(Constant(root'), Negated(q)))` for the other root
 
 PINNED by the reference's own known answer K3: for the k = 17 shape (4 gate + 1 lookup advice columns, 1 constants
 column) and the twelve verifying-key commitments the generated verifier carries, this rendering hashes to
@@ -38,8 +43,8 @@ R_HEX = "0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001"
 
 
 def supported(shape):
-    """Shapes whose selector compression is the plain one-column-per-selector case (no never-enabled gate column)."""
-    return shape.idle_gate_columns == 0
+    """Every shape the oracle models (kept for callers of earlier rounds: never-enabled gate columns used to be excluded)."""
+    return True
 
 
 def halo2_fixed_column(shape, i):
@@ -80,13 +85,15 @@ def _fix(shape, i):
 
 def pinned_debug(shape, fixed_commitments, permutation_commitments):
     """`format!("{:?}", vk.pinned())`; commitments in the oracle's order (fixed: query order), affine ints or None."""
-    if not supported(shape):
-        raise NotImplementedError("selector compression with never-enabled gate columns is not restated")
     A, F = shape.num_advice, shape.num_fixed
     gates = []
     for j in range(A):
         a, b, c, d = (_adv(4 * j + r, j, r) for r in range(4))
-        gates.append("Product(%s, Sum(Sum(%s, Product(%s, %s)), Negated(%s)))" % (_fix(shape, shape.fx_sel[j]), a, b, c, d))
+        col, form = shape.gate_sel[j]
+        q = _fix(shape, col)
+        if form:  # combined pair: q * (other_root - q); Constant's Debug is the field element's (0x + 64 hex digits)
+            q = "Product(%s, Sum(Constant(%s), Negated(%s)))" % (q, _fe(2 if form == 1 else 1), q)
+        gates.append("Product(%s, Sum(Sum(%s, Product(%s, %s)), Negated(%s)))" % (q, a, b, c, d))
     advice_queries = ["(%s, Rotation(%d))" % (_col(j, "Advice"), r) for (j, r) in shape.advice_queries]
     fixed_queries = ["(%s, Rotation(0))" % _col(halo2_fixed_column(shape, i), "Fixed") for i in range(shape.n_fix)]
     perm_cols = [_col(halo2_fixed_column(shape, i), "Fixed") if kind == "fixed" else _col(i, "Advice") for (kind, i) in shape.perm_cols]

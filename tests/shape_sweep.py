@@ -29,7 +29,7 @@ def mid_shapes(count, seed):
         L = 1 if A == 1 else pr.choice([1, 2, max(1, A // 6), max(1, A // 4)])
         F = pr.choice([1, 1, 2, 4])
         lb = pr.randrange(k - 4, k)
-        idle = pr.choice([0, 0, 0, 1, 3]) if A >= 4 else 0
+        idle = min(pr.choice([0, 0, 0, 1, 3]) if A >= 4 else 0, A // 2)
         out.append((A, L, F, k, lb, idle))
     return out
 

@@ -16,7 +16,11 @@ struct Layout {
     uint32_t k, n, A, L, F, lookup_bits, idle;
     bool single;
     uint32_t n_gate, n_lookup_cols, n_adv, fx_table, fx_qlookup, n_fix;
-    std::vector<uint32_t> fx_sel;
+    std::vector<uint32_t> fx_sel;    // the selector column a gate column OWNS (NO_SELECTOR: a never-enabled selector has none)
+    // gate j's selector after halo2's compress_selectors: fixed column | form << 24.  A never-enabled simple selector excludes
+    // nobody, so the greedy pass puts the t-th one into the column of gate t (degree 2 + 2 members <= 4), and both selectors of
+    // the pair are replaced: form 1 = q (2 - q) (the used one), form 2 = q (1 - q) (the never-enabled one); form 0 = q
+    std::vector<uint32_t> gate_sel;
     std::vector<Col> perm_cols;
     uint32_t n_lookups, degree, chunk_len, n_chunks, n_h, ext_k, usable;
     int last_rot;
@@ -25,7 +29,7 @@ struct Layout {
     bool init(const zk_circuit_params& p) {
         k = p.k; A = p.num_advice; L = p.num_lookup_advice; F = p.num_fixed; lookup_bits = p.lookup_bits;
         idle = p.num_idle_gate_columns;
-        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1 || idle >= A) return false;
+        if (k < 4 || k > 22 || A < 1 || L < 1 || F < 1 || idle >= A || 2 * idle > A) return false;  // (more idle than used: pairs of their own)
         if (lookup_bits < 1 || lookup_bits >= k) return false;  // the range table 0 .. 2^lookup_bits - 1 must fit in the usable rows
         n = 1u << k;
         single = A == 1;
@@ -44,6 +48,11 @@ struct Layout {
             for (uint32_t j = 0; j < A; j++) fx_sel.push_back(j < A - idle ? F + 1 + j : NO_SELECTOR);
             fx_qlookup = 0;
             n_fix = F + 1 + A - idle;
+        }
+        gate_sel.assign(fx_sel.begin(), fx_sel.end());
+        for (uint32_t t = 0; t < (single ? 0u : idle); t++) {
+            gate_sel[t] = fx_sel[t] | (1u << 24);
+            gate_sel[A - idle + t] = fx_sel[t] | (2u << 24);
         }
         perm_cols.clear();
         for (uint32_t f = 0; f < F; f++) perm_cols.push_back(Col{1, f});

@@ -16,7 +16,7 @@ static constexpr uint32_t MAX_CHUNKS = 176;
 static constexpr uint32_t MAX_LOOKUPS = 56;
 static constexpr uint32_t MAX_TERMS = MAX_ADV + 2 * MAX_CHUNKS + 1 + 5 * MAX_LOOKUPS;  // y-combination terms of the quotient
 static_assert(MAX_CHUNKS + MAX_LOOKUPS <= 256, "gp_chain_kernel scans all grand products of a proof in one 256-lane block");
-static constexpr uint32_t NO_SELECTOR = 0xffffffffu;  // gate column whose selector was compressed to the constant 0
+static constexpr uint32_t NO_SELECTOR = 0xffffffffu;  // gate column whose never-enabled selector owns no fixed column (it shares another gate's: Layout::gate_sel)
 static constexpr uint32_t BLINDING_FACTORS = 6;  // max(3, 4 queries per gate column) + 2
 
 struct LincombArgs {

@@ -161,28 +161,9 @@ void pk_destroy_all(zk_ctx* c) {
 }
 
 // halo2's transcript_repr of a key made (or read) here: the hash of the pinned verifying key's Debug rendering
-// (vkrepr.h).  Shapes with never-enabled gate columns, whose selector compression is not restated, keep a stand-in hash
-// over the shape and the commitments (same rule as the oracle's keygen); a host-supplied value replaces either.
-Fr pk_standin_transcript_repr(const zk_pk_rec* pk) {
-    const Layout& lay = pk->lay;
-    if (vkrepr::supported(lay)) return vkrepr::transcript_repr(lay, pk->fixed_commit, pk->perm_commit);
-    {
-        Blake2b h("zkmi355-vk-repr");
-        const uint16_t hdr[6] = {(uint16_t)lay.k, (uint16_t)lay.A,           (uint16_t)lay.L,
-                                 (uint16_t)lay.F, (uint16_t)lay.lookup_bits, (uint16_t)lay.idle};
-        h.update((const uint8_t*)hdr, 12);
-        auto absorb = [&](const G1Affine& p) {
-            const Fq x = fe_from_mont(p.x), y = fe_from_mont(p.y);
-            h.update((const uint8_t*)x.v, 32);
-            h.update((const uint8_t*)y.v, 32);
-        };
-        for (auto& p : pk->fixed_commit) absorb(p);
-        for (auto& p : pk->perm_commit) absorb(p);
-        uint8_t dg[64];
-        h.finalize_copy(dg);
-        return fr_from_u512_le(dg);
-    }
-}
+// (vkrepr.h) — every shape, never-enabled gate columns included (round 4: their combined selectors are rendered as
+// compress_selectors builds them; the stand-in hash of earlier rounds is gone).  A host-supplied value still replaces it.
+Fr pk_standin_transcript_repr(const zk_pk_rec* pk) { return vkrepr::transcript_repr(pk->lay, pk->fixed_commit, pk->perm_commit); }
 
 int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk) {
     const Layout& lay = pk->lay;
@@ -485,7 +466,7 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
     q.fx_qlookup = lay.fx_qlookup;
     for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = qc.adv[j];
     for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
-    for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.fx_sel[j];
+    for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.gate_sel[j];
     for (uint32_t p = 0; p < q.n_perm; p++) {
         q.sigma[p] = pk->sigma_coset[p];
         const Col& col = lay.perm_cols[p];

@@ -67,10 +67,14 @@ __device__ __forceinline__ Fr29 quotient_row(const QuotientArgs& a, uint32_t i, 
 
     // ---- gates: term j
     for (uint32_t j = sl; j < a.n_gate; j += ns) {
-        if (a.fx_sel[j] == NO_SELECTOR) continue;  // never-enabled gate: contributes 0 but keeps its power of y
+        // fx_sel[j] = fixed column | form << 24: the gate's selector after halo2's compress_selectors (pk.h Layout::gate_sel):
+        // form 0: q;  1: q (2 - q), the used selector of a combined pair;  2: q (1 - q), the never-enabled one — zero on the
+        // domain but not on the coset: the gate over the (blinded, otherwise empty) column contributes to h(X)
+        const uint32_t form = a.fx_sel[j] >> 24;
         const Fr* c = a.adv[j];
         const Fr29 a0 = q_load(c + i), a1 = q_load(c + rot(1)), a2 = q_load(c + rot(2)), a3 = q_load(c + rot(3));
-        const Fr29 q = q_load(a.fix[a.fx_sel[j]] + i);
+        Fr29 q = q_load(a.fix[a.fx_sel[j] & 0xffffffu] + i);
+        if (form) q = mul29(q, sub29<33, 29>(form == 1 ? add29(one, one) : one, q));  // 32 * 35 = 1120: (8 ; 29)
         const Fr29 m = mul29(a1, a2);                        // 32 * 32 = 1024: (8 ; 29)
         const Fr29 w = sub29<33, 29>(add29(a0, m), a3);      // (40 ; 30) - (32 ; 29): (73 ; 31.3)
         const Fr29 g = mul29(q, w);                          // 32 * 73 = 2336: (15 ; 29)

@@ -26,7 +26,7 @@
 
 namespace vkrepr {
 
-inline bool supported(const Layout& lay) { return lay.idle == 0; }
+inline bool supported(const Layout&) { return true; }  // (never-enabled gate columns used to be excluded)
 
 inline uint32_t halo2_fixed_column(const Layout& lay, uint32_t i) { return i < lay.F ? i + 1 : (i == lay.F ? 0 : i); }
 
@@ -44,6 +44,11 @@ inline std::string hex_of(const F& mont) {  // halo2curves Debug of a field elem
     char* p = buf;
     p += snprintf(p, 3, "0x");
     for (int w = 7; w >= 0; w--) p += snprintf(p, 9, "%08x", c.v[w]);
+    return std::string(buf);
+}
+inline std::string small_fe(uint32_t v) {  // the same Debug form of a small constant (Expression::Constant)
+    char buf[67];
+    snprintf(buf, sizeof(buf), "0x%056x%08x", 0u, v);
     return std::string(buf);
 }
 inline std::string point(const G1Affine& a) {
@@ -78,7 +83,11 @@ inline std::string pinned_debug(const Layout& lay, const std::vector<G1Affine>& 
     for (uint32_t i = 0; i < lay.n_fix; i++) fix_idx[i] = i;
     for (uint32_t l = 0; l < lay.n_lookup_cols; l++) lk_idx[l] = l;
     const std::string gates = join(gate_cols.begin(), gate_cols.end(), [&](uint32_t j) {
-        return "Product(" + fixed(lay, lay.fx_sel[j]) + ", Sum(Sum(" + advice(4 * j, j, 0) + ", Product(" + advice(4 * j + 1, j, 1) + ", " +
+        // the selector after compress_selectors: q, or for a combined pair q * (other_root - q) (pk.h Layout::gate_sel)
+        const uint32_t form = lay.gate_sel[j] >> 24;
+        std::string q = fixed(lay, lay.gate_sel[j] & 0xffffffu);
+        if (form) q = "Product(" + q + ", Sum(Constant(" + small_fe(form == 1 ? 2 : 1) + "), Negated(" + q + ")))";
+        return "Product(" + q + ", Sum(Sum(" + advice(4 * j, j, 0) + ", Product(" + advice(4 * j + 1, j, 1) + ", " +
                advice(4 * j + 2, j, 2) + ")), Negated(" + advice(4 * j + 3, j, 3) + ")))";
     });
     const std::string advice_queries = join(lay.advice_queries.begin(), lay.advice_queries.end(), [&](const std::pair<uint32_t, int>& q) {
