@@ -105,6 +105,13 @@ struct MsmWorkspace {
     // wide path (15 / 16-bit windows, fixed-base mode): per-column regions
     bool wide;
     bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
+    // per-bucket totals and level-2 cursors exist twice: pass i counts in set i & 1 while its first kernel — 131 K lanes with
+    // nothing to wait for — zeroes the other set for pass i + 1 (in the 16 waves of the last tail kernel the reset cost 25 us
+    // of exposed latency per pass)
+    uint32_t* w_tot[2];
+    uint32_t* w_cur[2];
+    uint32_t w_par;
+    uint32_t w_used_cols[2];    // columns of a set that hold counts of its last pass (what the next H1 has to zero)
     uint32_t w_ib, w_fb;        // entry layout: table index bits, fine key bits (msm_wide_shape)
     size_t w_ent_stride;        // entries per column region (multiple of 64)
     uint32_t w_lane_stride;     // accumulation lanes per column region
@@ -1020,7 +1027,15 @@ __device__ __forceinline__ uint32_t wide_slot_count(uint32_t s, uint32_t cnt) { 
 //   * the coarse scan is the prologue of the first scatter (every workgroup scans the <= 512 bin totals itself, workgroup
 //     0 publishes the header), the reset of the counters is the epilogue of the last tail kernel.
 static constexpr uint32_t WCB = 512;                  // coarse bins at most (65 536 buckets / 128, or 32 768 / 64)
-static constexpr uint32_t WHDR = 5 * (WCB + 1);       // per column: bin starts, chunk prefix, append cursors, (unused), part regions
+// per column: bin starts, chunk prefix, (unused), (unused), part regions — WCB + 1 words each — then the append cursors, ONE
+// PER 128-BYTE LINE: every workgroup of H1 ends with a returning atomic per bin on them (131 K atomics on 256 words per 2^19
+// column); side by side they would all land on 8 cache lines
+#ifndef ZK_WCUR_STRIDE
+#define ZK_WCUR_STRIDE 32
+#endif
+static constexpr uint32_t WCUR = ZK_WCUR_STRIDE;      // words between two append cursors
+static constexpr uint32_t WCUR0 = 5 * (WCB + 1);      // first cursor
+static constexpr uint32_t WHDR = WCUR0 + WCB * WCUR;  // words of the header; the workgroups' reserved bases [blocks][WCB] follow
 static constexpr uint32_t WSUB = 256 * 17;            // entries of a scatter sub-round: 256 scalars x all their windows (<= 17)
 
 struct WideGeo {
@@ -1077,18 +1092,40 @@ __device__ __forceinline__ void wide_wave_scan(const uint32_t* in, uint32_t bins
 // bin of `inter`: one returning atomic per non-empty bin on the append cursors, which end up holding the bins' totals
 template <uint32_t C>
 __global__ __launch_bounds__(256) void msm_whist_kernel(MsmBatch batch, uint32_t n, WideGeo g, uint32_t* __restrict__ coarse_all,
-                                                        uint32_t coarse_stride) {
+                                                        uint32_t coarse_stride, uint32_t* __restrict__ next_totals,
+                                                        uint32_t* __restrict__ next_cursor, uint32_t next_cols,
+                                                        uint32_t* __restrict__ counts) {
     __shared__ uint32_t hist[WCB];
     constexpr uint32_t NWIN = 254 / C + 1;
     const uint32_t col = blockIdx.y;
+    {
+        // the NEXT pass's per-bucket counters (the other set: nothing of this pass touches it) and this pass's redo count
+        // (next_cols: the columns the last pass on that set used — it may have been a wider batch than this one)
+        const uint32_t step = gridDim.x * 256;
+        for (uint32_t cc = col; cc < next_cols; cc += gridDim.y)
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < g.nb; i += step) {
+                next_totals[(size_t)cc * g.nb + i] = 0;
+                next_cursor[(size_t)cc * g.nb + i] = 0;
+            }
+        if (col == 0 && blockIdx.x == 0 && threadIdx.x == 0) counts[1] = 0;
+    }
     const Fr* __restrict__ scalars = batch.s[col];
     uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     for (uint32_t b = threadIdx.x; b < g.bins; b += 256) hist[b] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    constexpr uint32_t PERL = FCHUNK / 256;
+    Fr sv[PERL];  // the lane's scalars, all loads in flight together
+#pragma unroll
+    for (uint32_t q = 0; q < PERL; q++) {
+        const uint32_t i = lo + threadIdx.x + q * 256;
+        sv[q] = i < hi ? fe_load(scalars + i) : Fr::zero();
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < PERL; q++) {
+        if (lo + threadIdx.x + q * 256 >= hi) break;
         uint32_t u[9];
-        wide_biased(fe_load(scalars + i), g, u);
+        wide_biased(sv[q], g, u);
 #pragma unroll
         for (uint32_t w = 0; w < NWIN; w++) {
             const int32_t d = wide_digit<C>(u, w);
@@ -1098,7 +1135,7 @@ __global__ __launch_bounds__(256) void msm_whist_kernel(MsmBatch batch, uint32_t
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < g.bins; b += 256) {
         const uint32_t sum = hist[b];
-        chdr[WHDR + (size_t)blockIdx.x * WCB + b] = sum ? atomicAdd(&chdr[2 * (WCB + 1) + b], sum) : 0;
+        chdr[WHDR + (size_t)blockIdx.x * WCB + b] = sum ? atomicAdd(&chdr[WCUR0 + b * WCUR], sum) : 0;
     }
 }
 
@@ -1127,13 +1164,15 @@ __global__ __launch_bounds__(256) void msm_wscatter1_kernel(MsmBatch batch, uint
     const uint32_t* __restrict__ cbase = chdr + WHDR + (size_t)blockIdx.x * WCB;
     uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t bins = g.bins, keys = 1u << g.fb;
-    const uint32_t* __restrict__ tot = chdr + 2 * CB;
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) S.cnt[b] = chdr[WCUR0 + b * WCUR];  // the bins' totals (H1's cursors)
+    __syncthreads();
+    const uint32_t* tot = S.cnt;
     if (threadIdx.x < 64) {
         wide_wave_scan(tot, bins, S.lstart, [](uint32_t t) { return t; });
         if (blockIdx.x == 0) {
             wide_wave_scan(tot, bins, chdr, [](uint32_t t) { return t; });
             wide_wave_scan(tot, bins, chdr + CB, [](uint32_t t) { return (t + SUB - 1) / SUB; });
-            wide_wave_scan(tot, bins, chdr + 4 * CB, [&](uint32_t t) { return t ? (t / WL + 2 * keys + WCAP - 1) / WCAP + keys : 0u; });
+            wide_wave_scan(tot, bins, chdr + 4 * CB, [=](uint32_t t) { return t ? (t / WL + 2 * keys + WCAP - 1) / WCAP + keys : 0u; });
         }
     }
     __syncthreads();
@@ -1143,17 +1182,20 @@ __global__ __launch_bounds__(256) void msm_wscatter1_kernel(MsmBatch batch, uint
         counts[4 * col + 2] = chdr[4 * CB + bins];  // written by this wave above (same lane 63 -> memory; read back after the barrier)
     }
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
+    Fr next = lo + threadIdx.x < hi ? fe_load(scalars + lo + threadIdx.x) : Fr::zero();
     for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
         __syncthreads();  // gbase / the previous round's lstart, kid, sorted are free
         for (uint32_t b = threadIdx.x; b < bins; b += 256) S.cnt[b] = 0;
         __syncthreads();
         const uint32_t i = i0 + threadIdx.x;
+        const Fr cur = next;  // the next round's scalar is loaded under this round's sort
+        if (i + 256 < hi) next = fe_load(scalars + i + 256);
         uint32_t ent[NWIN], meta[NWIN];  // meta = key << 16 | rank, 0xffffffff = no entry
 #pragma unroll
         for (uint32_t w = 0; w < NWIN; w++) meta[w] = 0xffffffffu;
         if (i < hi) {
             uint32_t u[9];
-            wide_biased(fe_load(scalars + i), g, u);
+            wide_biased(cur, g, u);
 #pragma unroll
             for (uint32_t w = 0; w < NWIN; w++) {
                 const int32_t d = wide_digit<C>(u, w);
@@ -1199,6 +1241,12 @@ __global__ __launch_bounds__(256) void msm_wfinehist_kernel(const uint32_t* __re
     const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     const uint32_t* cpre = chdr + (WCB + 1);
+    if (blockIdx.x == gridDim.x - 1) {
+        // (one block more than the worst case of chunks is launched for this)  The append cursors of the coarse bins have been
+        // read by the first scatter: back to zero for the next pass's H1
+        uint32_t* cur = const_cast<uint32_t*>(chdr) + WCUR0;
+        for (uint32_t b = threadIdx.x; b < WCB; b += 256) cur[b * WCUR] = 0;
+    }
     if (blockIdx.x >= cpre[g.bins]) return;  // the grid is sized for the worst case
     if (threadIdx.x == 0) {
         uint32_t lo = 0, hi = g.bins;  // the bin whose chunk range holds blockIdx.x
@@ -1366,16 +1414,20 @@ __global__ __launch_bounds__(256) void msm_wscatter2_kernel(const uint32_t* __re
 
 // the counters a pass of the wide path expects to be zero: per-bucket totals and level-2 cursors, the append cursors of the
 // coarse bins, counts[].  Launched only when the workspace is not known to be clean (first pass, after an error or after the
-// 13-bit plan used the workspace): every pass leaves them clean (msm_wbits_kernel's epilogue)
-__global__ void msm_wclear_kernel(uint32_t* __restrict__ totals, uint32_t* __restrict__ cursor, uint32_t nbt,
-                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
+// 13-bit plan used the workspace): every pass leaves them clean (H1 zeroes the other set of per-bucket counters and the redo
+// count, the fine histogram's spare block the append cursors)
+__global__ void msm_wclear_kernel(uint32_t* __restrict__ totals, uint32_t* __restrict__ cursor, uint32_t* __restrict__ totals2,
+                                  uint32_t* __restrict__ cursor2, uint32_t nbt, uint32_t* __restrict__ counts,
+                                  uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nbt) {
         totals[i] = 0;
         cursor[i] = 0;
+        totals2[i] = 0;
+        cursor2[i] = 0;
     }
     if (i < 4 * (MSM_MAX_BATCH + 1)) counts[i] = 0;
-    if (i < ncols * WCB) coarse[(size_t)(i / WCB) * coarse_stride + 2 * (WCB + 1) + (i % WCB)] = 0;
+    if (i < ncols * WCB) coarse[(size_t)(i / WCB) * coarse_stride + WCUR0 + (i % WCB) * WCUR] = 0;
 }
 
 // the bucket of the entry at position `pos` of a column (the escape of a first-of-bucket entry whose distance field is
@@ -1585,24 +1637,8 @@ __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restric
 
 // T3: blockIdx.x = t < 9: sum of the column sums C_l with bit t of (l + 1) set; t >= 9: sum of the row sums R_h with bit
 // t - 9 of h set.  One wave each; lane 0 hands the sum over in the standard form.  out[col][WIDE_SUMS]
-__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out,
-                                                       uint32_t* __restrict__ totals_all, uint32_t* __restrict__ cursor_all,
-                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ coarse_all,
-                                                       uint32_t coarse_stride) {
+__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out) {
     const uint32_t col = blockIdx.y, rows = nb >> 8, t = blockIdx.x, lane = threadIdx.x;
-    {
-        // epilogue of the PASS (nothing after this kernel reads them): the column's counters go back to zero, shared among the
-        // kernel's waves.  The next pass on this workspace starts after the host has waited for this kernel.
-        const uint32_t step = gridDim.x * 64, first = t * 64 + lane;
-        for (uint32_t i = first; i < nb; i += step) {
-            totals_all[(size_t)col * nb + i] = 0;
-            cursor_all[(size_t)col * nb + i] = 0;
-        }
-        uint32_t* cur = coarse_all + (size_t)col * coarse_stride + 2 * (WCB + 1);
-        for (uint32_t i = first; i < WCB; i += step) cur[i] = 0;
-        if (col == 0)
-            for (uint32_t i = first; i < 4 * (gridDim.y + 1); i += step) counts[i] = 0;
-    }
     const G1X29S* __restrict__ rc = rc_all + (size_t)col * (rows + 256);
     const bool cols = t < 9;
     const uint32_t items = cols ? 256u : rows;
@@ -1794,6 +1830,10 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
             msm_workspace_destroy(ws);
             return nullptr;
         }
+        ws->w_tot[0] = ws->totals;
+        ws->w_cur[0] = ws->cursor;
+        MSM_TRY(hipMalloc(&ws->w_tot[1], (size_t)max_batch * ws->nb * 4));
+        MSM_TRY(hipMalloc(&ws->w_cur[1], (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_lane_b, (size_t)max_batch * ws->w_lane_stride * 4));
         MSM_TRY(hipMalloc(&ws->w_delta, (size_t)max_batch * ws->nb));
         MSM_TRY(hipMalloc(&ws->w_bstart, (size_t)max_batch * ws->nb * 4));
@@ -1821,6 +1861,10 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
     hipFree(ws->partial);
     hipFree(ws->part);
     hipFree(ws->bit_sum);
+    if (ws->wide) {
+        hipFree(ws->w_tot[1]);
+        hipFree(ws->w_cur[1]);
+    }
     hipFree(ws->w_lane_b);
     hipFree(ws->w_delta);
     hipFree(ws->w_bstart);
@@ -1869,10 +1913,15 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         uint32_t m = all;
         if (ws->max_batch * WCB > m) m = ws->max_batch * WCB;
         if (4 * (MSM_MAX_BATCH + 1) > m) m = 4 * (MSM_MAX_BATCH + 1);
-        hipLaunchKernelGGL(msm_wclear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->totals, ws->cursor, all, ws->counts, ws->coarse,
-                           ws->coarse_stride, ws->max_batch);
+        hipLaunchKernelGGL(msm_wclear_kernel, dim3((m + 255) / 256), dim3(256), 0, st, ws->w_tot[0], ws->w_cur[0], ws->w_tot[1], ws->w_cur[1],
+                           all, ws->counts, ws->coarse, ws->coarse_stride, ws->max_batch);
+        ws->w_used_cols[0] = ws->w_used_cols[1] = 0;
     }
     ws->w_clean = false;
+    uint32_t* const totals = ws->w_tot[ws->w_par];  // this pass's set of per-bucket counters; H1 zeroes the other one
+    uint32_t* const cursor = ws->w_cur[ws->w_par];
+    uint32_t* const next_totals = ws->w_tot[ws->w_par ^ 1];
+    uint32_t* const next_cursor = ws->w_cur[ws->w_par ^ 1];
     const uint32_t n32 = (uint32_t)n;
     const uint32_t lanes = (uint32_t)(((size_t)n * nwin + WL - 1) / WL);  // accumulation lanes of one column at most
     if (n > 0) {
@@ -1882,25 +1931,28 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         for (uint32_t q = 0; q < batch; q++) mb.s[q] = scalars_list[q];
         const dim3 gh(nblk, batch);
         if (c == 17) {
-            hipLaunchKernelGGL(msm_whist_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_whist_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, next_totals,
+                               next_cursor, ws->w_used_cols[ws->w_par ^ 1], ws->counts);
             hipLaunchKernelGGL(msm_wscatter1_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
                                ws->inter, ws->inter_stride, ws->counts, WCAP);
         } else if (c == 16) {
-            hipLaunchKernelGGL(msm_whist_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_whist_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, next_totals,
+                               next_cursor, ws->w_used_cols[ws->w_par ^ 1], ws->counts);
             hipLaunchKernelGGL(msm_wscatter1_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
                                ws->inter, ws->inter_stride, ws->counts, WCAP);
         } else {
-            hipLaunchKernelGGL(msm_whist_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride);
+            hipLaunchKernelGGL(msm_whist_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, next_totals,
+                               next_cursor, ws->w_used_cols[ws->w_par ^ 1], ws->counts);
             hipLaunchKernelGGL(msm_wscatter1_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
                                ws->inter, ws->inter_stride, ws->counts, WCAP);
         }
         const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + g.bins;
-        hipLaunchKernelGGL(msm_wfinehist_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, g, ws->totals);
-        hipLaunchKernelGGL(msm_wbinscan_kernel, dim3(g.bins, batch), dim3(1u << g.fb), 0, st, ws->coarse, ws->coarse_stride, g, ws->totals,
+        hipLaunchKernelGGL(msm_wfinehist_kernel, dim3(max_chunks + 1, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, g, totals);
+        hipLaunchKernelGGL(msm_wbinscan_kernel, dim3(g.bins, batch), dim3(1u << g.fb), 0, st, ws->coarse, ws->coarse_stride, g, totals,
                            ws->w_bstart, ws->w_delta, ws->w_lane_b, ws->w_lane_stride, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, WCAP);
         hipLaunchKernelGGL(msm_wscatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, g, ws->w_bstart, ws->cursor, ws->entries, ws->w_ent_stride, (const uint8_t*)ws->w_delta);
+                           ws->coarse_stride, g, ws->w_bstart, cursor, ws->entries, ws->w_ent_stride, (const uint8_t*)ws->w_delta);
         if (accum_events) hipEventRecord(accum_events[0], st);
         if (bases_may_be_identity) {
             hipLaunchKernelGGL(msm_wacc_kernel, dim3((lanes + 63) / 64, batch), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts,
@@ -1925,18 +1977,21 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
                                ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo, g.ib);
         // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_wscatter1_kernel)
         const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * g.bins + 64;
-        hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, ws->totals,
+        hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, totals,
                            ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
     }
-    hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, ws->totals, ws->w_bstart,
+    hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, totals, ws->w_bstart,
                        ws->w_pstart, nb, ws->w_rc, WCAP);
-    // T3; its epilogue zeroes this pass's counters (totals, cursors, append cursors, counts) for the next pass on this workspace
-    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum, ws->totals, ws->cursor,
-                       ws->counts, ws->coarse, ws->coarse_stride);
+    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts)) != hipSuccess)
         return e;
     ws->w_clean = true;
+    if (n > 0) {  // (an empty pass neither counts nor zeroes anything)
+        ws->w_used_cols[ws->w_par] = batch;
+        ws->w_used_cols[ws->w_par ^ 1] = 0;
+        ws->w_par ^= 1;  // the next pass counts in the set this one has zeroed
+    }
     return hipSuccess;
 }
 
