@@ -71,6 +71,8 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
 #define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..256 */
 #define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..11 (clamped to the tile) */
 #define ZK_OPT_GP_BATCH_INVERT 4     /* 1: grand products always take halo2's batch_invert form (the fallback path) */
+#define ZK_OPT_MSM_TAIL_STREAM 5     /* where the MSM reduction tails run: 0 auto (the context's side stream while at most two proofs
+                                        are in flight on the device, its main stream beyond), 1 side stream, 2 main stream */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

@@ -60,13 +60,21 @@ struct zk_ctx {
     uint64_t srs_gen = 0;  // bumped by every zk_srs_setup / zk_srs_load / zk_srs_read: keys remember the SRS they were made under
     // tuning options (zk_ctx_set_option); 0 = built-in choice
     uint32_t opt_msm_window = 0, opt_msm_batch = 0, opt_ntt_max_r = 0, opt_gp_batch_invert = 0;
-    // MSM lanes: each in-flight MSM owns a workspace, a tail stream and a pinned result buffer
+    uint32_t opt_tail_stream = 0;  // ZK_OPT_MSM_TAIL_STREAM: 0 auto, 1 always the context's tail stream, 2 always the main stream
+    // The context's TAIL stream (round 4: one, shared by the lanes; rounds 2-3 had one per lane).  Where a pass's reduction tail
+    // runs is decided per pass (ctx_msm_begin_batch): on this stream while at most two proofs are in flight on the device — a
+    // lone proof hides its tails behind its next head —, on the main stream beyond that: HIP maps streams onto FOUR hardware
+    // queues, and streams that share a queue run in order, so with three or more pipelines every extra stream puts some
+    // pipeline's kernels behind another's accumulation (measured, tools/queue_ab2.sh: 4 pipelines 103.7 proofs/s with one
+    // stream each, 99.1 with a tail stream each even on 8 queues, 94.4 for round 3's 2 pipelines x 4 streams)
+    hipStream_t tail_stream = nullptr;
+    // MSM lanes: each in-flight MSM owns a workspace and a pinned result buffer
     static constexpr int MSM_LANES = 3;
     struct MsmLane {
         MsmWorkspace* ws = nullptr;      // fixed-base mode over the resident SRS (window = the tables')
         MsmWorkspace* ws_gen = nullptr;  // arbitrary bases (the fine-grained seam): its own workspace, so that a host mixing both does not rebuild one per call
         MsmWorkspace* ws_run = nullptr;  // the one the MSM in flight uses
-        hipStream_t tail = nullptr;
+        hipStream_t tail = nullptr;      // the stream the tail of the MSM in flight runs on (the context's tail stream or its main stream)
         hipEvent_t head_done = nullptr, tail_done = nullptr;
         hipEvent_t t_head[2] = {nullptr, nullptr}, t_acc[2] = {nullptr, nullptr};  // timing: whole head / accumulate kernel
         size_t n = 0;
@@ -132,6 +140,10 @@ struct zk_ctx {
 
 
 int ctx_bind(zk_ctx* c);
+// proofs in flight on a device (all contexts of the process): decides where the MSM reduction tails run (engine.hip)
+void ctx_proof_enter(int device);
+void ctx_proof_leave(int device);
+int ctx_proofs_in_flight(int device);
 void ctx_release_spares(zk_ctx* c);  // frees the vectors zk_poly_free parked (caller holds c->mu, device bound)
 int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);

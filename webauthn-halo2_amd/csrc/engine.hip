@@ -3,6 +3,7 @@
 // include/zkmi355.h).
 #include <stdlib.h>
 
+#include <atomic>
 #include <new>
 
 #include "ctx.h"
@@ -190,6 +191,17 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     return ZK_OK;
 }
 
+namespace {
+std::atomic<int> g_proofs_in_flight[64];
+}
+void ctx_proof_enter(int device) {
+    if (device >= 0 && device < 64) g_proofs_in_flight[device].fetch_add(1);
+}
+void ctx_proof_leave(int device) {
+    if (device >= 0 && device < 64) g_proofs_in_flight[device].fetch_sub(1);
+}
+int ctx_proofs_in_flight(int device) { return device >= 0 && device < 64 ? g_proofs_in_flight[device].load() : 0; }
+
 int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_t batch, const G1Affine* d_bases, size_t n) {
     if (lane < 0 || lane >= zk_ctx::MSM_LANES || c->lanes[lane].busy || batch == 0) return ZK_EINVAL;
     zk_ctx::MsmLane& L = c->lanes[lane];
@@ -211,6 +223,8 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     int rc = get_msm_ws(c, lane, table ? (size_t)stride : n, table ? c->table_c : 0u, &ws);
     if (rc) return rc;
     if (batch > 1 && (!table || batch > msm_ws_max_batch(ws))) return ZK_EINVAL;
+    // where this pass's reduction tail runs (ctx.h tail_stream): the side stream for up to two proofs in flight on the device
+    L.tail = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && ctx_proofs_in_flight(c->device) > 2) ? c->stream : c->tail_stream;
     HIPCHK(c, hipEventRecord(L.t_head[0], c->stream));
     HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
                       L.head_done, !table || ident));
@@ -317,9 +331,14 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
             zk_ctx_destroy(c);
             return ZK_EHIP;
         }
+    if (hipStreamCreate(&c->tail_stream) != hipSuccess) {
+        zk_ctx_destroy(c);
+        return ZK_EHIP;
+    }
     for (int i = 0; i < zk_ctx::MSM_LANES; i++) {
         zk_ctx::MsmLane& L = c->lanes[i];
-        if (hipStreamCreate(&L.tail) != hipSuccess || hipEventCreate(&L.t_head[0]) != hipSuccess ||
+        L.tail = c->tail_stream;
+        if (hipEventCreate(&L.t_head[0]) != hipSuccess ||
             hipEventCreate(&L.t_head[1]) != hipSuccess || hipEventCreate(&L.t_acc[0]) != hipSuccess ||
             hipEventCreate(&L.t_acc[1]) != hipSuccess || hipEventCreateWithFlags(&L.head_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.tail_done, hipEventDisableTiming) != hipSuccess ||
@@ -360,6 +379,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
         c->opt_msm_batch = parent->opt_msm_batch;
         c->opt_ntt_max_r = parent->opt_ntt_max_r;
         c->opt_gp_batch_invert = parent->opt_gp_batch_invert;
+        c->opt_tail_stream = parent->opt_tail_stream;
         c->srs_gen++;
     }
     *out = c;
@@ -370,6 +390,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
     for (auto& kv : c->twiddles_ninv) hipFree(kv.second);
@@ -380,7 +401,6 @@ void zk_ctx_destroy(zk_ctx* c) {
     c->srs.reset();  // frees the bases and tables unless another context shares them
     for (int i = 0; i < zk_ctx::MSM_LANES; i++) {
         zk_ctx::MsmLane& L = c->lanes[i];
-        if (L.tail) hipStreamSynchronize(L.tail);
         if (L.ws) msm_workspace_destroy(L.ws);
         if (L.ws_gen) msm_workspace_destroy(L.ws_gen);
         if (L.host_buf) hipHostFree(L.host_buf);
@@ -390,7 +410,6 @@ void zk_ctx_destroy(zk_ctx* c) {
         }
         if (L.head_done) hipEventDestroy(L.head_done);
         if (L.tail_done) hipEventDestroy(L.tail_done);
-        if (L.tail) hipStreamDestroy(L.tail);
     }
     if (c->host_small) hipHostFree(c->host_small);
     if (c->scratch) hipFree(c->scratch);
@@ -400,6 +419,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (int i = 0; i < ZK_T_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) hipEventDestroy(c->ev[i][j]);
+    if (c->tail_stream) hipStreamDestroy(c->tail_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -458,6 +478,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_MSM_WINDOW:
             if (value && (value < 9 || value > 17)) return ZK_EINVAL;
             c->opt_msm_window = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_MSM_TAIL_STREAM:
+            if (value > 2) return ZK_EINVAL;
+            c->opt_tail_stream = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_MSM_BATCH:
             if (value > MSM_MAX_BATCH) return ZK_EINVAL;

@@ -1493,7 +1493,15 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     Blake2bTranscript b2;
     Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
     Prover p(c, pk, rng_seed, tr);
-    rc = p.run(adv.data(), scheme);
+    {
+        // the proofs in flight on the device decide where the MSM tails run (engine.hip); counted down on every way out
+        struct InFlight {
+            int d;
+            explicit InFlight(int dev) : d(dev) { ctx_proof_enter(d); }
+            ~InFlight() { ctx_proof_leave(d); }
+        } in_flight(c->device);
+        rc = p.run(adv.data(), scheme);
+    }
     ctx_msm_drain(c);  // an early error may leave commitments in flight
     hipStreamSynchronize(c->stream);
     if (rc) return rc;
