@@ -544,18 +544,42 @@ def test_k19_batch_of_8_jobs_equals_committed_oracle_proofs():
     p = zk.circuit.K19
     wit = batch.synthesize_jobs(p, jobs)
     fixed, copies = batch.structure(p)
-    pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True) for _ in range(2)]
-    for q, pl in enumerate(pipes):
-        for j in jobs[q::2]:
-            pl.load(j, wit[j])
-    got = batch.run(pipes, jobs, E.ZK_TRANSCRIPT_BLAKE2B)
-    for pl in pipes:
-        pl.close()
-    assert sorted(got) == jobs
-    for j in jobs:
-        assert len(got[j]) == 960
-        assert hashlib.sha256(got[j]).hexdigest() == fx["jobs"][str(j)]["sha256"], j
-        assert got[j].hex() == fx["jobs"][str(j)]["proof"], j
+    # two pipelines (each MSM pass's reduction tail on its context's side stream), then bench.py's four (three or more proofs
+    # in flight: the tails follow on the main streams — engine.hip ctx_msm_begin_batch)
+    for npipe in (2, 4):
+        pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)]
+        for _ in range(npipe - 1):
+            pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
+        for q, pl in enumerate(pipes):
+            for j in jobs[q::npipe]:
+                pl.load(j, wit[j])
+        got = batch.run(pipes, jobs, E.ZK_TRANSCRIPT_BLAKE2B)
+        for pl in pipes[::-1]:
+            pl.close()
+        assert sorted(got) == jobs
+        for j in jobs:
+            assert len(got[j]) == 960
+            assert hashlib.sha256(got[j]).hexdigest() == fx["jobs"][str(j)]["sha256"], (npipe, j)
+            assert got[j].hex() == fx["jobs"][str(j)]["proof"], (npipe, j)
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["tails-on-side-stream", "tails-on-main-stream"])
+def test_tail_stream_placement_does_not_change_proofs(mode):
+    """ZK_OPT_MSM_TAIL_STREAM pins where the MSM reduction tails run (the default decides per pass from the proofs in flight
+    on the device): the same bytes as the oracle's either way, at a shape whose commitments take the wide path (k = 10)."""
+    A, L, F, k, lb = SHAPES["k10batched"][:5]
+    eng = zk.Engine(0)
+    eng.set_option(E.ZK_OPT_MSM_TAIL_STREAM, mode)
+    p, asg, pk, polys = setup(eng, A, L, F, k, lb)
+    sh = plonk.Shape(k, A, L, F, lb)
+    opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
+    seed = bytes([mode]) * 32
+    for kind in ("blake2b", "evm"):
+        assert eng.prove(pk, polys, seed, KIND[kind]) == prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), kind)
+    for h in polys:
+        h.free()
+    eng.pk_free(pk)
+    eng.close()
 
 
 def test_shared_srs_contexts():
