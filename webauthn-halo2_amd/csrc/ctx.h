@@ -78,6 +78,7 @@ struct zk_ctx {
         hipEvent_t head_done = nullptr, tail_done = nullptr;
         hipEvent_t t_head[2] = {nullptr, nullptr}, t_acc[2] = {nullptr, nullptr};  // timing: whole head / accumulate kernel
         size_t n = 0;
+        const G1Affine* table = nullptr;  // the window table of the MSM in flight (fixed-base mode)
         G1X* host_buf = nullptr;  // pinned
         bool busy = false;
         uint32_t nwin = 0, cw = 0;

@@ -73,6 +73,10 @@ uint32_t msm_sums_per_result(uint32_t c);
 // fixed-base mode, by workspace (the wide path of 15 / 16-bit windows hands over 16 sums per column)
 uint32_t msm_ws_sums_per_result(const MsmWorkspace* ws);
 G1Jac msm_ws_finish_fixed(const MsmWorkspace* ws, const G1X* sums);
+// wide path: lanes of the unchecked accumulation that must be redone with the checked loop (0 unless the basis is degenerate),
+// as reported with the pass's sums, and that redo + the tail again (results into host_window_sums once `st` has drained)
+uint32_t msm_wide_redo_count(const MsmWorkspace* ws, const G1X* host_window_sums, uint32_t batch);
+hipError_t msm_wide_redo(MsmWorkspace* ws, uint32_t batch, size_t n, hipStream_t st, G1X* host_window_sums, const G1Affine* table);
 // Host-side finish: Horner over windows -> Jacobian (Montgomery).
 G1Jac msm_finish_host(const G1X* window_sums, uint32_t nwin, uint32_t c);
 

@@ -233,6 +233,7 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     c->msm_launches++;
     L.n = n;
     L.batch = batch;
+    L.table = table;
     L.fixed = table != nullptr;
     L.busy = true;
     return ZK_OK;
@@ -247,6 +248,11 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
     zk_ctx::MsmLane& L = c->lanes[lane];
     L.busy = false;
     HIPCHK(c, hipEventSynchronize(L.tail_done));
+    if (L.fixed && L.n > 0 && msm_wide_redo_count(L.ws_run, L.host_buf, L.batch)) {
+        // a degenerate basis (equal or opposite points): the unchecked accumulation reported lanes to redo with the checked loop
+        HIPCHK(c, msm_wide_redo(L.ws_run, L.batch, L.n, L.tail, L.host_buf, L.table));
+        HIPCHK(c, hipStreamSynchronize(L.tail));
+    }
     if (L.fixed) {
         // fixed-base mode: one independent result per column
         const uint32_t per = msm_ws_sums_per_result(L.ws_run);

@@ -1637,8 +1637,13 @@ __global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restric
 
 // T3: blockIdx.x = t < 9: sum of the column sums C_l with bit t of (l + 1) set; t >= 9: sum of the row sums R_h with bit
 // t - 9 of h set.  One wave each; lane 0 hands the sum over in the standard form.  out[col][WIDE_SUMS]
-__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out) {
+__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out,
+                                                       const uint32_t* __restrict__ counts) {
     const uint32_t col = blockIdx.y, rows = nb >> 8, t = blockIdx.x, lane = threadIdx.x;
+    // the word after the last column's sums tells the host how many lanes of the unchecked accumulation saw an exceptional
+    // step (same x: possible only over a degenerate basis): it then re-runs those lanes and this tail (msm_wide_redo) — the
+    // common case pays no redo launch
+    if (col == 0 && t == 0 && lane == 0) *reinterpret_cast<uint32_t*>(out + (size_t)gridDim.y * WIDE_SUMS) = counts[1];
     const G1X29S* __restrict__ rc = rc_all + (size_t)col * (rows + 256);
     const bool cols = t < 9;
     const uint32_t items = cols ? 256u : rows;
@@ -1970,11 +1975,6 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         ts = tail_st;
     }
     if (n > 0) {
-        // the checked re-run of the lanes the unchecked accumulation reported (almost always none) opens the TAIL: on the main
-        // stream this launch — a no-op — queued behind the other pipeline's accumulation for ~50 us per pass
-        if (!bases_may_be_identity)
-            hipLaunchKernelGGL(msm_wacc_redo_kernel, dim3(256), dim3(64), 0, ts, ws->entries, ws->w_ent_stride, table, ws->counts, ws->w_lane_b,
-                               ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo, g.ib);
         // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_wscatter1_kernel)
         const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * g.bins + 64;
         hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, totals,
@@ -1982,10 +1982,13 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     }
     hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, totals, ws->w_bstart,
                        ws->w_pstart, nb, ws->w_rc, WCAP);
-    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, ws->bit_sum);
+    // T3 writes its sums (and the redo count) STRAIGHT into the caller's pinned host buffer: 17 x 128 bytes per column over the
+    // bus instead of a copy kernel at the end of every pass's chain (host_window_sums must be device-visible pinned memory: the
+    // engine's lanes allocate it with hipHostMalloc)
+    G1X* out_dev = nullptr;
+    if ((e = hipHostGetDevicePointer((void**)&out_dev, host_window_sums, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, out_dev, ws->counts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(host_window_sums, ws->bit_sum, (size_t)batch * WIDE_SUMS * sizeof(G1X), hipMemcpyDeviceToHost, ts)) != hipSuccess)
-        return e;
     ws->w_clean = true;
     if (n > 0) {  // (an empty pass neither counts nor zeroes anything)
         ws->w_used_cols[ws->w_par] = batch;
@@ -1993,6 +1996,39 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         ws->w_par ^= 1;  // the next pass counts in the set this one has zeroed
     }
     return hipSuccess;
+}
+
+// The unchecked accumulation of the wide path lists the lanes whose sums show an exceptional step; the count travels to the host
+// with the pass's sums (msm_wbits_kernel).  Non-zero — a degenerate basis only — and the host calls this: the listed lanes again
+// with the checked loop, then the tail again, on `st`; the pass's workspace is intact until the lane's next pass.
+uint32_t msm_wide_redo_count(const MsmWorkspace* ws, const G1X* host_window_sums, uint32_t batch) {
+    if (!ws->wide) return 0;
+    uint32_t v;
+    memcpy(&v, host_window_sums + (size_t)batch * WIDE_SUMS, 4);
+    return v;
+}
+
+hipError_t msm_wide_redo(MsmWorkspace* ws, uint32_t batch, size_t n, hipStream_t st, G1X* host_window_sums, const G1Affine* table) {
+    if (!ws->wide || n == 0 || batch == 0 || batch > ws->max_batch) return hipErrorInvalidValue;
+    const uint32_t nb = ws->nb, rows = nb >> 8, nwin = ws->nwin, WCAP = wcap_for(batch);
+    uint32_t row_bits = 0;
+    while ((1u << row_bits) < rows) row_bits++;
+    const uint32_t lanes = (uint32_t)(((size_t)n * nwin + WL - 1) / WL);
+    const uint32_t bins = nb >> ws->w_fb;
+    uint32_t* const totals = ws->w_tot[ws->w_par ^ 1];  // the set the pass counted in (the parity has moved on)
+    hipLaunchKernelGGL(msm_wacc_redo_kernel, dim3(256), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts, ws->w_lane_b,
+                       ws->w_lane_stride, ws->w_bstart, nb, ws->slot_pt, ws->w_slot_stride, ws->redo, ws->w_ib);
+    hipError_t e = hipMemsetAsync(ws->counts + 1, 0, 4, st);  // the second tail reports none
+    if (e != hipSuccess) return e;
+    const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * bins + 64;
+    hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, st, ws->slot_pt, ws->w_slot_stride, totals,
+                       ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
+    hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, st, ws->w_part, ws->w_part_stride, totals, ws->w_bstart,
+                       ws->w_pstart, nb, ws->w_rc, WCAP);
+    G1X* out_dev = nullptr;
+    if ((e = hipHostGetDevicePointer((void**)&out_dev, host_window_sums, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, st, ws->w_rc, nb, out_dev, ws->counts);
+    return hipGetLastError();
 }
 
 // `table` != nullptr selects the fixed-base mode: table[w * table_stride + i] = 2^(c w) P_i.
