@@ -225,6 +225,26 @@ def cpu_baseline(budget_s=30.0):
     return fastprover.cpu_baseline(K, budget_s)
 
 
+def check_against_oracle_digests(proofs):
+    """Every timed proof against the committed SHA-256 of the ORACLE's proof of the same job (tests/golden/batch_k19_sha256.json:
+    all 256 jobs of BASELINE configs[3], made by the oracle's CPU prover in the build container — data, no oracle code runs
+    here).  Returns the number of proofs compared; a mismatch raises."""
+    import hashlib
+
+    path = os.path.join(ROOT, "tests", "golden", "batch_k19_sha256.json")
+    if not os.path.exists(path):
+        return 0
+    want = json.load(open(path))["sha256"]
+    n = 0
+    for j, pf in proofs.items():
+        w = want.get(str(j))
+        if w is not None:
+            if hashlib.sha256(pf).hexdigest() != w:
+                raise SystemExit("bench.py: proof of job %d differs from the oracle's (tests/golden/batch_k19_sha256.json)" % j)
+            n += 1
+    return n
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -332,6 +352,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert len(wl.proofs) == args.steps
+    # byte parity of the timed steps themselves: every rank compares its proofs with the oracle's digests (outside the clock)
+    oracle_checked = 0 if fake else check_against_oracle_digests(wl.proofs)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if fake else "cuda")
@@ -340,8 +362,15 @@ def main():
         per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if dist is not None and not fake:
+        tc = torch.tensor([oracle_checked], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        oracle_checked = int(tc.item())
     launcher = {"launcher": "torchrun" if dist is not None else "in-process",
-                "dist_backend": (dist.get_backend() if dist is not None else None), "ms_per_step_per_rank": per_rank_ms}
+                "dist_backend": (dist.get_backend() if dist is not None else None), "ms_per_step_per_rank": per_rank_ms,
+                # timed proofs (all ranks) whose bytes were compared with the oracle's committed digests: all of them for the
+                # 256-job batch of configs[3]
+                "proofs_checked_against_oracle_digests": oracle_checked}
     # Two further timed repeats of the same K jobs (after `value`'s region, same barriers and max-over-ranks clock): their
     # spread says how large a round-over-round delta must be before it means anything (boxes and runs differ by ~3 %).
     repeats = [world * args.steps / elapsed]

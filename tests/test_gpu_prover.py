@@ -238,7 +238,7 @@ def test_reference_api_mirror(engine, tmp_path):
     import json
     from webauthn_halo2_amd import ecdsa_p256 as api, proving_server as srv
 
-    api._STATE.clear()
+    api.shutdown()
     pkp, vkp = str(tmp_path / "proving_key.pk"), str(tmp_path / "verifying_key.vk")
     api.download_keys(17, pkp, vkp)
     eng = api._STATE[0]["eng"]
@@ -287,8 +287,18 @@ def test_reference_api_mirror(engine, tmp_path):
     for brk in (dict(body, r=list(req[2])[:31]), dict(body, s=[256] + list(req[3])[1:]), {k: v for k, v in body.items() if k != "msghash"}):
         with pytest.raises(ValueError):
             srv.prove_evm(brk)
-    eng.close()
-    api._STATE.clear()
+    # requests in flight side by side (ecdsa_p256.PIPELINES_PER_DEVICE pipelines on the device): six concurrent requests with
+    # fixed blinding seeds give the bytes of the lone ones
+    import threading
+    conc = [None] * 6
+    def one(i):
+        conc[i] = api.generate_proof_evm_synthetic(*req, pkp, 17, rng_seed=bytes(32))
+    ths = [threading.Thread(target=one, args=(i,)) for i in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert conc == [pe] * 6 and len(api._STATE[0]["extra"]) == api.PIPELINES_PER_DEVICE - 1
+    api.shutdown()
+    assert not api._STATE
 
 
 def test_batch_of_jobs_equals_lone_proofs():
@@ -580,6 +590,31 @@ def test_tail_stream_placement_does_not_change_proofs(mode):
         h.free()
     eng.pk_free(pk)
     eng.close()
+
+
+def test_k19_batch_slice_through_four_pipelines_matches_oracle_digests():
+    """BASELINE configs[3] as bench.py runs it on one GPU: a slice of the 256-job batch (jobs 40 .. 71: beyond the eight whose
+    full bytes are committed) through FOUR pipelines — tails on the main streams — against the oracle's digests of the same jobs
+    (tests/golden/batch_k19_sha256.json, tests/golden/make_batch_hashes.py)."""
+    from webauthn_halo2_amd import batch
+
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch_k19_sha256.json")))["sha256"]
+    jobs = [j for j in range(40, 72) if str(j) in want]
+    assert len(jobs) >= 16
+    p = zk.circuit.K19
+    wit = batch.synthesize_jobs(p, jobs)
+    fixed, copies = batch.structure(p)
+    pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)]
+    for _ in range(3):
+        pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
+    for q, pl in enumerate(pipes):
+        for j in jobs[q::4]:
+            pl.load(j, wit[j])
+    got = batch.run(pipes, jobs, E.ZK_TRANSCRIPT_BLAKE2B)
+    for pl in pipes[::-1]:
+        pl.close()
+    for j in jobs:
+        assert len(got[j]) == 960 and hashlib.sha256(got[j]).hexdigest() == want[str(j)], j
 
 
 def test_shared_srs_contexts():

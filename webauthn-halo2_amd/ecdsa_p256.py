@@ -27,6 +27,7 @@ What the scope of this repository imposes, stated where a caller
 """
 import hashlib
 import os
+import queue
 import threading
 
 import numpy as np
@@ -34,8 +35,15 @@ import numpy as np
 from . import circuit
 from .engine import ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM, Engine
 
-_STATE = {}  # (device) -> {"eng": Engine, "k": int, "keys": {path: (params, pk_handle)}, "slots": {columns: [[Poly]]}}
+# (device) -> {"eng": Engine, "k": int, "keys": {path: (params, pk_handle)}, "slots": {columns: [[Poly]]},
+#              "extra": [{"eng": Engine sharing the first one's SRS, "keys": {path: pk_handle}, "slots": {..}}], "free": Queue of pipeline indices}
+_STATE = {}
 _SLOTS_LOCK = threading.Lock()
+# Proof pipelines per device = requests proved CONCURRENTLY on it (the reference: one Rocket worker thread per request,
+# proving-server/src/main.rs:457-472).  Each is a context of its own (own key, own workspace, shared SRS and window tables).
+# Two is the measured optimum for the server's default shape: 144 / 195 / 173 / 183 proofs/s at k = 17 with 1 / 2 / 3 / 4
+# (tools/inflight_k17.py, DESIGN.md §5 "Streams and hardware queues"); k = 19 batches want four (batch.py, bench.py).
+PIPELINES_PER_DEVICE = 2
 _MAX_SLOT_SETS = 4  # parked request-slot sets per column count: the server's usual number of requests in flight per device
 
 
@@ -56,7 +64,7 @@ def _config_for(degree: int) -> circuit.CircuitParams:
 
 def gen_srs(degree: int, device: int = 0) -> Engine:
     """halo2-base `gen_srs(k)`: ParamsKZG::setup(k, ChaCha20Rng::from_seed([0; 32])), kept resident."""
-    st = _STATE.setdefault(device, {"eng": None, "k": None, "keys": {}, "slots": {}})
+    st = _STATE.setdefault(device, {"eng": None, "k": None, "keys": {}, "slots": {}, "extra": [], "free": None})
     if st["eng"] is None:
         st["eng"] = Engine(device)
     if st["k"] != degree:
@@ -69,9 +77,36 @@ def gen_srs(degree: int, device: int = 0) -> Engine:
                     for h in polys:
                         h.free()
             st["slots"].clear()
+        for m in st["extra"]:  # the further pipelines saw the old SRS: they go with it
+            m["eng"].close()
+        st["extra"] = []
         st["eng"].srs_setup(degree, bytes(32))
         st["k"] = degree
+        st["extra"] = [{"eng": Engine(device, share_with=st["eng"]), "keys": {}, "slots": {}} for _ in range(max(1, PIPELINES_PER_DEVICE) - 1)]
+        st["free"] = queue.LifoQueue()
+        for i in range(len(st["extra"]), -1, -1):  # pipeline 0 (the first context) on top: a lone request takes it
+            st["free"].put(i)
     return st["eng"]
+
+
+def shutdown(device=None):
+    """Release the resident state (every pipeline's context, keys and request slots) of `device`, or of all devices."""
+    for d in ([device] if device is not None else list(_STATE)):
+        st = _STATE.pop(d, None)
+        if not st:
+            continue
+        for m in st["extra"][::-1]:
+            m["eng"].close()
+        if st["eng"] is not None:
+            st["eng"].close()
+
+
+def _pipeline(st, i):
+    """(engine, {key name: pk handle}, request slots) of pipeline i of a device: 0 is the first context."""
+    if i == 0:
+        return st["eng"], {name: v[1] for name, v in st["keys"].items()}, st["slots"]
+    m = st["extra"][i - 1]
+    return m["eng"], m["keys"], m["slots"]
 
 
 def download_keys(degree: int, proving_key_path=None, verifying_key_path=None, device: int = 0):
@@ -83,12 +118,17 @@ def download_keys(degree: int, proving_key_path=None, verifying_key_path=None, d
     p = _config_for(degree)
     asg = circuit.synthesize(p, 0)  # structure only: fixed columns and copy constraints
     fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
-    keys = _STATE[device]["keys"]
+    st = _STATE[device]
+    keys = st["keys"]
     name = proving_key_path or "<default>"
     if name in keys:  # /setup called again: the resident key (GBs at k = 17 / 19) is replaced, not leaked
         eng.pk_free(keys.pop(name)[1])
     pk = eng.keygen(p, fixed, asg.copies)
     keys[name] = (p, pk)
+    for m in st["extra"]:  # every further pipeline of the device holds the key too (its own workspace comes with it)
+        if name in m["keys"]:
+            m["eng"].pk_free(m["keys"].pop(name))
+        m["keys"][name] = m["eng"].keygen(p, fixed, asg.copies)
     if verifying_key_path:
         with open(verifying_key_path, "wb") as f:
             f.write(eng.vk_write(pk).tobytes())
@@ -110,7 +150,7 @@ def create_proof_from_advice(advice_columns, proving_key_path, degree, transcrip
     """create_proof over host-synthesized advice columns — what an unchanged Rust host hands the engine
     after `ECDSACircuit::synthesize`.  `advice_columns`: sequence of (n, 4) uint64 arrays of canonical
     little-endian limbs, one per advice column of the key's shape."""
-    eng, p, pk = _resident_key(proving_key_path, degree, device)
+    _resident_key(proving_key_path, degree, device)  # (raises for an unknown key)
     n = 1 << degree
     cols = []
     for col in advice_columns:
@@ -118,9 +158,19 @@ def create_proof_from_advice(advice_columns, proving_key_path, degree, transcrip
         if col.shape != (n, 4):
             raise ValueError("an advice column must be an (n, 4) array of canonical limbs")
         cols.append(col)
+    # a pipeline of the device for this request: concurrent requests prove side by side (PIPELINES_PER_DEVICE), further ones wait
+    st = _STATE[device]
+    which = st["free"].get()
+    try:
+        eng, pks, slots = _pipeline(st, which)
+        return _prove_on(eng, pks[proving_key_path or "<default>"], slots, cols, n, degree, device, transcript, rng_seed)
+    finally:
+        st["free"].put(which)
+
+
+def _prove_on(eng, pk, slots, cols, n, degree, device, transcript, rng_seed):
     # request slots: the columns' device buffers are kept between requests (a hipFree per request would wait for the whole
     # device, i.e. for every other request in flight on it); concurrent requests each take a set of their own
-    slots = _STATE[device]["slots"]
     with _SLOTS_LOCK:
         free = slots.setdefault(len(cols), [])
         polys = free.pop() if free else None

@@ -72,20 +72,23 @@ def prove(body, device=0, degree=DEGREE, rng_seed=None) -> str:
 
 
 def prove_batch(bodies, evm=True, devices=(0,), degree=DEGREE):
-    """A recorded batch of requests over several GPUs: request i goes to devices[i % len(devices)], one host
-    thread per device (the reference: one Rocket worker thread per request, main.rs:457-472).  Every device
-    must have been `setup`.  Returns the hex proofs in request order; a failed request yields its exception."""
+    """A recorded batch of requests over several GPUs: request i goes to devices[i % len(devices)], and every device proves
+    `ecdsa_p256.PIPELINES_PER_DEVICE` of its requests side by side — one host thread per request in flight (the reference:
+    one Rocket worker thread per request, main.rs:457-472).  Every device must have been `setup`.  Returns the hex proofs in
+    request order; a failed request yields its exception."""
     bodies = list(bodies)
     out = [None] * len(bodies)
+    per = max(1, ecdsa_p256.PIPELINES_PER_DEVICE)
+    workers = len(devices) * per
 
     def work(q):
-        for i in range(q, len(bodies), len(devices)):
+        for i in range(q, len(bodies), workers):
             try:
-                out[i] = _prove(bodies[i], evm, devices[q], degree, None)
+                out[i] = _prove(bodies[i], evm, devices[q % len(devices)], degree, None)
             except Exception as e:  # the reference answers 500 for that request and keeps serving
                 out[i] = e
 
-    ths = [threading.Thread(target=work, args=(q,)) for q in range(len(devices))]
+    ths = [threading.Thread(target=work, args=(q,)) for q in range(workers)]
     for t in ths:
         t.start()
     for t in ths:
