@@ -596,6 +596,9 @@ def test_k19_batch_slice_through_four_pipelines_matches_oracle_digests():
     """BASELINE configs[3] as bench.py runs it on one GPU: a slice of the 256-job batch (jobs 40 .. 71: beyond the eight whose
     full bytes are committed) through FOUR pipelines — tails on the main streams — against the oracle's digests of the same jobs
     (tests/golden/batch_k19_sha256.json, tests/golden/make_batch_hashes.py)."""
+    import hashlib
+    import json
+
     from webauthn_halo2_amd import batch
 
     want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch_k19_sha256.json")))["sha256"]
