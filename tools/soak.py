@@ -1,6 +1,7 @@
-"""Determinism soak: N proofs of the k=19 shape over two concurrent pipelines, every proof of a job compared with the first
-proof of that job (same witness, same RNG seed -> same bytes).  A race between streams / lanes / pipelines shows up as a
-differing proof.  usage: soak.py [proofs_per_pipeline] [k]"""
+"""Determinism soak: N proofs of the k=19 shape over P concurrent pipelines (default 4: bench.py's regime — tails on the main
+streams, double-buffered pass counters; 2: a tail stream each), every proof of a job compared with the first proof of that job
+(same witness, same RNG seed -> same bytes).  A race between streams / lanes / pipelines shows up as a differing proof.
+usage: soak.py [proofs_per_pipeline] [k] [pipelines]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import webauthn_halo2_amd as zk
@@ -8,12 +9,14 @@ from webauthn_halo2_amd import batch, circuit, engine as E
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 19
+npipe = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 p = circuit.K19 if k == 19 else circuit.K17
 jobs = list(range(4))
 wit = batch.synthesize_jobs(p, jobs)
 fixed, copies = batch.structure(p)
 pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)]
-pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
+for _ in range(npipe - 1):
+    pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
 for pl in pipes:
     for j in jobs:
         pl.load(j, wit[j])
@@ -36,5 +39,5 @@ for t in ths:
 for t in ths:
     t.join()
 dt = time.time() - t0
-print("soak k=%d: %d proofs over 2 pipelines in %.1f s (%.1f proofs/s), mismatches: %d %s" % (k, 2 * reps, dt, 2 * reps / dt, len(bad), bad[:5]))
+print("soak k=%d: %d proofs over %d pipelines in %.1f s (%.1f proofs/s), mismatches: %d %s" % (k, npipe * reps, npipe, dt, npipe * reps / dt, len(bad), bad[:5]))
 sys.exit(1 if bad else 0)
