@@ -447,7 +447,7 @@ def main():
                 "avg_launch_ms": accum_ms,
                 "launches": int(acc_n),
                 "columns_per_launch": cols_per_launch,
-                "note": "integer-ALU-bound kernel (no MFMA, SURVEY.md 8d); MSM head (recode..accumulate) avg %.3f ms x %d per proof, tails overlapped on side streams; quotient kernel %.3f ms"
+                "note": "integer-ALU-bound kernel (no MFMA, SURVEY.md 8d); MSM pass, sort .. accumulate, avg %.3f ms x %d per proof as timed inside the overlapping pipelines (reduction tails: on the side stream up to two proofs in flight, on the main stream beyond); quotient kernel %.3f ms"
                 % (msm_total / max(msm_n, 1), msm_n // max(args.steps, 1), eng.last_ms(2)),
             },
         }
