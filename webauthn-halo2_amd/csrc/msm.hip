@@ -106,8 +106,8 @@ struct MsmWorkspace {
     bool wide;
     bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
     // per-bucket totals and level-2 cursors exist twice: pass i counts in set i & 1 while its first kernel — 131 K lanes with
-    // nothing to wait for — zeroes the other set for pass i + 1 (in the 16 waves of the last tail kernel the reset cost 25 us
-    // of exposed latency per pass)
+    // to spare (the fine histogram: two thousand workgroups) — zeroes the other set for pass i + 1 (in the 16 waves of the last
+    // tail kernel the reset cost 25 us of exposed latency per pass, in H1 13 us)
     uint32_t* w_tot[2];
     uint32_t* w_cur[2];
     uint32_t w_par;
@@ -118,7 +118,6 @@ struct MsmWorkspace {
     uint32_t w_slot_stride;     // slots per column region: lanes + buckets
     uint32_t w_part_stride;     // parts per column region
     uint32_t* w_lane_b;         // [max_batch][w_lane_stride] the bucket every lane starts in
-    uint8_t* w_delta;           // [max_batch][nb] distance of a bucket from the previous non-empty one (first-of-bucket entries carry it)
     uint32_t* w_bstart;         // [max_batch][nb] places of the buckets in their column's entry region
     uint32_t* w_pstart;         // [max_batch][nb] first part of every bucket
     uint32_t* w_pbucket;        // [max_batch][w_part_stride] bucket of every part
@@ -1092,25 +1091,13 @@ __device__ __forceinline__ void wide_wave_scan(const uint32_t* in, uint32_t bins
 // bin of `inter`: one returning atomic per non-empty bin on the append cursors, which end up holding the bins' totals
 template <uint32_t C>
 __global__ __launch_bounds__(256) void msm_whist_kernel(MsmBatch batch, uint32_t n, WideGeo g, uint32_t* __restrict__ coarse_all,
-                                                        uint32_t coarse_stride, uint32_t* __restrict__ next_totals,
-                                                        uint32_t* __restrict__ next_cursor, uint32_t next_cols,
-                                                        uint32_t* __restrict__ counts) {
+                                                        uint32_t coarse_stride, uint32_t* __restrict__ counts) {
     __shared__ uint32_t hist[WCB];
     constexpr uint32_t NWIN = 254 / C + 1;
     const uint32_t col = blockIdx.y;
-    {
-        // the NEXT pass's per-bucket counters (the other set: nothing of this pass touches it) and this pass's redo count
-        // (next_cols: the columns the last pass on that set used — it may have been a wider batch than this one)
-        const uint32_t step = gridDim.x * 256;
-        for (uint32_t cc = col; cc < next_cols; cc += gridDim.y)
-            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < g.nb; i += step) {
-                next_totals[(size_t)cc * g.nb + i] = 0;
-                next_cursor[(size_t)cc * g.nb + i] = 0;
-            }
-        if (col == 0 && blockIdx.x == 0 && threadIdx.x == 0) counts[1] = 0;
-    }
     const Fr* __restrict__ scalars = batch.s[col];
     uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
+    if (col == 0 && blockIdx.x == 0 && threadIdx.x == 0) counts[1] = 0;  // this pass's redo count
     for (uint32_t b = threadIdx.x; b < g.bins; b += 256) hist[b] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
@@ -1234,13 +1221,25 @@ __global__ __launch_bounds__(256) void msm_wscatter1_kernel(MsmBatch batch, uint
 // (a permuted lookup column at k = 19: 400 K entries in bin 0 — one workgroup needed 200 us for them).
 __global__ __launch_bounds__(256) void msm_wfinehist_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
                                                             const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
-                                                            uint32_t* __restrict__ totals_all) {
+                                                            uint32_t* __restrict__ totals_all, uint32_t* __restrict__ next_totals,
+                                                            uint32_t* __restrict__ next_cursor, uint32_t next_cols) {
     __shared__ uint32_t hist[128];
     __shared__ uint32_t s_bin, s_chunk;
     const uint32_t col = blockIdx.y, keys = 1u << g.fb;
     const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
     const uint32_t* cpre = chdr + (WCB + 1);
+    {
+        // the NEXT pass's per-bucket counters — the other set: nothing of this pass touches it — shared among this kernel's
+        // (worst-case many) workgroups (next_cols: the columns the last pass on that set used: it may have been a wider batch than
+        // this one).  In H1, whose lanes all have a scalar to wait for, the same stores cost 13 us
+        const uint32_t step = gridDim.x * 256;
+        for (uint32_t cc = col; cc < next_cols; cc += gridDim.y)
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < g.nb; i += step) {
+                next_totals[(size_t)cc * g.nb + i] = 0;
+                next_cursor[(size_t)cc * g.nb + i] = 0;
+            }
+    }
     if (blockIdx.x == gridDim.x - 1) {
         // (one block more than the worst case of chunks is launched for this)  The append cursors of the coarse bins have been
         // read by the first scatter: back to zero for the next pass's H1
@@ -1271,30 +1270,32 @@ __global__ __launch_bounds__(256) void msm_wfinehist_kernel(const uint32_t* __re
     }
 }
 
-// one workgroup (a lane per bucket: 128 / 64 / 32 lanes) per (coarse bin, column): the bin-local scans of the per-bucket
-// totals: bstart[b] (the bucket's place in the column's dense entry list), delta[b] (distance from the previous non-empty
-// bucket of the bin minus one, `esc` for a bin's first one or a longer gap: what the bucket's first entry tells the lane that
-// runs into it), lane_b[] (the bucket a lane starts in), pstart[b] / pbucket[] (the bucket's parts of at most WCAP slots, T1)
-// and the no-part markers at the end of the bin's part region.
-__global__ __launch_bounds__(128) void msm_wbinscan_kernel(const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
-                                                           const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
-                                                           uint8_t* __restrict__ delta_all, uint32_t* __restrict__ lane_b_all,
-                                                           uint32_t lane_stride, uint32_t* __restrict__ pstart_all,
-                                                           uint32_t* __restrict__ pbucket_all, uint32_t part_stride, uint32_t WCAP) {
-    __shared__ uint32_t wsum[4];
-    __shared__ int wlast[2];
+// The bin-local scans of the per-bucket totals (the first `keys` lanes of the workgroup, a lane per bucket of the bin; every lane
+// of the workgroup must call): the bucket's place in the column's dense entry list (returned) and its distance from the previous
+// non-empty bucket of the bin minus one (`esc` for a bin's first one or a longer gap: what the bucket's first entry tells the
+// accumulation lane that runs into it).  `publish`: also write what the LATER kernels read — bstart[b], lane_b[] (the bucket an
+// accumulation lane starts in), pstart[b] / pbucket[] (the bucket's parts of at most WCAP slots, T1) and the no-part markers at
+// the end of the bin's part region.  (Round 3 ran this as a kernel of its own between the fine histogram and the second scatter;
+// now every chunk of a bin redoes the two 128-element scans — a few microseconds — and the bin's first chunk publishes.)
+struct WideBinScan {
+    uint32_t wsum[4];
+    int wlast[2];
+};
+__device__ __forceinline__ uint32_t wide_binscan(WideBinScan& B, const uint32_t* __restrict__ chdr, const WideGeo& g, uint32_t col,
+                                                 uint32_t bin, const uint32_t* __restrict__ totals_all, bool publish,
+                                                 uint32_t* __restrict__ bstart_all, uint32_t* __restrict__ lane_b,
+                                                 uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket, uint32_t WCAP,
+                                                 uint32_t* delta_out) {
     constexpr uint32_t CB = WCB + 1;
-    const uint32_t col = blockIdx.y, bin = blockIdx.x, nb = g.nb, keys = blockDim.x;  // blockDim.x = 1 << fb
+    const uint32_t nb = g.nb, keys = 1u << g.fb;
     const uint32_t esc = (1u << (30 - g.ib)) - 1;
-    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    uint32_t* __restrict__ pbucket = pbucket_all + (size_t)col * part_stride;
-    uint32_t* __restrict__ lane_b = lane_b_all + (size_t)col * lane_stride;
+    const bool mine = threadIdx.x < keys;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t top = min(63u, keys - 1);  // the last lane of a wave of this workgroup
+    const uint32_t top = min(63u, keys - 1);  // the last lane of a wave that holds buckets
     const uint32_t b = bin * keys + threadIdx.x;
-    const uint32_t cnt = totals_all[(size_t)col * nb + b];
-    if (threadIdx.x < 4) wsum[threadIdx.x] = 0;
-    if (threadIdx.x < 2) wlast[threadIdx.x] = -1;
+    const uint32_t cnt = mine ? totals_all[(size_t)col * nb + b] : 0;
+    if (threadIdx.x < 4) B.wsum[threadIdx.x] = 0;
+    if (threadIdx.x < 2) B.wlast[threadIdx.x] = -1;
     __syncthreads();
     // exclusive scan of the counts -> place in the entry list
     uint32_t xe = cnt;
@@ -1307,58 +1308,78 @@ __global__ __launch_bounds__(128) void msm_wbinscan_kernel(const uint32_t* __res
             last = max(last, yl);
         }
     }
-    if (lane == top) {
-        wsum[2 * wave] = xe;
-        wlast[wave] = last;
+    if (mine && lane == top) {
+        B.wsum[2 * wave] = xe;
+        B.wlast[wave] = last;
     }
     __syncthreads();
-    const uint32_t s = chdr[bin] + xe - cnt + (wave ? wsum[0] : 0);
+    const uint32_t s = chdr[bin] + xe - cnt + (wave == 1 ? B.wsum[0] : 0);
     // the last non-empty bucket strictly before this one
     int prev = __shfl_up(last, 1);
     if (lane == 0) prev = -1;
-    if (wave) prev = max(prev, wlast[0]);
+    if (wave == 1) prev = max(prev, B.wlast[0]);
+    const uint32_t gap = prev < 0 ? esc : (uint32_t)((int)threadIdx.x - prev - 1);
+    *delta_out = gap < esc ? gap : esc;
+    if (!publish) return s;  // (workgroup-uniform)
     const uint32_t slots = wide_slot_count(s, cnt);
-    const uint32_t np = (slots + WCAP - 1) / WCAP;
+    const uint32_t np = mine ? (slots + WCAP - 1) / WCAP : 0;
     // exclusive scan of the part counts -> place in the bin's part region
     uint32_t xp = np;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t yp = __shfl_up(xp, off);
         if ((int)lane >= off) xp += yp;
     }
-    if (lane == top) wsum[2 * wave + 1] = xp;
+    if (mine && lane == top) B.wsum[2 * wave + 1] = xp;
     __syncthreads();
     const uint32_t pbase = chdr[4 * CB + bin], pend = chdr[4 * CB + bin + 1];
-    const uint32_t p_used = wsum[1] + wsum[3];
-    const uint32_t p0 = pbase + xp - np + (wave ? wsum[1] : 0);
-    bstart_all[(size_t)col * nb + b] = s;
-    pstart_all[(size_t)col * nb + b] = p0;
-    if (cnt) {
-        const uint32_t gap = prev < 0 ? esc : (uint32_t)((int)threadIdx.x - prev - 1);
-        delta_all[(size_t)col * nb + b] = (uint8_t)(gap < esc ? gap : esc);
-        // lanes whose first entry lies in this bucket
-        for (uint32_t t = (s + WL - 1) / WL; t * WL < s + cnt; t++) lane_b[t] = b;
+    const uint32_t p_used = B.wsum[1] + B.wsum[3];
+    const uint32_t p0 = pbase + xp - np + (wave == 1 ? B.wsum[1] : 0);
+    if (mine) {
+        bstart_all[(size_t)col * nb + b] = s;
+        pstart_all[(size_t)col * nb + b] = p0;
+        if (cnt)  // lanes whose first entry lies in this bucket
+            for (uint32_t t = (s + WL - 1) / WL; t * WL < s + cnt; t++) lane_b[t] = b;
+        for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
     }
-    for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
-    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += keys) pbucket[q] = 0xffffffffu;
+    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 256) pbucket[q] = 0xffffffffu;
+    return s;
 }
 
 // level 2 of the sort: one chunk (<= SUB entries) of one coarse bin into its buckets, dense (no padding): the first entry of
-// every bucket carries WIDE_FLAG and the bucket's distance from the previous non-empty one in its spare bits
+// every bucket carries WIDE_FLAG and the bucket's distance from the previous non-empty one in its spare bits.  The bin-local
+// scans are the kernel's prologue (wide_binscan); the first chunk of a bin publishes them, one block beyond the worst case of
+// chunks covers the bins without entries.
 __global__ __launch_bounds__(256) void msm_wscatter2_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
                                                             const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
-                                                            const uint32_t* __restrict__ bstart_all, uint32_t* __restrict__ cursor_all,
-                                                            uint32_t* __restrict__ entries_all, size_t ent_stride,
-                                                            const uint8_t* __restrict__ delta_all) {
+                                                            const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
+                                                            uint32_t* __restrict__ cursor_all, uint32_t* __restrict__ entries_all,
+                                                            size_t ent_stride, uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
+                                                            uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket_all,
+                                                            uint32_t part_stride, uint32_t WCAP) {
     __shared__ SortLds S;
+    __shared__ WideBinScan B;
     __shared__ uint32_t s_bin, s_chunk;
     __shared__ uint32_t s_mark[128];  // flag bits of a key's first entry when this chunk holds the bucket's first
+    __shared__ uint32_t s_start[128], s_delta[128];
+    constexpr uint32_t CB = WCB + 1;
     const uint32_t col = blockIdx.y, nb = g.nb, keys = 1u << g.fb;
     const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
     const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    const uint32_t* __restrict__ bstart = bstart_all + (size_t)col * nb;
     uint32_t* __restrict__ cursor = cursor_all + (size_t)col * nb;
     uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
-    const uint32_t* cpre = chdr + (WCB + 1);
+    const uint32_t* cpre = chdr + CB;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the spare block: bins without entries have no chunk, but their buckets' starts are read all the same (an empty bucket
+        // shares its start with the next non-empty one: wide_bucket_at) and their part ranges must be empty
+        for (uint32_t bin = 0; bin < g.bins; bin++) {
+            if (chdr[bin + 1] != chdr[bin]) continue;
+            if (threadIdx.x < keys) {
+                bstart_all[(size_t)col * nb + bin * keys + threadIdx.x] = chdr[bin];
+                pstart_all[(size_t)col * nb + bin * keys + threadIdx.x] = chdr[4 * CB + bin];
+            }
+        }
+        return;
+    }
     if (blockIdx.x >= cpre[g.bins]) return;  // the grid is sized for the worst case
     if (threadIdx.x == 0) {
         uint32_t lo = 0, hi = g.bins;  // the bin whose chunk range holds blockIdx.x
@@ -1373,6 +1394,15 @@ __global__ __launch_bounds__(256) void msm_wscatter2_kernel(const uint32_t* __re
     if (threadIdx.x < keys) S.cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t bin = s_bin;
+    {
+        uint32_t dl;
+        const uint32_t st = wide_binscan(B, chdr, g, col, bin, totals_all, s_chunk == 0, bstart_all, lane_b_all + (size_t)col * lane_stride,
+                                         pstart_all, pbucket_all + (size_t)col * part_stride, WCAP, &dl);
+        if (threadIdx.x < keys) {
+            s_start[threadIdx.x] = st;
+            s_delta[threadIdx.x] = dl;
+        }
+    }
     const uint32_t beg = chdr[bin] + s_chunk * SUB;
     const uint32_t end = min(chdr[bin + 1], beg + SUB);
     constexpr uint32_t PER = SUB / 256;
@@ -1393,8 +1423,8 @@ __global__ __launch_bounds__(256) void msm_wscatter2_kernel(const uint32_t* __re
     if (threadIdx.x < keys) {
         const uint32_t cnt = S.cnt[threadIdx.x], b = bin * keys + threadIdx.x;
         const uint32_t before = cnt ? atomicAdd(&cursor[b], cnt) : 0;
-        S.gbase[threadIdx.x] = bstart[b] + before;
-        s_mark[threadIdx.x] = (cnt && before == 0) ? (WIDE_FLAG | ((uint32_t)delta_all[(size_t)col * nb + b] << g.ib)) : 0;
+        S.gbase[threadIdx.x] = s_start[threadIdx.x] + before;
+        s_mark[threadIdx.x] = (cnt && before == 0) ? (WIDE_FLAG | (s_delta[threadIdx.x] << g.ib)) : 0;
     }
     __syncthreads();
 #pragma unroll
@@ -1840,7 +1870,6 @@ MsmWorkspace* msm_workspace_create(size_t max_n, uint32_t c, hipError_t* err, ui
         MSM_TRY(hipMalloc(&ws->w_tot[1], (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_cur[1], (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_lane_b, (size_t)max_batch * ws->w_lane_stride * 4));
-        MSM_TRY(hipMalloc(&ws->w_delta, (size_t)max_batch * ws->nb));
         MSM_TRY(hipMalloc(&ws->w_bstart, (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_pstart, (size_t)max_batch * ws->nb * 4));
         MSM_TRY(hipMalloc(&ws->w_pbucket, (size_t)max_batch * ws->w_part_stride * 4));
@@ -1871,7 +1900,6 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
         hipFree(ws->w_cur[1]);
     }
     hipFree(ws->w_lane_b);
-    hipFree(ws->w_delta);
     hipFree(ws->w_bstart);
     hipFree(ws->w_pstart);
     hipFree(ws->w_pbucket);
@@ -1936,28 +1964,24 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         for (uint32_t q = 0; q < batch; q++) mb.s[q] = scalars_list[q];
         const dim3 gh(nblk, batch);
         if (c == 17) {
-            hipLaunchKernelGGL(msm_whist_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, next_totals,
-                               next_cursor, ws->w_used_cols[ws->w_par ^ 1], ws->counts);
+            hipLaunchKernelGGL(msm_whist_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, ws->counts);
             hipLaunchKernelGGL(msm_wscatter1_kernel<17>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
                                ws->inter, ws->inter_stride, ws->counts, WCAP);
         } else if (c == 16) {
-            hipLaunchKernelGGL(msm_whist_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, next_totals,
-                               next_cursor, ws->w_used_cols[ws->w_par ^ 1], ws->counts);
+            hipLaunchKernelGGL(msm_whist_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, ws->counts);
             hipLaunchKernelGGL(msm_wscatter1_kernel<16>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
                                ws->inter, ws->inter_stride, ws->counts, WCAP);
         } else {
-            hipLaunchKernelGGL(msm_whist_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, next_totals,
-                               next_cursor, ws->w_used_cols[ws->w_par ^ 1], ws->counts);
+            hipLaunchKernelGGL(msm_whist_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, ws->coarse, ws->coarse_stride, ws->counts);
             hipLaunchKernelGGL(msm_wscatter1_kernel<15>, gh, dim3(256), 0, st, mb, n32, g, table_stride, ws->coarse, ws->coarse_stride,
                                ws->inter, ws->inter_stride, ws->counts, WCAP);
         }
         const uint32_t max_chunks = (uint32_t)(((uint64_t)n32 * nwin + SUB - 1) / SUB) + g.bins;
         hipLaunchKernelGGL(msm_wfinehist_kernel, dim3(max_chunks + 1, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, g, totals);
-        hipLaunchKernelGGL(msm_wbinscan_kernel, dim3(g.bins, batch), dim3(1u << g.fb), 0, st, ws->coarse, ws->coarse_stride, g, totals,
-                           ws->w_bstart, ws->w_delta, ws->w_lane_b, ws->w_lane_stride, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, WCAP);
-        hipLaunchKernelGGL(msm_wscatter2_kernel, dim3(max_chunks, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
-                           ws->coarse_stride, g, ws->w_bstart, cursor, ws->entries, ws->w_ent_stride, (const uint8_t*)ws->w_delta);
+                           ws->coarse_stride, g, totals, next_totals, next_cursor, ws->w_used_cols[ws->w_par ^ 1]);
+        hipLaunchKernelGGL(msm_wscatter2_kernel, dim3(max_chunks + 1, batch), dim3(256), 0, st, ws->inter, ws->inter_stride, ws->coarse,
+                           ws->coarse_stride, g, totals, ws->w_bstart, cursor, ws->entries, ws->w_ent_stride, ws->w_lane_b, ws->w_lane_stride,
+                           ws->w_pstart, ws->w_pbucket, ws->w_part_stride, WCAP);
         if (accum_events) hipEventRecord(accum_events[0], st);
         if (bases_may_be_identity) {
             hipLaunchKernelGGL(msm_wacc_kernel, dim3((lanes + 63) / 64, batch), dim3(64), 0, st, ws->entries, ws->w_ent_stride, table, ws->counts,
