@@ -47,6 +47,12 @@ extern "C" {
 #define ZK_EWITNESS (-6) /* witness violates the circuit (lookup input not in table): halo2's
                             Error::ConstraintSystemFailure */
 #define ZK_EINTERNAL (-7) /* a C++ exception was stopped at the boundary (nothing is ever thrown across it) */
+#define ZK_ELAYOUT (-8)  /* zk_keygen / zk_pk_read: the selector columns do not fit the layout the key is built for — halo2's
+                            compress_selectors would combine them differently (two used gate selectors that share no row, a used
+                            selector that is never enabled, an "idle" one that is; or 2 * num_idle_gate_columns > num_advice:
+                            the surplus never-enabled selectors would pair up in all-zero columns of their own): another vk
+                            digest and other gates than the engine's closed form, so the key is refused rather than made to
+                            prove something else */
 
 typedef struct zk_ctx zk_ctx;
 typedef uint64_t zk_poly; /* opaque device-resident vector of Fr; 0 is never valid */
@@ -71,8 +77,20 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
 #define ZK_OPT_MSM_BATCH 2           /* columns per fixed-base MSM pass, 1..256 */
 #define ZK_OPT_NTT_MAX_RADIX_LOG2 3  /* largest radix of one NTT pass, 1..11 (clamped to the tile) */
 #define ZK_OPT_GP_BATCH_INVERT 4     /* 1: grand products always take halo2's batch_invert form (the fallback path) */
-#define ZK_OPT_MSM_TAIL_STREAM 5     /* where the MSM reduction tails run: 0 auto (the context's side stream while at most two proofs
-                                        are in flight on the device, its main stream beyond), 1 side stream, 2 main stream */
+#define ZK_OPT_MSM_TAIL_STREAM 5     /* where the MSM reduction tails run: 0 auto, 1 the context's side stream, 2 its main stream.
+                                        Auto: the side stream while at most ZK_OPT_MSM_TAIL_MAIN_ABOVE contexts are ACTIVE on the
+                                        device, the main stream beyond.  A context is active if it enqueued an MSM pass within the
+                                        last 4 ms through ANY entry point (zk_prove, zk_commit, zk_commit_batch, zk_msm_srs,
+                                        zk_msm_bn254, keygen): four host threads on the phase-level ABI are seen like four
+                                        zk_prove calls.  The count is PROCESS-LOCAL — other processes on the same GPU are not seen:
+                                        a host that runs several worker processes per device pins the regime with 1 / 2.
+                                        Why it matters: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware
+                                        queues (4 unless that environment variable of the HIP runtime says otherwise) and streams
+                                        that share a queue run in order — with more than four streams busy some pipeline's kernels
+                                        wait behind another's accumulation (DESIGN.md "Streams and hardware queues"; measured: 4
+                                        pipelines 103.7 proofs/s on one stream each against 99.1 with a side stream each) */
+#define ZK_OPT_MSM_TAIL_MAIN_ABOVE 6 /* the auto threshold above, 1..64; 0 restores the measured default (2, for the runtime's default
+                                        of four hardware queues: two contexts x two streams fill them) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------
@@ -251,6 +269,7 @@ int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canoni
 #define ZK_T_MSM_ACCUM 4 /* the bucket-accumulation kernel of the last MSM alone */
 #define ZK_T_MSM_COLUMNS 5 /* count only: scalar vectors (commitments) the accumulate launches served — a launch
                               serves several columns when commitments are batched */
+#define ZK_T_MSM_TAIL_MAIN 6 /* count only: MSM passes whose reduction tail ran on the context's main stream (ZK_OPT_MSM_TAIL_STREAM) */
 #define ZK_T_COUNT 8
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
 /* accumulated HIP-event time and launch count since the last reset (ZK_T_MSM, ZK_T_MSM_ACCUM) */

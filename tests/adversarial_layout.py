@@ -18,7 +18,9 @@ import random
 from zkoracle.field import R
 
 
-def build(shape, seed):
+def build(shape, seed, disjoint_selectors=False):
+    """disjoint_selectors: leave the gate selectors as drawn — the almost-unused column's five rows then usually miss some
+    other column's rows, a layout halo2 would compress differently (the refusal test)."""
     rng = random.Random(seed)
     n, usable, F, A = shape.n, shape.usable_rows, shape.num_fixed, shape.n_gate
     T = 1 << shape.lookup_bits
@@ -37,6 +39,7 @@ def build(shape, seed):
     blk0 = rng.randrange(8, usable - blk_len - 8)
     block = range(blk0, blk0 + blk_len)
 
+    common_row = 2
     # ---- selectors: irregular rows, overlapping gates; no gate OUTPUT inside the lookup block of a looked-up gate column
     sel_rows = []
     for j in range(A):
@@ -59,6 +62,10 @@ def build(shape, seed):
                     r += rng.randrange(1, 7)
         if shape.single:
             rows = {r for r in rows if r + 3 not in block}
+        elif not disjoint_selectors:
+            # every pair of gate selectors shares a row: halo2's compress_selectors then leaves each its own fixed column (the
+            # layout zk_keygen builds keys for; selectors that never meet would be COMBINED into one column — ZK_ELAYOUT)
+            rows.add(common_row)
         sel_rows.append(sorted(rows))
         col = fixed[shape.fx_sel[j]]
         for r in rows:

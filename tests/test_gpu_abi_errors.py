@@ -1,5 +1,6 @@
 """Error behaviour at the C-ABI (include/zkmi355.h): negative codes, outputs untouched, no crash."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -219,4 +220,49 @@ def test_keygen_validates_its_inputs():
         eng.set_option(99, 1)
     with pytest.raises(zk.ZkError):
         eng.set_option(E.ZK_OPT_MSM_WINDOW, 40)
+    eng.close()
+
+
+def test_keygen_refuses_selector_layouts_halo2_would_compress_differently():
+    """ADVICE r4: the key's gates and vk digest use the CLOSED FORM of halo2's compress_selectors (csrc/pk.h Layout::gate_sel) —
+    valid only while every pair of used gate selectors shares a row.  Two used selectors that never meet would be combined
+    into one fixed column by halo2: zk_keygen must refuse (ZK_ELAYOUT = -8), not build a key that proves something else.  Same
+    for a used selector that is never enabled, a column that is no 0/1 selector, and 2 * idle > num_advice."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import adversarial_layout as adv
+    from zkoracle import plonk
+
+    eng = zk.Engine(0)
+    k, A, L, F, lb = 8, 3, 2, 2, 5
+    eng.srs_setup(k)
+    sh = plonk.Shape(k, A, L, F, lb)
+    params = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+
+    def limbs(cols):
+        return np.stack([zk.circuit.Assignment.to_limbs(c) for c in cols])
+
+    fixed, copies, _ = adv.build(sh, 1234, disjoint_selectors=True)  # the 5-row selector misses another column's rows
+    sels = [set(r for r, v in enumerate(fixed[F + 1 + j]) if v) for j in range(A)]
+    assert any(not (sels[a] & sels[b]) for a in range(A) for b in range(a + 1, A))
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(params, limbs(fixed), copies)
+    assert e.value.code == -8
+    good, copies2, _ = adv.build(sh, 1234)  # the same generator with a shared row: accepted
+    pk = eng.keygen(params, limbs(good), copies2)
+    eng.pk_free(pk)
+    never = [list(c) for c in good]
+    never[F + 1 + 1] = [0] * (1 << k)  # a selector declared used that is never enabled
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(params, limbs(never), copies2)
+    assert e.value.code == -8
+    two = [list(c) for c in good]
+    two[F + 1][2] = 2  # not a 0/1 column
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(params, limbs(two), copies2)
+    assert e.value.code == -1
+    many_idle = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb, idle_gate_columns=2)
+    with pytest.raises(zk.ZkError) as e:
+        eng.keygen(many_idle, limbs(good[:F + 1 + 1]), copies2)  # 2 * 2 > 3
+    assert e.value.code == -8
     eng.close()

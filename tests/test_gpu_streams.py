@@ -1,0 +1,86 @@
+"""Where the MSM reduction tails run (ZK_OPT_MSM_TAIL_STREAM auto mode) must depend on how busy the DEVICE is, not on which
+entry point the host uses: round 4 counted zk_prove calls only, so four threads on the phase-level ABI
+(the Rust shim of INTEGRATION.md) stayed in the slow regime."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import webauthn_halo2_amd as zk
+from webauthn_halo2_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _column(n, seed):
+    a = np.frombuffer(np.random.default_rng(seed).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return a
+
+
+def test_tail_placement_follows_device_activity_whatever_the_entry_point():
+    k = 14
+    n = 1 << k
+    engs = [zk.Engine(0)]
+    engs[0].srs_setup(k)
+    for _ in range(3):
+        engs.append(zk.Engine(0, share_with=engs[0]))
+    polys = [e.poly(n, _column(n, 7 + i)) for i, e in enumerate(engs)]
+    want = [e.commit(p, E.ZK_BASIS_LAGRANGE).copy() for e, p in zip(engs, polys)]
+    time.sleep(0.02)  # the set-up commits above fall out of the activity window
+    # (a) one context alone: every tail on its side stream
+    engs[0].timer_reset()
+    for _ in range(20):
+        engs[0].commit(polys[0], E.ZK_BASIS_LAGRANGE)
+    assert engs[0].timer_stats(E.ZK_T_MSM_TAIL_MAIN)[1] == 0
+    assert engs[0].timer_stats(E.ZK_T_MSM)[1] == 20
+    # (b) four host threads, each on zk_commit of its own context: the device is as busy as under four zk_prove calls
+    time.sleep(0.02)
+    for e in engs:
+        e.timer_reset()
+    reps = 300
+    errs = []
+    go = threading.Barrier(4)
+
+    def work(i):
+        try:
+            go.wait()
+            for _ in range(reps):
+                got = engs[i].commit(polys[i], E.ZK_BASIS_LAGRANGE)
+            assert np.array_equal(got, want[i])
+        except Exception as ex:  # surfaced below
+            errs.append(ex)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    main = sum(e.timer_stats(E.ZK_T_MSM_TAIL_MAIN)[1] for e in engs)
+    total = sum(e.timer_stats(E.ZK_T_MSM)[1] for e in engs)
+    assert total == 4 * reps
+    assert main >= 0.8 * total, (main, total)  # the start and the end of the run see fewer than three active contexts
+    # (c) the threshold is an option: above 8 active contexts never happens here -> side stream again
+    time.sleep(0.02)
+    for e in engs:
+        e.set_option(E.ZK_OPT_MSM_TAIL_MAIN_ABOVE, 8)
+        e.timer_reset()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    go.reset()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert sum(e.timer_stats(E.ZK_T_MSM_TAIL_MAIN)[1] for e in engs) == 0
+    # (d) pinned: main stream for a lone caller
+    engs[0].set_option(E.ZK_OPT_MSM_TAIL_STREAM, 2)
+    engs[0].timer_reset()
+    assert np.array_equal(engs[0].commit(polys[0], E.ZK_BASIS_LAGRANGE), want[0])
+    assert engs[0].timer_stats(E.ZK_T_MSM_TAIL_MAIN)[1] == 1
+    for p in polys:
+        p.free()
+    for e in engs[::-1]:
+        e.close()

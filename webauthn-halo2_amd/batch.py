@@ -70,6 +70,17 @@ def structure(params):
     return np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies
 
 
+def _quietly(fn, *args):
+    """Run a clean-up step; a failure is reported on stderr and returned, never raised (the caller is already unwinding)."""
+    try:
+        fn(*args)
+        return None
+    except Exception as e:  # noqa: BLE001 — whatever the engine raises
+        import sys
+        print("webauthn-halo2_amd.batch: clean-up step %s failed: %s" % (getattr(fn, "__name__", fn), e), file=sys.stderr)
+        return e
+
+
 class Pipeline:
     """One proof in flight: a zk_ctx on `device` with the SRS of params.degree and the proving key resident."""
 
@@ -134,18 +145,25 @@ class Pipeline:
                 staged.append(ld.poly_detach(h))
                 h = None
         except Exception:
-            # a later column failed: nobody will ever attach the ones already detached — give their memory back
+            # a later column failed: nobody will ever attach the ones already detached — give their memory back.  The clean-up
+            # itself may fail (after a device fault every call does): that must neither replace the original error nor stop
+            # the remaining tokens from being discarded
             if h is not None and h.h:
-                h.free()
+                _quietly(h.free)
             for d in staged:
-                ld.poly_discard(d)
+                _quietly(ld.poly_discard, d)
             raise
         return staged
 
     def discard(self, staged):
-        """Drop staged columns that will not be adopted (the request was cancelled, the pipeline is closing)."""
+        """Drop staged columns that will not be adopted (the request was cancelled, the pipeline is closing).  Every token is
+        tried; the first failure is raised once all have been."""
+        first = None
         for d in staged:
-            self.loader().poly_discard(d)
+            err = _quietly(self.loader().poly_discard, d)
+            first = first or err
+        if first is not None:
+            raise first
 
     def adopt(self, job, staged):
         """Make staged columns this pipeline's resident advice of `job` (no copy)."""

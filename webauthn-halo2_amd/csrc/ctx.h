@@ -61,9 +61,12 @@ struct zk_ctx {
     // tuning options (zk_ctx_set_option); 0 = built-in choice
     uint32_t opt_msm_window = 0, opt_msm_batch = 0, opt_ntt_max_r = 0, opt_gp_batch_invert = 0;
     uint32_t opt_tail_stream = 0;  // ZK_OPT_MSM_TAIL_STREAM: 0 auto, 1 always the context's tail stream, 2 always the main stream
+    uint32_t opt_tail_main_above = 0;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE: auto mode puts the tails on the main stream with MORE than this many contexts active on the device (0 = the measured default, 2)
+    int act_slot = -1;             // this context's slot in its device's activity table (engine.hip ctx_activity_*)
     // The context's TAIL stream (round 4: one, shared by the lanes; rounds 2-3 had one per lane).  Where a pass's reduction tail
-    // runs is decided per pass (ctx_msm_begin_batch): on this stream while at most two proofs are in flight on the device — a
-    // lone proof hides its tails behind its next head —, on the main stream beyond that: HIP maps streams onto FOUR hardware
+    // runs is decided per pass (ctx_msm_begin_batch): on this stream while at most two contexts are ACTIVE on the device (have
+    // enqueued an MSM pass within the last 4 ms, through whatever entry point: ctx_activity_touch) — a lone proof hides its
+    // tails behind its next head —, on the main stream beyond that: HIP maps a process's streams onto FOUR hardware
     // queues, and streams that share a queue run in order, so with three or more pipelines every extra stream puts some
     // pipeline's kernels behind another's accumulation (measured, tools/queue_ab2.sh: 4 pipelines 103.7 proofs/s with one
     // stream each, 99.1 with a tail stream each even on 8 queues, 94.4 for round 3's 2 pipelines x 4 streams)
@@ -141,10 +144,11 @@ struct zk_ctx {
 
 
 int ctx_bind(zk_ctx* c);
-// proofs in flight on a device (all contexts of the process): decides where the MSM reduction tails run (engine.hip)
-void ctx_proof_enter(int device);
-void ctx_proof_leave(int device);
-int ctx_proofs_in_flight(int device);
+// contexts active on a device (all contexts of THIS process that enqueued an MSM pass within the last few ms): decides where
+// the MSM reduction tails run (engine.hip)
+void ctx_activity_register(zk_ctx* c);
+void ctx_activity_unregister(zk_ctx* c);
+int ctx_activity_touch(zk_ctx* c);
 void ctx_release_spares(zk_ctx* c);  // frees the vectors zk_poly_free parked (caller holds c->mu, device bound)
 int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <new>
 
 #include "ctx.h"
@@ -191,16 +192,54 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     return ZK_OK;
 }
 
+// ---- how busy the device is, as far as this process can see: contexts that enqueued an MSM pass within the last few
+// milliseconds.  Every context owns a slot of its device's table and stamps it in ctx_msm_begin_batch — the one place every
+// MSM pass goes through, whoever asked for it (zk_prove, zk_commit / zk_commit_batch, zk_msm_srs, zk_msm_bn254, zk_keygen,
+// zk_pk_read): a host that drives the phase-level ABI from four threads is seen exactly like four zk_prove calls (round 4
+// counted zk_prove calls only).  PROCESS-LOCAL: contexts of other processes on the same GPU are invisible.
 namespace {
-std::atomic<int> g_proofs_in_flight[64];
+constexpr int ACT_DEVICES = 64, ACT_SLOTS = 64;
+constexpr int64_t ACT_WINDOW_NS = 4 * 1000 * 1000;  // a proving context enqueues a pass every 0.3 .. 1.5 ms
+std::atomic<int64_t> g_act_ts[ACT_DEVICES][ACT_SLOTS];
+std::atomic<uint64_t> g_act_used[ACT_DEVICES];
+int64_t act_now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+void ctx_activity_register(zk_ctx* c) {
+    c->act_slot = -1;
+    if (c->device < 0 || c->device >= ACT_DEVICES) return;
+    std::atomic<uint64_t>& used = g_act_used[c->device];
+    uint64_t cur = used.load();
+    for (;;) {
+        if (~cur == 0) return;  // more than 64 contexts on one device: the surplus ones are not counted
+        const int slot = __builtin_ctzll(~cur);
+        if (used.compare_exchange_weak(cur, cur | (1ull << slot))) {
+            g_act_ts[c->device][slot].store(0);
+            c->act_slot = slot;
+            return;
+        }
+    }
 }
-void ctx_proof_enter(int device) {
-    if (device >= 0 && device < 64) g_proofs_in_flight[device].fetch_add(1);
+void ctx_activity_unregister(zk_ctx* c) {
+    if (c->act_slot < 0 || c->device < 0 || c->device >= ACT_DEVICES) return;
+    g_act_ts[c->device][c->act_slot].store(0);
+    g_act_used[c->device].fetch_and(~(1ull << c->act_slot));
+    c->act_slot = -1;
 }
-void ctx_proof_leave(int device) {
-    if (device >= 0 && device < 64) g_proofs_in_flight[device].fetch_sub(1);
+// stamps this context and returns the number of contexts (this one included) active on its device
+int ctx_activity_touch(zk_ctx* c) {
+    if (c->device < 0 || c->device >= ACT_DEVICES) return 1;
+    const int64_t now = act_now();
+    if (c->act_slot >= 0) g_act_ts[c->device][c->act_slot].store(now);
+    int active = c->act_slot >= 0 ? 0 : 1;
+    uint64_t used = g_act_used[c->device].load();
+    while (used) {
+        const int slot = __builtin_ctzll(used);
+        used &= used - 1;
+        const int64_t ts = g_act_ts[c->device][slot].load();
+        if (ts && now - ts < ACT_WINDOW_NS) active++;
+    }
+    return active;
 }
-int ctx_proofs_in_flight(int device) { return device >= 0 && device < 64 ? g_proofs_in_flight[device].load() : 0; }
 
 int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_t batch, const G1Affine* d_bases, size_t n) {
     if (lane < 0 || lane >= zk_ctx::MSM_LANES || c->lanes[lane].busy || batch == 0) return ZK_EINVAL;
@@ -224,7 +263,10 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     if (rc) return rc;
     if (batch > 1 && (!table || batch > msm_ws_max_batch(ws))) return ZK_EINVAL;
     // where this pass's reduction tail runs (ctx.h tail_stream): the side stream for up to two proofs in flight on the device
-    L.tail = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && ctx_proofs_in_flight(c->device) > 2) ? c->stream : c->tail_stream;
+    const int active = ctx_activity_touch(c);
+    const uint32_t above = c->opt_tail_main_above ? c->opt_tail_main_above : 2u;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE; measured default (ctx.h)
+    L.tail = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && (uint32_t)active > above) ? c->stream : c->tail_stream;
+    if (L.tail == c->stream) c->acc_n[ZK_T_MSM_TAIL_MAIN]++;
     HIPCHK(c, hipEventRecord(L.t_head[0], c->stream));
     HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
                       L.head_done, !table || ident));
@@ -314,6 +356,7 @@ const char* zk_strerror(int code) {
         case ZK_ESTATE: return "missing prerequisite (SRS / key not loaded)";
         case ZK_EWITNESS: return "witness does not satisfy the circuit (lookup input outside the table)";
         case ZK_EINTERNAL: return "internal error (C++ exception stopped at the ABI boundary)";
+        case ZK_ELAYOUT: return "selector columns outside the layout of compress_selectors the key is built for";
         default: return "unknown error";
     }
 }
@@ -355,6 +398,7 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
     }
     c->zeta = fr_zeta();
     c->zeta2 = fe_sqr(c->zeta);
+    ctx_activity_register(c);
     *out = c;
     return ZK_OK;
 }
@@ -386,6 +430,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
         c->opt_ntt_max_r = parent->opt_ntt_max_r;
         c->opt_gp_batch_invert = parent->opt_gp_batch_invert;
         c->opt_tail_stream = parent->opt_tail_stream;
+        c->opt_tail_main_above = parent->opt_tail_main_above;
         c->srs_gen++;
     }
     *out = c;
@@ -394,6 +439,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
 
 void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
+    ctx_activity_unregister(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
@@ -488,6 +534,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_MSM_TAIL_STREAM:
             if (value > 2) return ZK_EINVAL;
             c->opt_tail_stream = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_MSM_TAIL_MAIN_ABOVE:
+            if (value > 64) return ZK_EINVAL;
+            c->opt_tail_main_above = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_MSM_BATCH:
             if (value > MSM_MAX_BATCH) return ZK_EINVAL;

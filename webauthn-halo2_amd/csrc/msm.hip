@@ -104,6 +104,9 @@ struct MsmWorkspace {
     G1X* bit_sum;               // [nwin * c]
     // wide path (15 / 16-bit windows, fixed-base mode): per-column regions
     bool wide;
+    bool w_redo_valid;          // the last pass on this workspace ran the wide path's unchecked accumulation over n > 0 scalars: the word
+                                // behind its sums in the host buffer is that pass's redo count (msm_wide_redo_count); any other pass —
+                                // the standard plan on a wide workspace, an empty one — leaves no such word
     bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
     // per-bucket totals and level-2 cursors exist twice: pass i counts in set i & 1 while its first kernel — 131 K lanes with
     // to spare (the fine histogram: two thousand workgroups) — zeroes the other set for pass i + 1 (in the 16 waves of the last
@@ -2014,6 +2017,7 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, out_dev, ws->counts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     ws->w_clean = true;
+    ws->w_redo_valid = n > 0 && !bases_may_be_identity;  // (the checked loop lists nothing; an empty pass never reset counts[1])
     if (n > 0) {  // (an empty pass neither counts nor zeroes anything)
         ws->w_used_cols[ws->w_par] = batch;
         ws->w_used_cols[ws->w_par ^ 1] = 0;
@@ -2026,7 +2030,7 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
 // with the pass's sums (msm_wbits_kernel).  Non-zero — a degenerate basis only — and the host calls this: the listed lanes again
 // with the checked loop, then the tail again, on `st`; the pass's workspace is intact until the lane's next pass.
 uint32_t msm_wide_redo_count(const MsmWorkspace* ws, const G1X* host_window_sums, uint32_t batch) {
-    if (!ws->wide) return 0;
+    if (!ws->wide || !ws->w_redo_valid) return 0;
     uint32_t v;
     memcpy(&v, host_window_sums + (size_t)batch * WIDE_SUMS, 4);
     return v;
@@ -2066,6 +2070,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     if (n > ws->max_n || batch == 0 || batch > ws->max_batch) return hipErrorInvalidValue;
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const bool fixed = table != nullptr;
+    ws->w_redo_valid = false;
     if (fixed && ws->wide && table_stride == ws->max_n)
         return msm_run_wide(ws, scalars_list, batch, n, st, host_window_sums, nwin_out, c_out, accum_events, table, table_stride, tail_st,
                             head_done, bases_may_be_identity);

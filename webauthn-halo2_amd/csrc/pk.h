@@ -75,6 +75,31 @@ struct Layout {
     }
 };
 
+// Whether the closed form above (Layout::gate_sel) is what halo2's compress_selectors would build from these selector
+// activations (bits[j]: selector j's 2^k rows, LSB-first, the VerifyingKey::write packing; j < n_gate).  The greedy pass
+// combines simple selectors that are never enabled on a common row, so the closed form — one column per USED selector,
+// never-enabled selector t in the column of gate t — holds iff (a) every selector declared used is enabled somewhere and
+// every pair of used selectors shares a row (no two of them are combined with each other), and (b) the selectors declared
+// idle are all-zero.  Anything else would make halo2 pair columns differently: another vk digest, other gates — refused
+// with ZK_ELAYOUT instead of proofs that silently diverge.  (2 * idle <= A is Layout::init's own limit: more never-enabled
+// selectors than used ones would pair up in all-zero columns of their own.)
+inline bool layout_selectors_fit(const Layout& lay, const std::vector<std::vector<uint8_t>>& bits) {
+    if (lay.single) return true;  // one simple selector; the complex q_lookup is never combined
+    const uint32_t used = lay.A - lay.idle, bytes = lay.n / 8;
+    if (bits.size() < lay.A) return false;
+    for (uint32_t j = used; j < lay.A; j++)
+        for (uint32_t i = 0; i < bytes; i++)
+            if (bits[j][i]) return false;
+    for (uint32_t a = 0; a < used; a++) {
+        for (uint32_t b = a; b < used; b++) {  // b == a: enabled somewhere
+            bool share = false;
+            for (uint32_t i = 0; i < bytes && !share; i++) share = (bits[a][i] & bits[b][i]) != 0;
+            if (!share) return false;
+        }
+    }
+    return true;
+}
+
 static constexpr uint32_t BATCH_ARGS_MIN = 8;  // more chunks / lookups / columns than this: one batched launch, argument blocks in device memory
 static constexpr uint32_t ROWS_CAP = 512, ROWS_BLOCKS = 16;  // staged row writes per flush / flushes per ring
 

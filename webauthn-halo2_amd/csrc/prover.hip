@@ -268,6 +268,7 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
     if (rc) return rc;
     ctx_release_spares(c);  // parked vectors are reclaimable: give them back before the key and its workspace are allocated
     Layout lay;
+    if (params->num_advice > 1 && 2 * (uint64_t)params->num_idle_gate_columns > params->num_advice) return ZK_ELAYOUT;  // zkmi355.h: more never-enabled selectors than used ones
     if (!lay.init(*params)) return ZK_EINVAL;
     if (n_fixed_columns != lay.n_fix) return ZK_EINVAL;  // fixed_canonical holds n_fixed_columns x n x 4 limbs
     if (c->srs_k != (int)lay.k) return ZK_ESTATE;
@@ -279,6 +280,20 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
             const uint64_t want = r < T ? r : 0;
             if (tab[4 * r] != want || tab[4 * r + 1] || tab[4 * r + 2] || tab[4 * r + 3]) return ZK_EINVAL;
         }
+    }
+    // the gate selectors must be what the key's closed-form layout assumes of them (pk.h layout_selectors_fit): 0 / 1 columns
+    // that halo2's compress_selectors would leave one fixed column each
+    if (!lay.single) {
+        std::vector<std::vector<uint8_t>> bits(lay.A, std::vector<uint8_t>(n / 8, 0));
+        for (uint32_t j = 0; j < lay.A; j++) {
+            if (lay.fx_sel[j] == NO_SELECTOR) continue;
+            const uint64_t* col = fixed_canonical + (size_t)lay.fx_sel[j] * n * 4;
+            for (uint32_t r = 0; r < n; r++) {
+                if (col[4 * r] > 1 || col[4 * r + 1] || col[4 * r + 2] || col[4 * r + 3]) return ZK_EINVAL;  // not a selector column
+                if (col[4 * r]) bits[j][r >> 3] |= (uint8_t)(1u << (r & 7));
+            }
+        }
+        if (!layout_selectors_fit(lay, bits)) return ZK_ELAYOUT;
     }
     const uint32_t m = (uint32_t)lay.perm_cols.size();
     for (size_t i = 0; i < n_copies; i++) {
@@ -1493,15 +1508,7 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     Blake2bTranscript b2;
     Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
     Prover p(c, pk, rng_seed, tr);
-    {
-        // the proofs in flight on the device decide where the MSM tails run (engine.hip); counted down on every way out
-        struct InFlight {
-            int d;
-            explicit InFlight(int dev) : d(dev) { ctx_proof_enter(d); }
-            ~InFlight() { ctx_proof_leave(d); }
-        } in_flight(c->device);
-        rc = p.run(adv.data(), scheme);
-    }
+    rc = p.run(adv.data(), scheme);
     ctx_msm_drain(c);  // an early error may leave commitments in flight
     hipStreamSynchronize(c->stream);
     if (rc) return rc;

@@ -744,6 +744,7 @@ ZK_API(zk_pk_read, (zk_ctx* c, const zk_circuit_params* params, const uint8_t* b
         if (rc) return rc;
         ctx_release_spares(c);
         Layout lay;
+        if (params->num_advice > 1 && 2 * (uint64_t)params->num_idle_gate_columns > params->num_advice) return ZK_ELAYOUT;
         if (!lay.init(*params)) return ZK_EINVAL;
         if (c->srs_k != (int)lay.k) return ZK_ESTATE;
         if (len != pk_size(lay, format)) return ZK_EINVAL;
@@ -814,6 +815,7 @@ ZK_API(zk_pk_read, (zk_ctx* c, const zk_circuit_params* params, const uint8_t* b
             std::vector<std::vector<uint8_t>> bits;
             if ((rc = selector_bits(c, pk, &bits))) return fail(rc == ZK_ESTATE ? ZK_EINVAL : rc);
             if (bits != vk.selectors) return fail(ZK_EINVAL);
+            if (!layout_selectors_fit(lay, bits)) return fail(ZK_ELAYOUT);  // halo2 would have compressed these selectors differently
         }
         hipFree(d_err);
         d_err = nullptr;

@@ -39,6 +39,7 @@ from .engine import ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM, Engine
 #              "extra": [{"eng": Engine sharing the first one's SRS, "keys": {path: pk_handle}, "slots": {..}}], "free": Queue of pipeline indices}
 _STATE = {}
 _SLOTS_LOCK = threading.Lock()
+_STATE_LOCK = threading.RLock()  # set-up / tear-down of a device's resident state (gen_srs with a new degree, shutdown)
 # Proof pipelines per device = requests proved CONCURRENTLY on it (the reference: one Rocket worker thread per request,
 # proving-server/src/main.rs:457-472).  Each is a context of its own (own key, own workspace, shared SRS and window tables).
 # Two is the measured optimum for the server's default shape: 144 / 195 / 173 / 183 proofs/s at k = 17 with 1 / 2 / 3 / 4
@@ -62,12 +63,29 @@ def _config_for(degree: int) -> circuit.CircuitParams:
     raise ValueError(f"no circuit config for degree {degree}; set ECDSA_CONFIG")
 
 
+def _drain(st):
+    """Take every pipeline of a device out of its free queue: returns once no request holds one (requests in flight finish
+    first — their `finally` puts the index back into THIS queue object), so contexts can be closed without a use after close."""
+    q = st.get("free")
+    if q is None:
+        return
+    for _ in range(1 + len(st["extra"])):
+        q.get()
+    st["free"] = None
+
+
 def gen_srs(degree: int, device: int = 0) -> Engine:
     """halo2-base `gen_srs(k)`: ParamsKZG::setup(k, ChaCha20Rng::from_seed([0; 32])), kept resident."""
+    with _STATE_LOCK:
+        return _gen_srs_locked(degree, device)
+
+
+def _gen_srs_locked(degree, device):
     st = _STATE.setdefault(device, {"eng": None, "k": None, "keys": {}, "slots": {}, "extra": [], "free": None})
     if st["eng"] is None:
         st["eng"] = Engine(device)
     if st["k"] != degree:
+        _drain(st)  # requests still proving under the old SRS hold a pipeline: wait for them before anything is closed
         for _, pk in st["keys"].values():
             st["eng"].pk_free(pk)
         st["keys"].clear()
@@ -91,14 +109,18 @@ def gen_srs(degree: int, device: int = 0) -> Engine:
 
 def shutdown(device=None):
     """Release the resident state (every pipeline's context, keys and request slots) of `device`, or of all devices."""
-    for d in ([device] if device is not None else list(_STATE)):
-        st = _STATE.pop(d, None)
-        if not st:
-            continue
-        for m in st["extra"][::-1]:
-            m["eng"].close()
-        if st["eng"] is not None:
-            st["eng"].close()
+    with _STATE_LOCK:
+        for d in ([device] if device is not None else list(_STATE)):
+            st = _STATE.get(d)
+            if not st:
+                continue
+            _drain(st)  # (a request that arrives from now on finds no queue: "no resident state")
+            _STATE.pop(d, None)
+            st["k"] = None
+            for m in st["extra"][::-1]:
+                m["eng"].close()
+            if st["eng"] is not None:
+                st["eng"].close()
 
 
 def _pipeline(st, i):
@@ -160,15 +182,27 @@ def create_proof_from_advice(advice_columns, proving_key_path, degree, transcrip
         cols.append(col)
     # a pipeline of the device for this request: concurrent requests prove side by side (PIPELINES_PER_DEVICE), further ones wait
     st = _STATE[device]
-    which = st["free"].get()
+    q = st["free"]  # THIS queue object gets the index back, whatever happens to the device's state meanwhile (_drain waits on it)
+    if q is None or st["k"] != degree:
+        raise RuntimeError("the device's resident state was released or replaced while this request was being set up")
+    while True:
+        try:
+            which = q.get(timeout=0.05)
+            break
+        except queue.Empty:  # every pipeline is busy — or the device's state went away while we waited (its queue is drained for good)
+            if st["free"] is not q:
+                raise RuntimeError("the device's resident state was released or replaced while this request was waiting")
     try:
         eng, pks, slots = _pipeline(st, which)
-        return _prove_on(eng, pks[proving_key_path or "<default>"], slots, cols, n, degree, device, transcript, rng_seed)
+        name = proving_key_path or "<default>"
+        if st["k"] != degree or name not in pks:  # gen_srs(another degree) ran between the key lookup above and here
+            raise FileNotFoundError(f"Unable to open proving key file: {proving_key_path} (the resident key was replaced)")
+        return _prove_on(st, eng, pks[name], slots, cols, n, degree, transcript, rng_seed)
     finally:
-        st["free"].put(which)
+        q.put(which)
 
 
-def _prove_on(eng, pk, slots, cols, n, degree, device, transcript, rng_seed):
+def _prove_on(st, eng, pk, slots, cols, n, degree, transcript, rng_seed):
     # request slots: the columns' device buffers are kept between requests (a hipFree per request would wait for the whole
     # device, i.e. for every other request in flight on it); concurrent requests each take a set of their own
     with _SLOTS_LOCK:
@@ -193,7 +227,7 @@ def _prove_on(eng, pk, slots, cols, n, degree, device, transcript, rng_seed):
             keep = slots.setdefault(len(cols), [])
             # at most _MAX_SLOT_SETS parked sets per column count (a set is GBs at k = 19 with many columns): more
             # concurrent requests than that allocate and free their own
-            if _STATE[device]["k"] == degree and len(keep) < _MAX_SLOT_SETS:
+            if st["k"] == degree and len(keep) < _MAX_SLOT_SETS:  # (`st` as captured at entry: shutdown() may have dropped _STATE[device])
                 keep.append(polys)
             else:  # the SRS was replaced meanwhile (these buffers belong to the old size), or enough sets are parked
                 for h in polys:
