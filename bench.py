@@ -44,7 +44,7 @@ class ProofWorkload:
     """This rank's share of the batch: `inflight` pipelines (own zk_ctx + host thread each) on one GPU, their jobs
     synthesized on the host (process pool) and shipped to HBM before the clock starts."""
 
-    def __init__(self, device, rank, world, inflight, steps, warmup, options=()):
+    def __init__(self, device, rank, world, inflight, steps, warmup, options=(), lockstep=1):
         from webauthn_halo2_amd import batch, circuit, engine as E
 
         def factory(dev):  # tuning experiments only (--opt id=value -> zk_ctx_set_option before the SRS is loaded)
@@ -54,6 +54,7 @@ class ProofWorkload:
             return e
 
         self.batch, self.E = batch, E
+        self.lockstep = max(1, lockstep)
         p = circuit.K19
         # rank r proves jobs r, r + N, ...: `steps` timed jobs, all distinct (warm-up re-proves the first ones)
         self.jobs = [rank + world * j for j in range(max(steps, 1))]
@@ -79,7 +80,10 @@ class ProofWorkload:
 
     def run(self, jobs):
         """Drain `jobs` over the pipelines (job j lives on pipeline index(j) % inflight)."""
-        self.proofs.update(self.batch.run(self.pipes, jobs, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True))
+        if self.lockstep > 1:  # every pipeline proves its share `lockstep` jobs at a time (zk_prove_batch)
+            self.proofs.update(self.batch.run_lockstep(self.pipes, jobs, self.lockstep, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True))
+        else:
+            self.proofs.update(self.batch.run(self.pipes, jobs, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True))
         for e in self.engs:
             e.sync()
 
@@ -97,9 +101,16 @@ class ProofWorkload:
             # measured slower: tools/stage_timing.py, DESIGN.md
             try:
                 pl = self.pipes[q]
-                for j in jobs[q::len(self.pipes)]:
-                    pl.reload(j, self.wit[j])  # into the job's resident buffers: no allocation in the loop
-                    out[j] = pl.prove(j, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
+                mine = jobs[q::len(self.pipes)]
+                for i in range(0, len(mine), self.lockstep):
+                    group = mine[i:i + self.lockstep]
+                    for j in group:
+                        pl.reload(j, self.wit[j])  # into the job's resident buffers: no allocation in the loop
+                    if self.lockstep > 1:
+                        for j, pf in zip(group, pl.prove_lockstep(group, self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True)):
+                            out[j] = pf
+                    else:
+                        out[group[0]] = pl.prove(group[0], self.E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
             except Exception as e:
                 errs.append(e)
 
@@ -266,7 +277,7 @@ def self_launch(args, fake):
             raise SystemExit("bench.py: no gfx950 device (no CPU fallback exists)")
         n = min(n, have)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--inflight", str(args.inflight)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+           "--inflight", str(args.inflight), "--lockstep", str(args.lockstep)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
     if n > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                "--master-port", str(free_port())] + cmd[1:]
@@ -292,6 +303,9 @@ def main():
                          "shared among them.  1 = strictly one proof at a time (single-proof latency).  4 = one pipeline per "
                          "hardware queue of the HIP runtime: with three or more proofs in flight the engine keeps every "
                          "pipeline on ONE stream (round 4: 94 -> 102-104 proofs/s; 5 pipelines share queues again: 96)")
+    ap.add_argument("--lockstep", type=int, default=1,
+                    help="proofs a pipeline advances together (zk_prove_batch: the same commitment of all of them in one MSM pass, "
+                         "the same transform in one NTT launch); 1 = one zk_prove per job")
     ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE",
                     help="tuning experiments: zk_ctx_set_option(ID, VALUE) on every pipeline (include/zkmi355.h ZK_OPT_*)")
     args = ap.parse_args()
@@ -324,7 +338,7 @@ def main():
         # independent proof streams: replicas, no data-path collective.  `inflight` pipelines share one GPU so
         # that the latency-bound phases of one proof (transcript round trips, reduction tails) overlap the
         # throughput-bound kernels of another.
-        wl = ProofWorkload(local_rank, rank, world, nfl, args.steps, args.warmup, options)
+        wl = ProofWorkload(local_rank, rank, world, nfl, args.steps, args.warmup, options, args.lockstep)
 
     def barrier():
         if not fake:
@@ -420,6 +434,7 @@ def main():
             "single_proof_ms": single_ms,
             **launcher,
             "inflight_per_gpu": nfl,
+            "lockstep": args.lockstep,
             "jobs_total": world * args.steps,
             "higher_is_better": True,
             "scaling": "weak",

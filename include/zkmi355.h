@@ -91,6 +91,7 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         pipelines 103.7 proofs/s on one stream each against 99.1 with a side stream each) */
 #define ZK_OPT_MSM_TAIL_MAIN_ABOVE 6 /* the auto threshold above, 1..64; 0 restores the measured default (2, for the runtime's default
                                         of four hardware queues: two contexts x two streams fill them) */
+#define ZK_OPT_BATCH_PASS_COLUMNS 7  /* zk_prove_batch: columns per MSM pass, 1..256; 0 = min(2 x batch, 8) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------
@@ -257,6 +258,19 @@ int zk_proof_size(zk_ctx* ctx, zk_pk pk, int transcript, int scheme, size_t* out
  * would hold after `finalize()`.  proof_out == NULL: only *proof_len is set. */
 int zk_prove(zk_ctx* ctx, zk_pk pk, const zk_poly* advice, size_t n_advice, const uint8_t rng_seed[32],
              int transcript, int scheme, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* `batch` independent create_proof calls for ONE key in lock-step on this context: the reference's concurrent requests
+ * (one Rocket worker thread per request, proving-server/src/main.rs:457-472, each inside create_proof, ecdsa_p256.rs:366-373 /
+ * 416-423) advanced phase by phase together, so that the same commitment of all proofs shares one MSM pass, the same
+ * transform one launch per NTT pass, and every proof's lookups / grand products / openings one set of launches.  Proof j
+ * gets advice[j * n_advice .. (j + 1) * n_advice) and rng_seeds[32 j .. 32 j + 32) and is byte-identical to zk_prove with
+ * the same key, advice and seed; the proofs have one length (*proof_len) and are written proof_stride bytes apart
+ * (proofs_out == NULL: only *proof_len).  The first call with a larger batch allocates the further workspaces (kept with
+ * the key: ~1.4 GiB each at k = 19).  ZK_EWITNESS means SOME proof's witness is off the table: the batch fails as a whole
+ * (zk_prove tells which).  ZK_EINVAL: batch == 0, batch > ZK_PROVE_BATCH_MAX, batch x (#chunks + #lookups) > 256. */
+#define ZK_PROVE_BATCH_MAX 64
+int zk_prove_batch(zk_ctx* ctx, zk_pk pk, size_t batch, const zk_poly* advice /* batch x n_advice, proof-major */, size_t n_advice,
+                   const uint8_t* rng_seeds /* batch x 32 */, int transcript, int scheme, uint8_t* proofs_out, size_t proof_stride,
+                   size_t* proof_len);
 /* upload canonical (non-Montgomery) integers and convert on the device */
 int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canonical, size_t n);
 

@@ -178,6 +178,19 @@ class Pipeline:
             self.unload(job)
         return proof
 
+    def prove_lockstep(self, jobs, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False, rng_seeds=None):
+        """The proofs of `jobs` (all resident on this pipeline) in ONE lock-step batch (zk_prove_batch): the same commitment of
+        every job shares an MSM pass, the same transform an NTT launch.  Returns the proofs in the order of `jobs`; each is
+        byte-identical to prove(job)."""
+        jobs = list(jobs)
+        if rng_seeds is None:
+            rng_seeds = [job_rng_seed(j) if self.deterministic_seeds else os.urandom(32) for j in jobs]
+        proofs = self.eng.prove_batch(self.pk, [self.resident[j] for j in jobs], rng_seeds, transcript)
+        if not keep:
+            for j in jobs:
+                self.unload(j)
+        return proofs
+
     def unload(self, job):
         """The job's buffers go to the pipeline's spare list, not back to the device allocator: hipFree waits for the whole
         device — for the other pipelines' kernels too — so a drain that freed per job would stall everybody per proof."""
@@ -196,6 +209,37 @@ class Pipeline:
         if getattr(self, "_loader", None) is not None:
             self._loader.close()
         self.eng.close()
+
+
+def run_lockstep(pipelines, jobs, lockstep, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False):
+    """Drain `jobs` (pipeline q holds jobs[q::len(pipelines)], as for `run`) in lock-step batches of `lockstep` proofs per
+    pipeline: one host thread per pipeline, each proving its share `lockstep` jobs at a time (the last batch may be
+    shorter).  Returns {job: proof bytes} — the same bytes as `run`."""
+    jobs = list(jobs)
+    out = {}
+    errs = []
+
+    def work(q):
+        try:
+            mine = jobs[q::len(pipelines)]
+            for i in range(0, len(mine), lockstep):
+                group = mine[i:i + lockstep]
+                for j, pf in zip(group, pipelines[q].prove_lockstep(group, transcript, keep)):
+                    out[j] = pf
+        except Exception as e:  # surfaced to the caller below
+            errs.append(e)
+
+    if len(pipelines) == 1:
+        work(0)
+    else:
+        ths = [threading.Thread(target=work, args=(q,)) for q in range(len(pipelines))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    if errs:
+        raise errs[0]
+    return out
 
 
 def run(pipelines, jobs, transcript=ZK_TRANSCRIPT_BLAKE2B, keep=False, on_done=None):

@@ -3,6 +3,7 @@
 // include/zkmi355.h).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <new>
@@ -170,17 +171,21 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     const uint32_t cw = table_window ? table_window : msm_auto_window_generic(want);
     zk_ctx::MsmLane& L = c->lanes[lane];
     MsmWorkspace*& slot = table_window ? L.ws : L.ws_gen;
-    if (slot && (msm_ws_max_n(slot) != want || msm_ws_window(slot) != cw)) {
+    // columns per pass the workspace must take: the single prover's batches, or a lock-step batch's wider passes
+    const uint32_t cols = table_window ? std::max(batch_for(c, want), std::min<uint32_t>(c->msm_min_cols, MSM_MAX_BATCH)) : 1u;
+    if (slot && (msm_ws_max_n(slot) != want || msm_ws_window(slot) != cw || msm_ws_max_batch(slot) < cols)) {
+        hipStreamSynchronize(c->stream);  // (a pass of the lane that has been collected may still have kernels of its tail queued behind others)
+        if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
         msm_workspace_destroy(slot);
         slot = nullptr;
     }
     if (!slot) {
         hipError_t e;
-        slot = msm_workspace_create(want, cw, &e, table_window ? batch_for(c, want) : 1u);
+        slot = msm_workspace_create(want, cw, &e, cols);
         if (!slot && e != hipErrorInvalidValue && !c->poly_spare.empty()) {
             ctx_release_spares(c);
             (void)hipGetLastError();
-            slot = msm_workspace_create(want, cw, &e, table_window ? batch_for(c, want) : 1u);
+            slot = msm_workspace_create(want, cw, &e, cols);
         }
         if (!slot) {
             c->last_hip = (int)e;
@@ -431,6 +436,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
         c->opt_gp_batch_invert = parent->opt_gp_batch_invert;
         c->opt_tail_stream = parent->opt_tail_stream;
         c->opt_tail_main_above = parent->opt_tail_main_above;
+        c->opt_batch_pass_cols = parent->opt_batch_pass_cols;
         c->srs_gen++;
     }
     *out = c;
@@ -538,6 +544,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_MSM_TAIL_MAIN_ABOVE:
             if (value > 64) return ZK_EINVAL;
             c->opt_tail_main_above = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_BATCH_PASS_COLUMNS:
+            if (value > MSM_MAX_BATCH) return ZK_EINVAL;
+            c->opt_batch_pass_cols = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_MSM_BATCH:
             if (value > MSM_MAX_BATCH) return ZK_EINVAL;

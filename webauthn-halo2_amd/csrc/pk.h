@@ -142,6 +142,24 @@ struct zk_pk_rec {
     LcTerm *d_lc_terms = nullptr, *h_lc_terms = nullptr;  // argument lists of the multi-open's long linear combinations
     uint32_t lc_cap = 0, lc_used = 0;                     // slots, and how many this proof has used so far
     Fr *ev_scratch = nullptr, *ev_out = nullptr;
+    // ---- lock-step batches (zk_prove_batch, prover_batch.h): proof j > 0 of a batch works in members[j - 1], a record whose
+    // key half (fixed / sigma / l_* vectors, commitments, transcript_repr) ALIASES this key's and whose workspace is its own
+    // (`dev` of a member lists its workspace only); `bb` holds what the merged launches of a batch need across proofs
+    bool is_member = false;
+    std::vector<zk_pk_rec*> members;
+    struct BatchBufs* bb = nullptr;
+};
+
+// buffers of the launches a lock-step batch shares between its proofs, sized for `cap` proofs
+struct BatchBufs {
+    uint32_t cap = 0;
+    uint32_t* lk_u32 = nullptr;   // lookup scratch of cap x n_lookups lookups (LookupScratch layout)
+    LookupScratch lks{};
+    GpItem* d_gp_items = nullptr; // cap x (chunks + lookups) grand products in one batch
+    Fr* gp_scal = nullptr;        // device: q, q_inv, k, init
+    Fr* gp_host = nullptr;        // pinned: q and q_inv
+    EvalItem *d_evargs = nullptr, *h_evargs = nullptr;  // every opened value of every proof in one launch
+    Fr *ev_scratch = nullptr, *ev_out = nullptr, *tail_host = nullptr;
 };
 
 
@@ -172,6 +190,9 @@ void pk_destroy(zk_pk_rec* pk);
 // the per-proof workspace (advice / z / lookup forms, quotient buffer, scan and evaluation scratch): everything a key
 // needs beyond the key material itself; called at the end of zk_keygen and zk_pk_read
 int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk);
+// makes sure `pk` can prove `batch` proofs in lock-step: batch - 1 member workspaces and the shared buffers (allocated on
+// first use, kept with the key); caller holds the context lock, device bound
+int pk_ensure_batch(zk_ctx* c, zk_pk_rec* pk, uint32_t batch);
 // transcript_repr of a key made or read here: halo2.s own hash of the pinned verifying key (vkrepr.h); a stand-in for the shapes
 // that rendering does not cover; a host-supplied value replaces either
 Fr pk_standin_transcript_repr(const zk_pk_rec* pk);

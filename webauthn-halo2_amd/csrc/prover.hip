@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
@@ -121,6 +123,29 @@ std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& pts) {
     return basis;
 }
 
+// affine forms of `cnt` Jacobian points with ONE field inversion for the whole batch (Montgomery's trick over the z's)
+void jac_batch_to_affine(const G1Jac* js, uint32_t cnt, G1Affine* af) {
+    Fq pre[MSM_MAX_BATCH];
+    Fq run = Fq::one();
+    for (uint32_t q = 0; q < cnt; q++) {
+        pre[q] = run;
+        if (!js[q].z.is_zero()) run = fe_mul(run, js[q].z);
+    }
+    Fq inv = fe_inv(run);
+    for (uint32_t q = cnt; q-- > 0;) {
+        if (js[q].z.is_zero()) {
+            af[q].x = Fq::zero();
+            af[q].y = Fq::zero();
+            continue;
+        }
+        const Fq zi = fe_mul(inv, pre[q]);
+        inv = fe_mul(inv, js[q].z);
+        const Fq zi2 = fe_sqr(zi);
+        af[q].x = fe_mul(js[q].x, zi2);
+        af[q].y = fe_mul(js[q].y, fe_mul(zi2, zi));
+    }
+}
+
 Fr eval_small(const std::vector<Fr>& c, const Fr& x) {
     Fr acc = Fr::zero();
     for (size_t i = c.size(); i-- > 0;) acc = fe_add(fe_mul(acc, x), c[i]);
@@ -135,8 +160,26 @@ Fr vanishing_eval(const std::vector<Fr>& pts, const Fr& x) {
 
 }  // namespace
 
+static void bb_destroy(BatchBufs* bb) {
+    if (!bb) return;
+    if (bb->lk_u32) hipFree(bb->lk_u32);
+    if (bb->d_gp_items) hipFree(bb->d_gp_items);
+    if (bb->gp_scal) hipFree(bb->gp_scal);
+    if (bb->gp_host) hipHostFree(bb->gp_host);
+    if (bb->d_evargs) hipFree(bb->d_evargs);
+    if (bb->h_evargs) hipHostFree(bb->h_evargs);
+    if (bb->ev_scratch) hipFree(bb->ev_scratch);
+    if (bb->ev_out) hipFree(bb->ev_out);
+    if (bb->tail_host) hipHostFree(bb->tail_host);
+    delete bb;
+}
+
 void pk_destroy(zk_pk_rec* pk) {
     if (!pk) return;
+    for (zk_pk_rec* m : pk->members) pk_destroy(m);  // (a member's key half aliases this record's: only its workspace goes)
+    pk->members.clear();
+    bb_destroy(pk->bb);
+    pk->bb = nullptr;
     for (Fr* p : pk->dev) hipFree(p);
     if (pk->tail_host) hipHostFree(pk->tail_host);
     if (pk->rows_host) hipHostFree(pk->rows_host);
@@ -256,6 +299,77 @@ int pk_alloc_workspace(zk_ctx* c, zk_pk_rec* pk) {
         pk->batch_args_bytes = bytes;
         if (hipMalloc(&pk->d_batch_args, bytes) != hipSuccess || hipHostMalloc(&pk->h_batch_args, bytes) != hipSuccess) return fail(ZK_ENOMEM);
     }
+    return ZK_OK;
+}
+
+// a further workspace for the same key: the record is copied (the key half stays shared — nothing of it is in the copy's
+// `dev` list), every workspace member is reset and allocated afresh
+static zk_pk_rec* pk_make_member(zk_ctx* c, const zk_pk_rec* pk) {
+    zk_pk_rec* m = new (std::nothrow) zk_pk_rec(*pk);
+    if (!m) return nullptr;
+    m->is_member = true;
+    m->dev.clear();
+    m->members.clear();
+    m->bb = nullptr;
+    for (auto* v : {&m->adv_val, &m->adv_poly, &m->adv_coset, &m->z_val, &m->z_poly, &m->z_coset, &m->lk_in, &m->lk_ap, &m->lk_ap_poly,
+                    &m->lk_ap_coset, &m->lk_sp, &m->lk_sp_poly, &m->lk_sp_coset, &m->lk_z, &m->lk_z_poly, &m->lk_z_coset, &m->lk_in_coset,
+                    &m->gp_num, &m->gp_den, &m->gp_loc_p, &m->gp_loc_r})
+        v->clear();
+    m->random_poly = m->h_ext = m->h_comb = m->t_num = m->t_den = m->t_frac = m->t_a = m->t_b = m->t_small = m->kd_scratch = nullptr;
+    m->tail_host = nullptr;
+    m->rows_host = m->rows_dev = nullptr;
+    m->lk_u32 = nullptr;
+    m->gp_tot = m->gp_scal = m->gp_host = nullptr;
+    m->d_gp_items = nullptr;
+    m->h_batch_args = m->d_batch_args = nullptr;
+    m->d_qargs = m->h_qargs = nullptr;
+    m->d_evargs = m->h_evargs = nullptr;
+    m->d_lc_terms = m->h_lc_terms = nullptr;
+    m->ev_scratch = m->ev_out = nullptr;
+    m->lc_used = 0;
+    if (pk_alloc_workspace(c, m) != ZK_OK) {
+        pk_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+int pk_ensure_batch(zk_ctx* c, zk_pk_rec* pk, uint32_t batch) {
+    if (batch <= 1) return ZK_OK;
+    const Layout& lay = pk->lay;
+    const uint32_t n = lay.n, T = 1u << lay.lookup_bits, nprod = lay.n_chunks + lay.n_lookups;
+    if ((pk->members.size() + 1 < batch || !pk->bb || pk->bb->cap < batch) && !c->poly_spare.empty()) ctx_release_spares(c);
+    while (pk->members.size() + 1 < batch) {
+        zk_pk_rec* m = pk_make_member(c, pk);
+        if (!m) return ZK_ENOMEM;
+        pk->members.push_back(m);
+    }
+    if (pk->bb && pk->bb->cap >= batch) return ZK_OK;
+    hipStreamSynchronize(c->stream);
+    bb_destroy(pk->bb);
+    pk->bb = nullptr;
+    BatchBufs* bb = new (std::nothrow) BatchBufs();
+    if (!bb) return ZK_ENOMEM;
+    pk->bb = bb;  // (freed with the key whatever happens below)
+    const size_t nl = (size_t)batch * lay.n_lookups, np = (size_t)batch * nprod, ne = (size_t)batch * pk->max_evals;
+    const uint32_t stride = 6 * (T + 2) + 3 * (T / 1024 + 2);
+    if (hipMalloc(&bb->lk_u32, ((size_t)stride * nl + 4) * 4) != hipSuccess || hipMalloc(&bb->d_gp_items, np * sizeof(GpItem)) != hipSuccess ||
+        hipMalloc(&bb->gp_scal, 4 * np * sizeof(Fr)) != hipSuccess || hipHostMalloc(&bb->gp_host, 2 * np * sizeof(Fr)) != hipSuccess ||
+        hipMalloc(&bb->d_evargs, ne * sizeof(EvalItem)) != hipSuccess || hipHostMalloc(&bb->h_evargs, ne * sizeof(EvalItem)) != hipSuccess ||
+        hipMalloc(&bb->ev_scratch, ne * eval_blocks(n) * sizeof(Fr)) != hipSuccess || hipMalloc(&bb->ev_out, ne * sizeof(Fr)) != hipSuccess ||
+        hipHostMalloc(&bb->tail_host, ne * sizeof(Fr)) != hipSuccess)
+        return ZK_ENOMEM;
+    uint32_t* b = bb->lk_u32;
+    bb->lks.hist = b;
+    bb->lks.present = b + (T + 2);
+    bb->lks.absent = b + 2 * (T + 2);
+    bb->lks.off = b + 3 * (T + 2);
+    bb->lks.dex = b + 4 * (T + 2);
+    bb->lks.aex = b + 5 * (T + 2);
+    bb->lks.bsum = b + 6 * (T + 2);
+    bb->lks.stride = stride;
+    bb->lks.err = b + (size_t)stride * nl;
+    bb->cap = batch;
     return ZK_OK;
 }
 
@@ -627,10 +741,20 @@ struct Prover {
     const Fr *tw, *tw_ext;
     Fr omega, omega_inv;
     int rc = ZK_OK;
-    uint32_t rows_block = 0, rows_count = 0;  // staged row writes: current block of the ring, entries in it
+    // staged row writes: a ring of ROWS_BLOCKS blocks in the key's pinned / device staging; `rows` is this prover's own stager,
+    // or — in a lock-step batch — the first prover's, so that the blinding rows of all proofs go up in one launch per phase
+    struct RowStager {
+        RowEntry *host = nullptr, *dev = nullptr;
+        uint32_t block = 0, count = 0;
+    };
+    RowStager own_rows;
+    RowStager* rows = &own_rows;
 
     Prover(zk_ctx* c_, zk_pk_rec* pk_, const uint8_t seed[32], Transcript* t)
-        : c(c_), pk(pk_), lay(pk_->lay), st(c_->stream), rng(seed), tr(t), n(pk_->lay.n), N(4 * pk_->lay.n) {}
+        : c(c_), pk(pk_), lay(pk_->lay), st(c_->stream), rng(seed), tr(t), n(pk_->lay.n), N(4 * pk_->lay.n) {
+        own_rows.host = pk_->rows_host;
+        own_rows.dev = pk_->rows_dev;
+    }
 
     bool ok() const { return rc == ZK_OK; }
     void fail(int code) {
@@ -644,24 +768,24 @@ struct Prover {
     void set_rows(Fr* col, uint32_t first, const std::vector<Fr>& vals) {
         if (!ok()) return;
         if (vals.size() > 8) return fail(ZK_ESTATE);
-        if (rows_count == ROWS_CAP) rows_flush();
-        RowEntry& e = pk->rows_host[(size_t)rows_block * ROWS_CAP + rows_count++];
+        if (rows->count == ROWS_CAP) rows_flush();
+        RowEntry& e = rows->host[(size_t)rows->block * ROWS_CAP + rows->count++];
         memcpy(e.vals, vals.data(), vals.size() * sizeof(Fr));
         e.dst = col + first;
         e.count = (uint32_t)vals.size();
         e.pad_ = 0;
     }
     void rows_flush() {
-        if (!ok() || rows_count == 0) return;
-        RowEntry* h = pk->rows_host + (size_t)rows_block * ROWS_CAP;
-        RowEntry* d = pk->rows_dev + (size_t)rows_block * ROWS_CAP;
-        if (hipMemcpyAsync(d, h, rows_count * sizeof(RowEntry), hipMemcpyHostToDevice, st) != hipSuccess) return fail(ZK_EHIP);
-        launch_scatter_rows(d, rows_count, st);
-        rows_count = 0;
-        if (++rows_block == ROWS_BLOCKS) {
+        if (!ok() || rows->count == 0) return;
+        RowEntry* h = rows->host + (size_t)rows->block * ROWS_CAP;
+        RowEntry* d = rows->dev + (size_t)rows->block * ROWS_CAP;
+        if (hipMemcpyAsync(d, h, rows->count * sizeof(RowEntry), hipMemcpyHostToDevice, st) != hipSuccess) return fail(ZK_EHIP);
+        launch_scatter_rows(d, rows->count, st);
+        rows->count = 0;
+        if (++rows->block == ROWS_BLOCKS) {
             // the ring wraps: the oldest block's upload must have been consumed before it is overwritten
             if (hipStreamSynchronize(st) != hipSuccess) return fail(ZK_EHIP);
-            rows_block = 0;
+            rows->block = 0;
         }
     }
     // commitments in flight over a set of MSM lanes, collected (written to the transcript) in the
@@ -738,27 +862,8 @@ struct Prover {
         const uint32_t cnt = c->lanes[lane].batch;
         int r = ctx_msm_end_batch(c, lane, js);
         if (r) return fail(r);
-        // affine forms with ONE field inversion for the whole batch (Montgomery's trick over the z's)
-        Fq pre[MSM_MAX_BATCH];
-        Fq run = Fq::one();
-        for (uint32_t q = 0; q < cnt; q++) {
-            pre[q] = run;
-            if (!js[q].z.is_zero()) run = fe_mul(run, js[q].z);
-        }
-        Fq inv = fe_inv(run);
         G1Affine af[MSM_MAX_BATCH];
-        for (uint32_t q = cnt; q-- > 0;) {
-            if (js[q].z.is_zero()) {
-                af[q].x = Fq::zero();
-                af[q].y = Fq::zero();
-                continue;
-            }
-            const Fq zi = fe_mul(inv, pre[q]);
-            inv = fe_mul(inv, js[q].z);
-            const Fq zi2 = fe_sqr(zi);
-            af[q].x = fe_mul(js[q].x, zi2);
-            af[q].y = fe_mul(js[q].y, fe_mul(zi2, zi));
-        }
+        jac_batch_to_affine(js, cnt, af);
         for (uint32_t q = 0; q < cnt && ok(); q++)
             if (!tr->write_point(af[q])) fail(ZK_EINVAL);  // identity: halo2 refuses to write it
     }
@@ -869,13 +974,93 @@ struct Prover {
         Fr eval;
     };
 
+    // every opened value of a proof in transcript order, then h(x) (not written); where the groups start
+    struct EvIdx {
+        size_t i_fix = 0, i_rand = 0, i_sig = 0, i_z = 0, i_lk = 0, n_written = 0;
+    };
+    void build_evals(std::vector<Q>& ev, EvIdx& ix) const {
+        for (auto& aq : lay.advice_queries) ev.push_back(Q{pk->adv_poly[aq.first], aq.second, Fr::zero()});
+        ix.i_fix = ev.size();
+        for (uint32_t f = 0; f < lay.n_fix; f++) ev.push_back(Q{pk->fixed_poly[f], 0, Fr::zero()});
+        ix.i_rand = ev.size();
+        ev.push_back(Q{pk->random_poly, 0, Fr::zero()});
+        ix.i_sig = ev.size();
+        for (uint32_t p = 0; p < lay.perm_cols.size(); p++) ev.push_back(Q{pk->sigma_poly[p], 0, Fr::zero()});
+        ix.i_z = ev.size();
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+            ev.push_back(Q{pk->z_poly[ci], 0, Fr::zero()});
+            ev.push_back(Q{pk->z_poly[ci], 1, Fr::zero()});
+            if (ci != lay.n_chunks - 1) ev.push_back(Q{pk->z_poly[ci], lay.last_rot, Fr::zero()});
+        }
+        ix.i_lk = ev.size();
+        for (uint32_t l = 0; l < lay.n_lookups; l++) {
+            ev.push_back(Q{pk->lk_z_poly[l], 0, Fr::zero()});
+            ev.push_back(Q{pk->lk_z_poly[l], 1, Fr::zero()});
+            ev.push_back(Q{pk->lk_ap_poly[l], 0, Fr::zero()});
+            ev.push_back(Q{pk->lk_ap_poly[l], -1, Fr::zero()});
+            ev.push_back(Q{pk->lk_sp_poly[l], 0, Fr::zero()});
+        }
+        ix.n_written = ev.size();
+        ev.push_back(Q{pk->h_comb, 0, Fr::zero()});
+    }
+    // prover query order (== verifier's): advice, perm z (x, wx per chunk; then `last` in reverse), lookups
+    // (zL@x, a'@x, s'@x, a'@w^-1 x, zL@wx), fixed, sigma, h, random
+    std::vector<Q> queries_from_evals(const std::vector<Q>& ev, const EvIdx& ix) const {
+        std::vector<Q> queries(ev.begin(), ev.begin() + ix.i_fix);
+        std::vector<Q> lastq(lay.n_chunks);
+        size_t pos = ix.i_z;
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+            queries.push_back(ev[pos++]);
+            queries.push_back(ev[pos++]);
+            if (ci != lay.n_chunks - 1) lastq[ci] = ev[pos++];
+        }
+        for (int ci = (int)lay.n_chunks - 2; ci >= 0; ci--) queries.push_back(lastq[ci]);
+        pos = ix.i_lk;
+        for (uint32_t l = 0; l < lay.n_lookups; l++, pos += 5) {
+            queries.push_back(ev[pos]);      // zL @ x
+            queries.push_back(ev[pos + 2]);  // a' @ x
+            queries.push_back(ev[pos + 4]);  // s' @ x
+            queries.push_back(ev[pos + 3]);  // a' @ w^-1 x
+            queries.push_back(ev[pos + 1]);  // zL @ w x
+        }
+        for (size_t i = ix.i_fix; i < ix.i_rand; i++) queries.push_back(ev[i]);
+        for (size_t i = ix.i_sig; i < ix.i_z; i++) queries.push_back(ev[i]);
+        queries.push_back(ev[ix.n_written]);  // h
+        queries.push_back(ev[ix.i_rand]);     // random poly
+        return queries;
+    }
+    // h(X) = sum_i x^(n i) h_i(X) -> h_comb
+    void combine_h(const Fr& x) {
+        const Fr xn = fr_pow(x, n);
+        LincombArgs a;
+        memset(&a, 0, sizeof(a));
+        a.out = pk->h_comb;
+        a.n = n;
+        a.count = lay.n_h;
+        Fr p = Fr::one();
+        for (uint32_t i = 0; i < lay.n_h; i++) {
+            a.in[i] = pk->h_ext + (size_t)i * n;
+            a.len[i] = n;
+            a.c[i] = p;
+            a.unit[i] = i == 0;
+            p = fe_mul(p, xn);
+        }
+        launch_lincomb(a, st);
+    }
+
     // ------------------------------------------------------------------ run ---
-    int run(const Fr* const* advice_dev, int scheme) {
+    // domain constants, and the transcript's first word
+    int begin() {
         if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
         omega = fr_omega(lay.k);
         omega_inv = fe_inv(omega);
-        const uint32_t bf = BLINDING_FACTORS, usable = lay.usable;
         tr->common_scalar(pk->transcript_repr);
+        return ZK_OK;
+    }
+
+    int run(const Fr* const* advice_dev, int scheme) {
+        if (begin()) return rc;
+        const uint32_t bf = BLINDING_FACTORS, usable = lay.usable;
 
         // Commitments are computed as early as their inputs exist (none of a', s', the random
         // polynomial needs a challenge) and collected in transcript order; RNG draws keep
@@ -1159,48 +1344,10 @@ struct Prover {
         HT("x squeezed");
 
         // -- 7. evaluations: every opened value in ONE batched launch, then written in transcript order
-        // h(X) = sum x^(n i) h_i(X)
-        const Fr xn = fr_pow(x, n);
-        {
-            LincombArgs a;
-            memset(&a, 0, sizeof(a));
-            a.out = pk->h_comb;
-            a.n = n;
-            a.count = lay.n_h;
-            Fr p = Fr::one();
-            for (uint32_t i = 0; i < lay.n_h; i++) {
-                a.in[i] = pk->h_ext + (size_t)i * n;
-                a.len[i] = n;
-                a.c[i] = p;
-                a.unit[i] = i == 0;
-                p = fe_mul(p, xn);
-            }
-            launch_lincomb(a, st);
-        }
+        combine_h(x);
         std::vector<Q> ev;  // transcript order, then h(x) (not written)
-        for (auto& aq : lay.advice_queries) ev.push_back(Q{pk->adv_poly[aq.first], aq.second, Fr::zero()});
-        const size_t i_fix = ev.size();
-        for (uint32_t f = 0; f < lay.n_fix; f++) ev.push_back(Q{pk->fixed_poly[f], 0, Fr::zero()});
-        const size_t i_rand = ev.size();
-        ev.push_back(Q{pk->random_poly, 0, Fr::zero()});
-        const size_t i_sig = ev.size();
-        for (uint32_t p = 0; p < lay.perm_cols.size(); p++) ev.push_back(Q{pk->sigma_poly[p], 0, Fr::zero()});
-        const size_t i_z = ev.size();
-        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
-            ev.push_back(Q{pk->z_poly[ci], 0, Fr::zero()});
-            ev.push_back(Q{pk->z_poly[ci], 1, Fr::zero()});
-            if (ci != lay.n_chunks - 1) ev.push_back(Q{pk->z_poly[ci], lay.last_rot, Fr::zero()});
-        }
-        const size_t i_lk = ev.size();
-        for (uint32_t l = 0; l < lay.n_lookups; l++) {
-            ev.push_back(Q{pk->lk_z_poly[l], 0, Fr::zero()});
-            ev.push_back(Q{pk->lk_z_poly[l], 1, Fr::zero()});
-            ev.push_back(Q{pk->lk_ap_poly[l], 0, Fr::zero()});
-            ev.push_back(Q{pk->lk_ap_poly[l], -1, Fr::zero()});
-            ev.push_back(Q{pk->lk_sp_poly[l], 0, Fr::zero()});
-        }
-        const size_t n_written = ev.size();
-        ev.push_back(Q{pk->h_comb, 0, Fr::zero()});
+        EvIdx ix;
+        build_evals(ev, ix);
         if (ev.size() > pk->max_evals) return ZK_ESTATE;
         {
             EvalItem* ha = pk->h_evargs;
@@ -1218,32 +1365,8 @@ struct Prover {
             for (size_t i = 0; i < ev.size(); i++) ev[i].eval = pk->tail_host[i];
         HT("evals on host");
         }
-        for (size_t i = 0; i < n_written; i++) tr->write_scalar(ev[i].eval);
-        // prover query order (== verifier's): advice, perm z (x, wx per chunk; then `last` in reverse), lookups
-        // (zL@x, a'@x, s'@x, a'@w^-1 x, zL@wx), fixed, sigma, h, random
-        std::vector<Q> queries(ev.begin(), ev.begin() + i_fix);
-        {
-            std::vector<Q> lastq(lay.n_chunks);
-            size_t pos = i_z;
-            for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
-                queries.push_back(ev[pos++]);
-                queries.push_back(ev[pos++]);
-                if (ci != lay.n_chunks - 1) lastq[ci] = ev[pos++];
-            }
-            for (int ci = (int)lay.n_chunks - 2; ci >= 0; ci--) queries.push_back(lastq[ci]);
-            pos = i_lk;
-            for (uint32_t l = 0; l < lay.n_lookups; l++, pos += 5) {
-                queries.push_back(ev[pos]);      // zL @ x
-                queries.push_back(ev[pos + 2]);  // a' @ x
-                queries.push_back(ev[pos + 4]);  // s' @ x
-                queries.push_back(ev[pos + 3]);  // a' @ w^-1 x
-                queries.push_back(ev[pos + 1]);  // zL @ w x
-            }
-            for (size_t i = i_fix; i < i_rand; i++) queries.push_back(ev[i]);
-            for (size_t i = i_sig; i < i_z; i++) queries.push_back(ev[i]);
-            queries.push_back(ev[n_written]);  // h
-            queries.push_back(ev[i_rand]);     // random poly
-        }
+        for (size_t i = 0; i < ix.n_written; i++) tr->write_scalar(ev[i].eval);
+        const std::vector<Q> queries = queries_from_evals(ev, ix);
         if (!ok()) return rc;
 
         // -- 8. multi-open
@@ -1252,8 +1375,14 @@ struct Prover {
         return scheme == ZK_SCHEME_GWC ? open_gwc(queries, x, max_batch) : open_shplonk(queries, x);
     }
 
-    // GWC (ProverGWC, halo2_proofs poly/kzg/multiopen/gwc): one witness polynomial per rotation
-    int open_gwc(const std::vector<Q>& queries, const Fr& x, uint32_t max_batch) {
+    // ---- multi-open, in stages: each stage ends with polynomials launched whose commitments the transcript needs next, so
+    // that a lock-step prover of several proofs (prover_batch.h) can put the same commitment of all its proofs into ONE MSM
+    // pass; open_gwc / open_shplonk below run the stages of one proof back to back.
+
+    // GWC (ProverGWC, halo2_proofs poly/kzg/multiopen/gwc): one witness polynomial per rotation.
+    // Stage 1 (squeezes v): every set's (sum v^i p_i - sum v^i e_i) / (X - point), all in one batched division; the witness
+    // polynomials — to be committed in this order, no challenge in between — are returned in `wit`.
+    int gwc_stage1(const std::vector<Q>& queries, const Fr& x, std::vector<const Fr*>& wit) {
         const Fr v = tr->squeeze();
         std::vector<std::pair<int, std::vector<Q>>> sets;
         for (auto& qq : queries) {
@@ -1266,12 +1395,9 @@ struct Prover {
                 }
             if (!found) sets.push_back({qq.rot, {qq}});
         }
-        // the witness polynomials need no challenge in between: all of them go through one MSM pass.  Buffers: the
-        // h pieces (free once h(X) has been combined) and two temporaries — GWC has at most six rotation sets.
+        // Buffers: the h pieces (free once h(X) has been combined) and two temporaries — GWC has at most six rotation sets.
         Fr* wbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
         if (sets.size() > 6) return ZK_ESTATE;
-        LaneFifo wf{{0, 1, 2}, {}};
-        Batcher wb{&wf, ZK_BASIS_MONOMIAL, max_batch, {}};
         size_t set_idx = 0;
         Fr pts[6];
         for (auto& s : sets) {
@@ -1287,23 +1413,54 @@ struct Prover {
             set_idx++;
             if (!ok()) return rc;
         }
-        // every set's (sum v^i p_i - sum v^i e_i) / (X - point) in one batched division, in place
         launch_kate_division_batch(wbuf, wbuf, pts, (uint32_t)set_idx, n, pk->kd_scratch, st);
-        for (size_t i = 0; i < set_idx; i++) batch_add(wb, wbuf[i]);
+        for (size_t i = 0; i < set_idx; i++) wit.push_back(wbuf[i]);
+        return rc;
+    }
+    int open_gwc(const std::vector<Q>& queries, const Fr& x, uint32_t max_batch) {
+        std::vector<const Fr*> wit;
+        if (int r = gwc_stage1(queries, x, wit)) return r;
+        // the witness polynomials need no challenge in between: all of them go through one MSM pass
+        LaneFifo wf{{0, 1, 2}, {}};
+        Batcher wb{&wf, ZK_BASIS_MONOMIAL, max_batch, {}};
+        for (const Fr* w : wit) batch_add(wb, w);
         batch_flush(wb);
         fifo_drain(wf);
         return rc;
     }
 
     // SHPLONK (ProverSHPLONK, poly/kzg/multiopen/shplonk)
-    int open_shplonk(const std::vector<Q>& queries, const Fr& x) {
-        // SHPLONK: group commitments by their set of rotations
-        struct CR {
-            const Fr* poly;
-            std::vector<int> rots;
-            std::vector<Fr> evals;
-        };
+    struct CR {  // a polynomial with its rotations (sorted by point value) and evaluations
+        const Fr* poly;
+        std::vector<int> rots;
+        std::vector<Fr> evals;
+    };
+    struct RotPt {
+        int rot;
+        Fr pt, canon;
+    };
+    struct RS {
+        std::vector<int> rots;     // sorted by point value (BTreeSet<Fr>)
+        std::vector<size_t> coms;  // indices into `com`
+    };
+    struct Shplonk {  // what stage 2 needs of stage 1
         std::vector<CR> com;
+        std::vector<RotPt> rot_pts;
+        std::vector<RS> rsets;
+        std::vector<int> all_rots;
+        std::vector<std::vector<Fr>> low;  // per commitment: its remainder polynomial (degree < |rotation set|)
+        Fr yc, v;
+        Fr* hx = nullptr;
+    };
+    static const RotPt& sh_rot_pt(const Shplonk& S, int r) {
+        for (auto& e : S.rot_pts)
+            if (e.rot == r) return e;
+        return S.rot_pts[0];  // (every rotation of a query is in the list: shplonk_stage1 fills it first)
+    }
+    // Stage 1 (squeezes y, v): h(X) = sum_i v^i (sum_j y^j (P_ij - R_ij)) / Z_i is launched; its commitment comes next.
+    int shplonk_stage1(const std::vector<Q>& queries, const Fr& x, Shplonk& S) {
+        // group commitments by their set of rotations
+        std::vector<CR>& com = S.com;
         {
             std::unordered_map<const Fr*, size_t> seen;  // wide circuits open hundreds of polynomials: no linear searches here
             seen.reserve(queries.size());
@@ -1318,32 +1475,24 @@ struct Prover {
             }
         }
         // the points, once per distinct rotation: x w^rot and its canonical image (BTreeSet<Fr> orders by the integer value)
-        struct RotPt {
-            int rot;
-            Fr pt, canon;
-        };
-        std::vector<RotPt> rot_pts;
-        auto rot_pt = [&](int r) -> const RotPt& {
-            for (auto& e : rot_pts)
-                if (e.rot == r) return e;
-            const Fr pt = xrot(x, r);
-            rot_pts.push_back(RotPt{r, pt, fe_from_mont(pt)});
-            return rot_pts.back();
-        };
-        for (auto& qq : queries) rot_pt(qq.rot);  // filled before any reference into rot_pts is held
+        for (auto& qq : queries) {
+            bool have = false;
+            for (auto& e : S.rot_pts) have = have || e.rot == qq.rot;
+            if (!have) {
+                const Fr pt = xrot(x, qq.rot);
+                S.rot_pts.push_back(RotPt{qq.rot, pt, fe_from_mont(pt)});
+            }
+        }
         auto pt_less = [&](int ra, int rb) {
-            const Fr &a = rot_pt(ra).canon, &b = rot_pt(rb).canon;
+            const Fr &a = sh_rot_pt(S, ra).canon, &b = sh_rot_pt(S, rb).canon;
             for (int i = 7; i >= 0; i--)
                 if (a.v[i] != b.v[i]) return a.v[i] < b.v[i];
             return false;
         };
-        struct RS {
-            std::vector<int> rots;  // sorted by point value (BTreeSet<Fr>)
-            std::vector<CR*> coms;
-        };
-        std::vector<RS> rsets;
-        std::vector<int> all_rots;
-        for (auto& cr : com) {
+        std::vector<RS>& rsets = S.rsets;
+        std::vector<int>& all_rots = S.all_rots;
+        for (size_t ci = 0; ci < com.size(); ci++) {
+            CR& cr = com[ci];
             // sort this commitment's (rot, eval) pairs by point
             std::vector<size_t> order(cr.rots.size());
             for (size_t i = 0; i < order.size(); i++) order[i] = i;
@@ -1358,24 +1507,22 @@ struct Prover {
             cr.evals = e2;
             for (int r : cr.rots)
                 if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
-            RS* hit = nullptr;
-            for (auto& rs : rsets)
-                if (rs.rots == cr.rots) hit = &rs;
-            if (!hit) {
-                rsets.push_back(RS{cr.rots, {}});
-                hit = &rsets.back();
-            }
-            hit->coms.push_back(&cr);
+            size_t hit = rsets.size();
+            for (size_t si = 0; si < rsets.size(); si++)
+                if (rsets[si].rots == cr.rots) hit = si;  // (the last match, as before: sets are distinct, so the only one)
+            if (hit == rsets.size()) rsets.push_back(RS{cr.rots, {}});
+            rsets[hit].coms.push_back(ci);
         }
         std::sort(all_rots.begin(), all_rots.end(), pt_less);
         HT("grouped");
-        const Fr yc = tr->squeeze();
-        const Fr v = tr->squeeze();
-        std::vector<std::vector<Fr>> low(com.size());
-        auto com_index = [&](CR* p) { return (size_t)(p - &com[0]); };
+        S.yc = tr->squeeze();
+        S.v = tr->squeeze();
+        const Fr yc = S.yc, v = S.v;
+        S.low.assign(com.size(), {});
         // h(X) = sum_i v^i * ( sum_j y^j (P_ij - R_ij) ) / Z_i.  Every rotation set has its own buffer (the h pieces
         // are free by now); step s divides, in ONE batched launch, every set that still has a point left by it.
         Fr* hx = pk->t_frac;  // h(X)
+        S.hx = hx;
         Fr* sbuf[6] = {pk->h_ext, pk->h_ext + n, pk->h_ext + 2 * (size_t)n, pk->h_ext + 3 * (size_t)n, pk->t_num, pk->t_den};
         if (rsets.size() > 6) return ZK_ESTATE;
         std::vector<std::vector<Fr>> set_pts;
@@ -1383,18 +1530,19 @@ struct Prover {
         for (size_t si = 0; si < rsets.size(); si++) {
             auto& rs = rsets[si];
             std::vector<Fr> pts;
-            for (int r : rs.rots) pts.push_back(rot_pt(r).pt);
+            for (int r : rs.rots) pts.push_back(sh_rot_pt(S, r).pt);
             const std::vector<std::vector<Fr>> basis = lagrange_basis(pts);
             std::vector<Term> terms;
             std::vector<Fr> rsum(pts.size(), Fr::zero());
             Fr py = Fr::one();
-            for (CR* cr : rs.coms) {
-                std::vector<Fr>& lo = low[com_index(cr)];
+            for (size_t ci : rs.coms) {
+                const CR& cr = com[ci];
+                std::vector<Fr>& lo = S.low[ci];
                 lo.assign(pts.size(), Fr::zero());
                 for (size_t j = 0; j < pts.size(); j++)
-                    for (size_t t = 0; t < pts.size(); t++) lo[t] = fe_add(lo[t], fe_mul(basis[j][t], cr->evals[j]));
-                terms.push_back(Term{cr->poly, py});
-                for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, low[com_index(cr)][t]));
+                    for (size_t t = 0; t < pts.size(); t++) lo[t] = fe_add(lo[t], fe_mul(basis[j][t], cr.evals[j]));
+                terms.push_back(Term{cr.poly, py});
+                for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, lo[t]));
                 py = fe_mul(py, yc);
             }
             // sum_j y^j P_j(X) minus sum_j y^j R_j(X) (degree < |set|: a few low coefficients, known on the host)
@@ -1426,8 +1574,11 @@ struct Prover {
             lincomb_many(hx, terms, false, Fr::zero());
         HT("hx launched");
         }
-        commit_write(hx, n, ZK_BASIS_MONOMIAL);
-        if (!ok()) return rc;
+        return rc;
+    }
+    // Stage 2 (h's commitment is in the transcript; squeezes u): the final quotient (L(X) / (X - u)) / z_0 is launched in
+    // *out; its commitment ends the proof.
+    int shplonk_stage2(Shplonk& S, const Fr** out) {
         const Fr u = tr->squeeze();
         HT("u squeezed");
         // L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X)
@@ -1435,33 +1586,45 @@ struct Prover {
         Fr sub = Fr::zero();
         Fr pv = Fr::one();
         std::vector<Fr> z_diffs;
-        for (auto& rs : rsets) {
+        for (auto& rs : S.rsets) {
             std::vector<Fr> diffs;
-            for (int r : all_rots)
-                if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(rot_pt(r).pt);
+            for (int r : S.all_rots)
+                if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(sh_rot_pt(S, r).pt);
             const Fr zi = vanishing_eval(diffs, u);
             z_diffs.push_back(zi);
             Fr py = Fr::one();
-            for (CR* cr : rs.coms) {
+            for (size_t ci : rs.coms) {
                 const Fr coef = fe_mul(fe_mul(pv, zi), py);
-                terms.push_back(Term{cr->poly, coef});
-                sub = fe_add(sub, fe_mul(coef, eval_small(low[com_index(cr)], u)));
-                py = fe_mul(py, yc);
+                terms.push_back(Term{S.com[ci].poly, coef});
+                sub = fe_add(sub, fe_mul(coef, eval_small(S.low[ci], u)));
+                py = fe_mul(py, S.yc);
             }
-            pv = fe_mul(pv, v);
+            pv = fe_mul(pv, S.v);
         }
         std::vector<Fr> all_pts;
-        for (int r : all_rots) all_pts.push_back(rot_pt(r).pt);
+        for (int r : S.all_rots) all_pts.push_back(sh_rot_pt(S, r).pt);
         const Fr zt = vanishing_eval(all_pts, u);
-        terms.push_back(Term{hx, fe_neg(zt)});
+        terms.push_back(Term{S.hx, fe_neg(zt)});
         lincomb_many(pk->t_a, terms, true, sub);
         HT("L launched");
         launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
         launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
-        commit_write(pk->t_b, n, ZK_BASIS_MONOMIAL);
+        *out = pk->t_b;
+        return rc;
+    }
+    int open_shplonk(const std::vector<Q>& queries, const Fr& x) {
+        Shplonk S;
+        if (int r = shplonk_stage1(queries, x, S)) return r;
+        commit_write(S.hx, n, ZK_BASIS_MONOMIAL);
+        if (!ok()) return rc;
+        const Fr* last = nullptr;
+        if (int r = shplonk_stage2(S, &last)) return r;
+        commit_write(last, n, ZK_BASIS_MONOMIAL);
         return rc;
     }
 };
+
+#include "prover_batch.h"
 
 }  // namespace
 
@@ -1516,6 +1679,64 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     *proof_len = tr->out.size();
     if (!proof_out || proof_cap < tr->out.size()) return proof_out ? ZK_EINVAL : ZK_OK;
     memcpy(proof_out, tr->out.data(), tr->out.size());
+    return ZK_OK;
+}
+
+// create_proof for `batch` independent proofs of one key in lock-step (prover_batch.h)
+ZK_API(zk_prove_batch, (zk_ctx* c, zk_pk h, size_t batch, const zk_poly* advice, size_t n_advice, const uint8_t* rng_seeds, int transcript, int scheme, uint8_t* proofs_out, size_t proof_stride, size_t* proof_len), (c, h, batch, advice, n_advice, rng_seeds, transcript, scheme, proofs_out, proof_stride, proof_len)) {
+    if (!c || !advice || !rng_seeds || !proof_len || batch == 0 || batch > ZK_PROVE_BATCH_MAX) return ZK_EINVAL;
+    if (batch == 1) return zk_prove(c, h, advice, n_advice, rng_seeds, transcript, scheme, proofs_out, proof_stride, proof_len);
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    zk_pk_rec* pk = it->second;
+    const Layout& lay = pk->lay;
+    if (pk->srs_gen != c->srs_gen) return ZK_ESTATE;  // the SRS was replaced after this key was made: its vk is stale
+    if (n_advice != lay.n_adv || c->srs_k != (int)lay.k) return ZK_EINVAL;
+    if (transcript != ZK_TRANSCRIPT_BLAKE2B && transcript != ZK_TRANSCRIPT_EVM) return ZK_EINVAL;
+    if (scheme == ZK_SCHEME_DEFAULT) scheme = transcript == ZK_TRANSCRIPT_EVM ? ZK_SCHEME_GWC : ZK_SCHEME_SHPLONK;
+    if (scheme != ZK_SCHEME_GWC && scheme != ZK_SCHEME_SHPLONK) return ZK_EINVAL;
+    const uint32_t B = (uint32_t)batch;
+    // all grand products of the batch are scanned by one 256-lane workgroup (gp_chain_kernel)
+    if ((uint64_t)B * (lay.n_chunks + lay.n_lookups) > 256) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    std::vector<const Fr*> adv(batch * n_advice);
+    for (size_t j = 0; j < batch * n_advice; j++) {
+        auto pit = c->polys.find(advice[j]);
+        if (pit == c->polys.end() || pit->second.n != lay.n) return ZK_EINVAL;
+        adv[j] = pit->second.ptr;
+    }
+    if ((rc = pk_ensure_batch(c, pk, B))) return rc;
+    // columns per MSM pass: the same commitment of all proofs at once, two columns per proof where a phase has them (a', s';
+    // z, zL) — ZK_OPT_BATCH_PASS_COLUMNS overrides; the lanes' workspaces grow to that on their next pass
+    uint32_t cap = c->opt_batch_pass_cols ? c->opt_batch_pass_cols : std::max(std::min<uint32_t>(2 * B, 8u), ctx_msm_max_batch(c));
+    cap = std::min<uint32_t>(cap, MSM_MAX_BATCH);
+    if (!c->table_c) cap = 1;  // no window tables (k < 10): one column per pass
+    c->msm_min_cols = std::max(c->msm_min_cols, cap);
+    std::vector<std::unique_ptr<Transcript>> trs;
+    std::vector<std::unique_ptr<Prover>> provers;
+    std::vector<Prover*> P;
+    for (uint32_t q = 0; q < B; q++) {
+        trs.emplace_back(transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)new EvmTranscript() : (Transcript*)new Blake2bTranscript());
+        provers.emplace_back(new Prover(c, q == 0 ? pk : pk->members[q - 1], rng_seeds + 32 * (size_t)q, trs.back().get()));
+        P.push_back(provers.back().get());
+    }
+    {
+        BatchRun run(c, pk, P, cap);
+        rc = run.run(adv.data(), scheme);
+    }
+    ctx_msm_drain(c);  // an early error may leave commitments in flight
+    hipStreamSynchronize(c->stream);
+    if (rc) return rc;
+    if (hipGetLastError() != hipSuccess) return ZK_EHIP;
+    const size_t len = trs[0]->out.size();
+    for (uint32_t q = 0; q < B; q++)
+        if (trs[q]->out.size() != len) return ZK_EINTERNAL;  // (one shape, one length)
+    *proof_len = len;
+    if (!proofs_out) return ZK_OK;
+    if (proof_stride < len) return ZK_EINVAL;
+    for (uint32_t q = 0; q < B; q++) memcpy(proofs_out + (size_t)q * proof_stride, trs[q]->out.data(), len);
     return ZK_OK;
 }
 

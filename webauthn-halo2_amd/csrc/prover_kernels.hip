@@ -719,18 +719,22 @@ __global__ __launch_bounds__(256) void gp_offsets_batch_kernel(const GpItem* __r
 }
 
 // k[p] = init_p / Q_p with init_p = 1, or (chained) the predecessor's z at row `row` (1 <= row < n):
-// z_p[row] = k[p] * P_{row-1} * R_row.  The chained products are the leading run of the list (the
-// permutation chunks): init_p = prod_{j<p} (P_{j,row-1} R_{j,row} / Q_j) — one lane per product and a
-// block scan.  nprod <= 256.
+// z_p[row] = k[p] * P_{row-1} * R_row.  A chain is a run of products whose members after the first carry the chain flag (the
+// permutation chunks of one proof); a list may hold several chains (the proofs of a lock-step batch):
+// init_p = prod over the chain's members j < p of (P_{j,row-1} R_{j,row} / Q_j) — one lane per product and a SEGMENTED block
+// scan (a product without the flag starts a new segment).  nprod <= 256.
 __global__ __launch_bounds__(256) void gp_chain_kernel(const GpItem* __restrict__ items, const Fr* __restrict__ q_inv, uint32_t nprod,
                                                        uint32_t row, Fr* __restrict__ kout, Fr* __restrict__ init_out) {
     __shared__ Fr sh[256];
+    __shared__ uint32_t head[256];  // the segment of lane p has a head at or before p within the scanned distance
     const uint32_t p = threadIdx.x;
     Fr v = Fr::one(), qi = Fr::one();
     bool chained_next = false;  // does product p + 1 start from this one?
+    bool is_head = true;
     if (p < nprod) {
         const GpItem it = items[p];
         qi = fe_load(q_inv + p);
+        is_head = p == 0 || !it.chain;
         chained_next = p + 1 < nprod && items[p + 1].chain;
         if (chained_next) {
             const Fr pfx = fe_mul(fe_load(it.tot_p + (row - 1) / PP_B), fe_load(it.loc_p + row - 1));
@@ -738,15 +742,21 @@ __global__ __launch_bounds__(256) void gp_chain_kernel(const GpItem* __restrict_
             v = fe_mul(qi, fe_mul(pfx, sfx));
         }
     }
-    sh[p] = v;  // 1 outside the chain: the inclusive scan below is then the chain's running product
+    sh[p] = v;  // 1 outside a chain: the inclusive scan below is then the chain's running product
+    head[p] = is_head ? 1u : 0u;
     __syncthreads();
 #pragma unroll 1
     for (uint32_t d = 1; d < 256; d <<= 1) {
         Fr o = Fr::one();
-        const bool has = p >= d;
+        uint32_t oh = 0;
+        const bool has = p >= d && !head[p];  // a lane whose segment head has been reached takes nothing from beyond it
+        if (p >= d) oh = head[p - d];
         if (has) o = sh[p - d];
         __syncthreads();
-        if (has) sh[p] = fe_mul(sh[p], o);
+        if (has) {
+            sh[p] = fe_mul(sh[p], o);
+            head[p] = oh;
+        }
         __syncthreads();
     }
     if (p < nprod) {

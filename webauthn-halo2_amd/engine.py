@@ -21,7 +21,7 @@ ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS, 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
 ZK_SERDE_PROCESSED, ZK_SERDE_RAW_BYTES, ZK_SERDE_RAW_BYTES_UNCHECKED = 0, 1, 2
 ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT, ZK_OPT_MSM_TAIL_STREAM = 1, 2, 3, 4, 5
-ZK_OPT_MSM_TAIL_MAIN_ABOVE = 6
+ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS = 6, 7
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
 
@@ -101,6 +101,8 @@ def load_library():
         "zk_proof_size": ([vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_prove": ([vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.c_char_p, ctypes.c_int,
                       ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(sz)], ctypes.c_int),
+        "zk_prove_batch": ([vp, ctypes.c_uint64, sz, ctypes.POINTER(ctypes.c_uint64), sz, ctypes.c_char_p, ctypes.c_int,
+                            ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_srs_write": ([vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)], ctypes.c_int),
         "zk_srs_read": ([vp, vp, sz, ctypes.c_int], ctypes.c_int),
         "zk_srs_set_g2": ([vp, u64p, u64p], ctypes.c_int),
@@ -401,6 +403,25 @@ class Engine:
         self._chk(self.L.zk_prove(self.ctx, pk, hs, len(advice_polys), seed, transcript, scheme, buf, len(buf),
                                   ctypes.byref(ln)), "zk_prove")
         return buf.raw[:ln.value]
+
+    def prove_batch(self, pk, advice_sets, seeds, transcript=ZK_TRANSCRIPT_BLAKE2B, scheme=ZK_SCHEME_DEFAULT):
+        """zk_prove_batch: len(advice_sets) independent proofs of one key in lock-step.  advice_sets[j]: proof j's advice
+        columns (resident Polys); seeds[j]: its 32-byte RNG seed.  Returns the proofs, each byte-identical to
+        prove(pk, advice_sets[j], seeds[j], ...)."""
+        B = len(advice_sets)
+        if B == 0 or len(seeds) != B or any(len(sd) != 32 for sd in seeds):
+            raise ValueError("one 32-byte rng seed per proof")
+        na = len(advice_sets[0])
+        if any(len(a) != na for a in advice_sets):
+            raise ValueError("every proof of a batch has the key's number of advice columns")
+        hs = (ctypes.c_uint64 * (B * na))(*[p.h for a in advice_sets for p in a])
+        ln = ctypes.c_size_t()
+        self._chk(self.L.zk_proof_size(self.ctx, pk, transcript, scheme, ctypes.byref(ln)), "zk_proof_size")
+        stride = ln.value
+        buf = ctypes.create_string_buffer(stride * B)
+        self._chk(self.L.zk_prove_batch(self.ctx, pk, B, hs, na, b"".join(bytes(sd) for sd in seeds), transcript, scheme, buf, stride,
+                                        ctypes.byref(ln)), "zk_prove_batch")
+        return [buf.raw[j * stride:j * stride + ln.value] for j in range(B)]
 
     def proof_size(self, pk, transcript=ZK_TRANSCRIPT_BLAKE2B, scheme=ZK_SCHEME_DEFAULT):
         ln = ctypes.c_size_t()
