@@ -1,5 +1,6 @@
 """Proofs/s of the proving server's default shape (k = 17, EVM transcript + GWC) against the number of pipelines in flight on
-one GPU (bench.py measures k = 19, where two are best).  usage: inflight_k17.py [pipelines ...]"""
+one GPU (bench.py measures k = 19).  usage: inflight_k17.py [pipelines[xlockstep] ...]   ("2x4": two pipelines, each proving four
+jobs at a time in lock-step, zk_prove_batch)"""
 import os
 import sys
 import threading
@@ -12,7 +13,8 @@ p = circuit.K17
 jobs = list(range(8))
 wit = batch.synthesize_jobs(p, jobs)
 fixed, copies = batch.structure(p)
-for npipe in [int(x) for x in (sys.argv[1:] or ["1", "2", "3", "4"])]:
+for spec in (sys.argv[1:] or ["1", "2", "3", "4"]):
+    npipe, ls = (int(x) for x in (spec.split("x") + ["1"])[:2])
     pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)]
     for _ in range(npipe - 1):
         pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
@@ -20,9 +22,13 @@ for npipe in [int(x) for x in (sys.argv[1:] or ["1", "2", "3", "4"])]:
         for j in jobs:
             pl.load(j, wit[j])
         pl.prove(0, E.ZK_TRANSCRIPT_EVM, keep=True)
-    reps = 60
+    reps = 64
 
     def work(pl):
+        if ls > 1:
+            for i in range(0, reps, ls):
+                pl.prove_lockstep([jobs[(i + q) % len(jobs)] for q in range(ls)], E.ZK_TRANSCRIPT_EVM, keep=True)
+            return
         for i in range(reps):
             pl.prove(jobs[i % len(jobs)], E.ZK_TRANSCRIPT_EVM, keep=True)
 
@@ -31,6 +37,6 @@ for npipe in [int(x) for x in (sys.argv[1:] or ["1", "2", "3", "4"])]:
     [t.start() for t in ths]
     [t.join() for t in ths]
     dt = time.perf_counter() - t0
-    print(f"k=17 EVM, {npipe} pipelines: {npipe * reps / dt:6.1f} proofs/s ({dt / reps * 1e3:.2f} ms per proof and pipeline)", flush=True)
+    print(f"k=17 EVM, {npipe} pipelines x lock-step {ls}: {npipe * reps / dt:6.1f} proofs/s ({dt / reps * 1e3:.2f} ms per proof and pipeline)", flush=True)
     for pl in pipes[::-1]:
         pl.close()
