@@ -92,6 +92,10 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
 #define ZK_OPT_MSM_TAIL_MAIN_ABOVE 6 /* the auto threshold above, 1..64; 0 restores the measured default (2, for the runtime's default
                                         of four hardware queues: two contexts x two streams fill them) */
 #define ZK_OPT_BATCH_PASS_COLUMNS 7  /* zk_prove_batch: columns per MSM pass, 1..256; 0 = min(2 x batch, 8) */
+#define ZK_OPT_XFORM_STREAM 8        /* zk_prove: where a proof's column transforms (values -> coefficients -> extended coset) run:
+                                        0 auto (beside the MSM passes on a stream of their own while this is the only active context
+                                        of the process on the device — a lone proof —, in order on the main stream otherwise: see
+                                        ZK_OPT_MSM_TAIL_STREAM on hardware queues), 1 always the side stream, 2 always the main stream */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

@@ -73,6 +73,15 @@ struct zk_ctx {
     // pipeline's kernels behind another's accumulation (measured, tools/queue_ab2.sh: 4 pipelines 103.7 proofs/s with one
     // stream each, 99.1 with a tail stream each even on 8 queues, 94.4 for round 3's 2 pipelines x 4 streams)
     hipStream_t tail_stream = nullptr;
+    // The context's TRANSFORM stream (round 5): the coefficient / extended-coset forms of a proof's columns are needed by the
+    // quotient only, so a LONE proof (no other context active on the device: three streams fit the four hardware queues)
+    // runs those NTTs beside its MSM passes instead of between them — both are bound by the issue of their own instruction
+    // streams and leave each other's stalls to fill.  ev_rows: the last flush of staged blinding rows on the main stream (what
+    // a column's transforms wait for); ev_xform: the last transform enqueued (what the quotient waits for).
+    hipStream_t xform_stream = nullptr;
+    hipEvent_t ev_rows = nullptr, ev_xform = nullptr;
+    bool xform_pending = false;
+    uint32_t opt_xform_stream = 0;  // ZK_OPT_XFORM_STREAM: 0 auto (side stream for a lone context), 1 side stream, 2 main stream
     // MSM lanes: each in-flight MSM owns a workspace and a pinned result buffer
     static constexpr int MSM_LANES = 3;
     struct MsmLane {
@@ -173,7 +182,7 @@ void ctx_msm_drain(zk_ctx* c);  // error paths: wait for every MSM in flight and
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out);
 // the same transform over `batch` vectors in one launch per pass (batch <= ctx_ntt_max_batch(log_n))
 int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dsts, uint32_t batch, uint32_t log_n, bool inverse,
-                  bool coset, size_t n_out);
+                  bool coset, size_t n_out, hipStream_t on = nullptr /* the context's main stream */);
 uint32_t ctx_ntt_max_batch(uint32_t log_n);
 void pk_destroy_all(zk_ctx* c);
 // SRS plumbing shared by engine.hip (setup / load) and serde.hip (read)

@@ -43,6 +43,7 @@ int ctx_bind(zk_ctx* c) {
 
 int ctx_ensure_scratch(zk_ctx* c, size_t n) {
     if (c->scratch_n >= n) return ZK_OK;
+    if (c->xform_stream) hipStreamSynchronize(c->xform_stream);  // (transforms in flight use the buffer)
     if (c->scratch) hipFree(c->scratch);
     c->scratch = nullptr;
     c->scratch_n = 0;
@@ -66,6 +67,7 @@ int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
     const size_t n = (size_t)1 << log_n;
     if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     launch_twiddles(tw, fr_omega(log_n), (uint32_t)n, c->stream);
+    hipStreamSynchronize(c->stream);  // made once per context and size; read from any of the context's streams afterwards
     c->twiddles[log_n] = tw;
     *out = tw;
     return ZK_OK;
@@ -82,6 +84,7 @@ int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out) {
     const size_t n = (size_t)1 << log_n;
     if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     launch_twiddles_internal(tw, fr_omega(log_n), (uint32_t)n, c->stream);
+    hipStreamSynchronize(c->stream);  // made once per context and size; read from any of the context's streams afterwards
     c->twiddles_ntt[log_n] = tw;
     *out = tw;
     return ZK_OK;
@@ -98,6 +101,7 @@ int ctx_get_twiddles_ninv(zk_ctx* c, uint32_t log_n, const Fr** out) {
     const size_t n = (size_t)1 << log_n;
     if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     launch_twiddles_scaled(tw, fr_omega(log_n), fe_inv(fr_from_u64(n)), (uint32_t)n, c->stream);
+    hipStreamSynchronize(c->stream);  // made once per context and size; read from any of the context's streams afterwards
     c->twiddles_ninv[log_n] = tw;
     *out = tw;
     return ZK_OK;
@@ -385,7 +389,9 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
             zk_ctx_destroy(c);
             return ZK_EHIP;
         }
-    if (hipStreamCreate(&c->tail_stream) != hipSuccess) {
+    if (hipStreamCreate(&c->tail_stream) != hipSuccess || hipStreamCreate(&c->xform_stream) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_xform, hipEventDisableTiming) != hipSuccess) {
         zk_ctx_destroy(c);
         return ZK_EHIP;
     }
@@ -437,6 +443,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
         c->opt_tail_stream = parent->opt_tail_stream;
         c->opt_tail_main_above = parent->opt_tail_main_above;
         c->opt_batch_pass_cols = parent->opt_batch_pass_cols;
+        c->opt_xform_stream = parent->opt_xform_stream;
         c->srs_gen++;
     }
     *out = c;
@@ -449,6 +456,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
+    if (c->xform_stream) hipStreamSynchronize(c->xform_stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
     for (auto& kv : c->twiddles_ninv) hipFree(kv.second);
@@ -477,6 +485,9 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (int i = 0; i < ZK_T_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) hipEventDestroy(c->ev[i][j]);
+    if (c->ev_rows) hipEventDestroy(c->ev_rows);
+    if (c->ev_xform) hipEventDestroy(c->ev_xform);
+    if (c->xform_stream) hipStreamDestroy(c->xform_stream);
     if (c->tail_stream) hipStreamDestroy(c->tail_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -544,6 +555,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_MSM_TAIL_MAIN_ABOVE:
             if (value > 64) return ZK_EINVAL;
             c->opt_tail_main_above = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_XFORM_STREAM:
+            if (value > 2) return ZK_EINVAL;
+            c->opt_xform_stream = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_BATCH_PASS_COLUMNS:
             if (value > MSM_MAX_BATCH) return ZK_EINVAL;
@@ -1093,7 +1108,8 @@ uint32_t ctx_ntt_max_batch(uint32_t log_n) {
 }
 
 int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dsts, uint32_t batch, uint32_t log_n, bool inverse,
-                  bool coset, size_t n_out) {
+                  bool coset, size_t n_out, hipStream_t on) {
+    const hipStream_t st = on ? on : c->stream;
     const size_t N = (size_t)1 << log_n;
     if (batch == 0 || batch > ctx_ntt_max_batch(log_n)) return ZK_EINVAL;
     int rc = ctx_ensure_scratch(c, N * batch);
@@ -1137,9 +1153,9 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
         job.post[1] = coset ? fe_mul(ninv, c->zeta2) : ninv;
         job.post[2] = coset ? fe_mul(ninv, c->zeta) : ninv;
     }
-    hipEventRecord(c->ev[ZK_T_NTT][0], c->stream);
-    hipError_t e = ntt_run(job, c->stream);
-    hipEventRecord(c->ev[ZK_T_NTT][1], c->stream);
+    hipEventRecord(c->ev[ZK_T_NTT][0], st);
+    hipError_t e = ntt_run(job, st);
+    hipEventRecord(c->ev[ZK_T_NTT][1], st);
     c->ev_valid[ZK_T_NTT] = true;
     if (e != hipSuccess) {
         c->last_hip = (int)e;

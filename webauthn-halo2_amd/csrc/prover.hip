@@ -749,6 +749,7 @@ struct Prover {
     };
     RowStager own_rows;
     RowStager* rows = &own_rows;
+    bool batch_member = false;  // one of the proofs of a lock-step batch (prover_batch.h): transforms stay on the main stream
 
     Prover(zk_ctx* c_, zk_pk_rec* pk_, const uint8_t seed[32], Transcript* t)
         : c(c_), pk(pk_), lay(pk_->lay), st(c_->stream), rng(seed), tr(t), n(pk_->lay.n), N(4 * pk_->lay.n) {
@@ -781,6 +782,7 @@ struct Prover {
         RowEntry* d = rows->dev + (size_t)rows->block * ROWS_CAP;
         if (hipMemcpyAsync(d, h, rows->count * sizeof(RowEntry), hipMemcpyHostToDevice, st) != hipSuccess) return fail(ZK_EHIP);
         launch_scatter_rows(d, rows->count, st);
+        hipEventRecord(c->ev_rows, st);  // what the transform stream waits for (transforms())
         rows->count = 0;
         if (++rows->block == ROWS_BLOCKS) {
             // the ring wraps: the oldest block's upload must have been consumed before it is overwritten
@@ -873,9 +875,33 @@ struct Prover {
         Fr* poly;
         Fr* coset;
     };
+    // The transforms of a LONE proof run on the context's transform stream, beside the MSM passes instead of between them (ctx.h
+    // xform_stream): they wait for the last flush of blinding rows — every transformed column has such rows, written after the
+    // kernels that made it — and the quotient waits for them (xform_join).
+    // Auto: a lone context and columns of 2^18 rows or more (measured, tools/single_ab.py OPTS=8=1 / 8=2, same box: k = 19 12.10 ->
+    // 11.47 ms, EVM 13.66 -> 13.03; k = 17 6.55 -> 6.67: there the transforms are too short to pay for the cross-stream events)
+    bool xform_side() const {
+        return !batch_member && (c->opt_xform_stream == 1 || (c->opt_xform_stream == 0 && lay.k >= 18 && ctx_activity_touch(c) <= 1));
+    }
+    void xform_join() {
+        if (!c->xform_pending) return;
+        c->xform_pending = false;
+        if (hipStreamWaitEvent(st, c->ev_xform, 0) != hipSuccess) fail(ZK_EHIP);
+    }
     void transforms(const std::vector<Forms>& cols) {
         rows_flush();
         if (!ok() || cols.empty()) return;
+        const bool side = xform_side();
+        const hipStream_t xs = side ? c->xform_stream : st;
+        if (side && hipStreamWaitEvent(xs, c->ev_rows, 0) != hipSuccess) return fail(ZK_EHIP);
+        if (!side) xform_join();  // (the two streams share the NTT's ping-pong scratch)
+        transforms_on(cols, xs);
+        if (side) {
+            if (hipEventRecord(c->ev_xform, xs) != hipSuccess) return fail(ZK_EHIP);
+            c->xform_pending = true;
+        }
+    }
+    void transforms_on(const std::vector<Forms>& cols, hipStream_t xs) {
         const uint32_t b1 = ctx_ntt_max_batch(lay.k), b2 = ctx_ntt_max_batch(lay.ext_k);
         const Fr* src[NTT_MAX_BATCH];
         Fr* dst[NTT_MAX_BATCH];
@@ -885,7 +911,7 @@ struct Prover {
                 src[q] = cols[i0 + q].val;
                 dst[q] = cols[i0 + q].poly;
             }
-            int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.k, true, false, n);
+            int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.k, true, false, n, xs);
             if (r) fail(r);
         }
         for (size_t i0 = 0; i0 < cols.size() && ok(); i0 += b2) {
@@ -894,7 +920,7 @@ struct Prover {
                 src[q] = cols[i0 + q].poly;
                 dst[q] = cols[i0 + q].coset;
             }
-            int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.ext_k, false, true, N);
+            int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.ext_k, false, true, N, xs);
             if (r) fail(r);
         }
     }
@@ -962,6 +988,8 @@ struct Prover {
             qc.lk_s.push_back(pk->lk_sp_coset[l]);
             qc.lk_z.push_back(pk->lk_z_coset[l]);
         }
+        xform_join();  // every coset form is complete
+        if (!ok()) return rc;
         int r = pk_quotient(c, pk, qc, beta, gamma, y, true, pk->h_ext);
         if (r) return r;
         return ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
@@ -1087,8 +1115,13 @@ struct Prover {
         // commitment's head: they need no challenge, and they keep the main stream busy while the MSM tails
         // (and the host's transcript work) would otherwise leave it idle.
         const uint32_t max_batch = ctx_msm_max_batch(c);
+        bool adv_transformed = false;
         if (pipe) {
             commit_begin(0, pk->adv_val[0], n, ZK_BASIS_LAGRANGE);
+            if (xform_side()) {  // a lone proof: the advice column's forms are made under its own MSM pass
+                transforms({Forms{pk->adv_val[0], pk->adv_poly[0], pk->adv_coset[0]}});
+                adv_transformed = true;
+            }
         } else {
             // several advice columns: whole batches of columns per MSM pass, up to MSM_LANES passes in flight,
             // each followed by its columns' transforms; collected in column order
@@ -1160,7 +1193,7 @@ struct Prover {
             if (lb.pend.empty()) lookup_transforms(false);
         }
         batch_flush(lb);
-        lookup_transforms(pipe);
+        lookup_transforms(pipe && !adv_transformed);
         {
             // one check for all lookups (the flag accumulates): an input outside the table is halo2's
             // ConstraintSystemFailure; nothing has been written for the lookups yet
@@ -1673,6 +1706,10 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     Prover p(c, pk, rng_seed, tr);
     rc = p.run(adv.data(), scheme);
     ctx_msm_drain(c);  // an early error may leave commitments in flight
+    if (c->xform_pending) {  // (an early error before the quotient: transforms still in flight)
+        hipStreamSynchronize(c->xform_stream);
+        c->xform_pending = false;
+    }
     hipStreamSynchronize(c->stream);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;

@@ -27,7 +27,10 @@ struct BatchRun {
     BatchRun(zk_ctx* c_, zk_pk_rec* pk_, std::vector<Prover*>& provers, uint32_t cap)
         : c(c_), pk0(pk_), lay(pk_->lay), st(c_->stream), n(pk_->lay.n), N(4 * pk_->lay.n), B((uint32_t)provers.size()), P(provers),
           bb(*pk_->bb), pass_cap(cap) {
-        for (Prover* p : P) p->rows = &P[0]->own_rows;  // one row stager for all proofs: one upload + one launch per phase
+        for (Prover* p : P) {
+            p->rows = &P[0]->own_rows;  // one row stager for all proofs: one upload + one launch per phase
+            p->batch_member = true;
+        }
     }
 
     bool ok() {
