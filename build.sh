@@ -23,3 +23,7 @@ echo "built $(pwd)/$OUT"
 cd ..
 g++ -O2 -std=c++17 -Wall -Iinclude examples/prove_host.cpp -Lwebauthn-halo2_amd -lzkmi355 -Wl,-rpath,'$ORIGIN/../webauthn-halo2_amd' -o examples/prove_host
 echo "built $(pwd)/examples/prove_host"
+# the phase-level host (examples/prove_host_phases.cpp): its host-side field / transcript code comes from the engine's host headers,
+# which carry HIP's function attributes — hence hipcc; it links against the same library through the public ABI only
+hipcc --offload-arch=gfx950 -O2 -std=c++17 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -x hip examples/prove_host_phases.cpp -Lwebauthn-halo2_amd -lzkmi355 -Wl,-rpath,'$ORIGIN/../webauthn-halo2_amd' -o examples/prove_host_phases
+echo "built $(pwd)/examples/prove_host_phases"

@@ -165,6 +165,15 @@ int zk_poly_len(zk_ctx* ctx, zk_poly p, size_t* out);
 int zk_poly_upload(zk_ctx* ctx, zk_poly p, const uint64_t* host_mont, size_t n);
 int zk_poly_download(zk_ctx* ctx, zk_poly p, uint64_t* host_mont, size_t n);
 int zk_poly_copy(zk_ctx* ctx, zk_poly dst, zk_poly src);
+/* rows [first, first + count) from the host: the blinding rows a host appends to a column the device made (halo2's provers push
+ * `blinding_factors` random rows onto a', s' and every z before committing), without shipping the column */
+int zk_poly_upload_range(zk_ctx* ctx, zk_poly p, size_t first, const uint64_t* host_mont, size_t count);
+/* dst[dst_first ..] = src[src_first .. src_first + count) (the h pieces: n-coefficient slices of the quotient) */
+int zk_poly_copy_range(zk_ctx* ctx, zk_poly dst, size_t dst_first, zk_poly src, size_t src_first, size_t count);
+/* out = sum_j coeffs[j] * in[j], minus *sub0 (may be NULL) on coefficient 0; all vectors of one length, out none of the inputs:
+ * the linear combinations of the multi-open provers (sum_i v^i (p_i(X) - e_i)) and of h(X) = sum_i x^(n i) h_i(X) */
+int zk_poly_lincomb(zk_ctx* ctx, zk_poly out, const zk_poly* in, const uint64_t* coeffs_mont /* count x 4 */, size_t count,
+                    const uint64_t sub0_mont[4]);
 
 /* replaces ParamsKZG::commit / commit_lagrange (MSM against the resident SRS) + to_affine */
 int zk_commit(zk_ctx* ctx, zk_poly p, int basis, uint64_t out_affine_mont[8]);
@@ -252,6 +261,34 @@ int zk_pk_shape(zk_ctx* ctx, zk_pk pk, uint32_t out[8]);
 int zk_quotient(zk_ctx* ctx, zk_pk pk, const zk_poly* advice_ext, size_t n_advice, const zk_poly* perm_z_ext, size_t n_chunks,
                 const zk_poly* lookup_ext, size_t n_lookups, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4],
                 int divide, zk_poly out_ext);
+/* ---- the provers between the commitments, for a host that drives the phases itself (its transcript, its RNG, its blinding:
+ * examples/prove_host_phases.cpp builds a whole proof from these and the calls above) ------------------------------------------
+ * replaces plonk::lookup::prover's `permute_expression_pair` for every lookup of the key (halo2_proofs
+ * plonk/lookup/prover.rs, reached from create_proof, ecdsa_p256.rs:366-373): from the advice columns (Lagrange values) the
+ * permuted input a' and permuted table s' of each lookup, rows 0 .. n - 8 (the usable rows; the host writes the 7 rows behind
+ * them — its blinding — with zk_poly_upload_range).  ZK_EWITNESS: an input is not in the table. */
+int zk_lookup_permute(zk_ctx* ctx, zk_pk pk, const zk_poly* advice, size_t n_advice, zk_poly* permuted_input /* out, n_lookups */,
+                      zk_poly* permuted_table /* out, n_lookups */, size_t n_lookups);
+/* replaces lookup::prover `commit_product`: the grand product zL of every lookup (rows 0 .. n - 7; the host blinds the last 6) */
+int zk_lookup_product(zk_ctx* ctx, zk_pk pk, const zk_poly* advice, size_t n_advice, const zk_poly* permuted_input,
+                      const zk_poly* permuted_table, size_t n_lookups, const uint64_t beta[4], const uint64_t gamma[4],
+                      zk_poly* z_out /* n_lookups */);
+/* replaces plonk::permutation::prover `commit`: the grand products z of the permutation argument, one per chunk of columns
+ * (zk_pk_shape), chunk c starting from chunk c - 1's value at the last usable row (rows 0 .. n - 7; the host blinds the rest) */
+int zk_permutation_product(zk_ctx* ctx, zk_pk pk, const zk_poly* advice, size_t n_advice, const uint64_t beta[4],
+                           const uint64_t gamma[4], zk_poly* z_out /* n_chunks */, size_t n_chunks);
+/* a copy of one of the key's own polynomials (coefficient form, n coefficients) into the caller's vector: the fixed columns
+ * (index in QUERY order: constants, lookup table, selector columns — the order of the fixed evaluations in a proof) and the
+ * permutation polynomials sigma (permutation-column order) that create_proof evaluates at x and opens (`pk.fixed_polys`,
+ * `pk.permutation.polys` of halo2's ProvingKey) */
+#define ZK_PK_FIXED_POLY 0
+#define ZK_PK_SIGMA_POLY 1
+int zk_pk_export_poly(zk_ctx* ctx, zk_pk pk, int which, size_t index, zk_poly dst);
+/* replaces the n `Fr::random(&mut rng)` draws of plonk::vanishing::prover `commit` (the random polynomial): coefficient i =
+ * the Fr::random of ChaCha20 block first_block + i under `chacha_key` — what rand_chacha's ChaCha20Rng::from_seed(key) yields
+ * for its draws first_block .. first_block + n - 1 when every draw is an Fr::random (as in create_proof).  The RNG stays the
+ * host's: it hands over key and position and skips n draws; a host with another RNG uploads the column. */
+int zk_random_poly(zk_ctx* ctx, const uint8_t chacha_key[32], uint64_t first_block, zk_poly out);
 /* bytes zk_prove will write for this key / transcript / scheme (what `transcript.finalize().len()` is in
  * the reference, e.g. 960 at k=19 Blake2b, halo2-circuits/src/results/ecdsa_bench.csv:2) */
 int zk_proof_size(zk_ctx* ctx, zk_pk pk, int transcript, int scheme, size_t* out);

@@ -1035,6 +1035,36 @@ ZK_API(zk_poly_download, (zk_ctx* c, zk_poly h, uint64_t* host, size_t n), (c, h
     return ZK_OK;
 }
 
+// rows [first, first + count) of a resident vector from the host (Montgomery images): the blinding rows a host appends to a
+// column the device made (a', s', z), without shipping the column
+ZK_API(zk_poly_upload_range, (zk_ctx* c, zk_poly h, size_t first, const uint64_t* host, size_t count), (c, h, first, host, count)) {
+    if (!c || (!host && count)) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec* r = find_poly(c, h);
+    if (!r || first > r->n || count > r->n - first) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    if (count == 0) return ZK_OK;
+    HIPCHK(c, hipMemcpyAsync(r->ptr + first, host, count * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+// dst[dst_first ..] = src[src_first .. src_first + count): e.g. the h pieces, n-coefficient slices of the quotient
+ZK_API(zk_poly_copy_range, (zk_ctx* c, zk_poly dst, size_t dst_first, zk_poly src, size_t src_first, size_t count), (c, dst, dst_first, src, src_first, count)) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PolyRec *d = find_poly(c, dst), *s = find_poly(c, src);
+    if (!d || !s || dst_first > d->n || count > d->n - dst_first || src_first > s->n || count > s->n - src_first) return ZK_EINVAL;
+    if (d == s && !(dst_first + count <= src_first || src_first + count <= dst_first)) return ZK_EINVAL;  // overlapping ranges
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    if (count == 0) return ZK_OK;
+    HIPCHK(c, hipMemcpyAsync(d->ptr + dst_first, s->ptr + src_first, count * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
 ZK_API(zk_poly_copy, (zk_ctx* c, zk_poly dst, zk_poly src), (c, dst, src)) {
     if (!c) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);

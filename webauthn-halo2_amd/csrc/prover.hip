@@ -1719,6 +1719,286 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     return ZK_OK;
 }
 
+// ===================================================== phase-level entry points ==
+// For a host that keeps halo2's own prover flow — its transcript, its RNG, its blinding — and off-loads phase by phase
+// (examples/prove_host_phases.cpp): the provers of plonk/lookup, plonk/permutation and plonk/vanishing that
+// sit between the commitments, over resident columns.  They run the very kernels zk_prove runs; each call is complete on return.
+namespace {
+struct PhaseCtx {
+    zk_ctx* c;
+    zk_pk_rec* pk;
+    std::vector<Fr*> adv;
+};
+// resolves the key and the advice handles (n rows each, Lagrange values, Montgomery)
+int phase_open(zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, PhaseCtx& out) {
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    zk_pk_rec* pk = it->second;
+    if (pk->srs_gen != c->srs_gen) return ZK_ESTATE;
+    if (n_advice != pk->lay.n_adv) return ZK_EINVAL;
+    out.c = c;
+    out.pk = pk;
+    for (size_t j = 0; j < n_advice; j++) {
+        auto pit = c->polys.find(advice[j]);
+        if (pit == c->polys.end() || pit->second.n != pk->lay.n) return ZK_EINVAL;
+        out.adv.push_back(pit->second.ptr);
+    }
+    return ctx_bind(c);
+}
+Fr* phase_vec(zk_ctx* c, zk_poly h, size_t n) {
+    auto it = c->polys.find(h);
+    return (it == c->polys.end() || it->second.n != n) ? nullptr : it->second.ptr;
+}
+// the compressed input expression of lookup l: the lookup advice column, or q_lookup * a for the one-column shape (into pk->lk_in)
+const Fr* phase_lookup_input(PhaseCtx& P, uint32_t l) {
+    const Layout& lay = P.pk->lay;
+    if (!lay.single) return P.adv[lay.n_gate + l];
+    launch_mul(P.pk->lk_in[l], P.pk->fixed_val[lay.fx_qlookup], P.adv[0], lay.n, P.c->stream);
+    return P.pk->lk_in[l];
+}
+// grand products z[p] of `items` (num / den already launched), halo2's semantics: one scan, one host round trip; a zero
+// denominator takes the batch_invert form.  chain[p]: product p starts from product p - 1's value at row `usable`.
+int phase_grand_products(zk_ctx* c, zk_pk_rec* pk, const std::vector<Fr*>& num, const std::vector<Fr*>& den, const std::vector<Fr*>& z,
+                         const std::vector<uint32_t>& chain) {
+    const Layout& lay = pk->lay;
+    const uint32_t n = lay.n, nprod = (uint32_t)z.size(), nblk = gp_blocks(n), usable = lay.usable;
+    hipStream_t st = c->stream;
+    std::vector<GpItem> items(nprod);
+    for (uint32_t p = 0; p < nprod; p++) {
+        items[p].num = num[p];
+        items[p].den = den[p];
+        items[p].loc_p = pk->gp_loc_p[p];
+        items[p].loc_r = pk->gp_loc_r[p];
+        items[p].tot_p = pk->gp_tot + (size_t)2 * nblk * p;
+        items[p].tot_r = items[p].tot_p + nblk;
+        items[p].z = z[p];
+        items[p].chain = chain[p];
+        items[p].pad_ = 0;
+    }
+    Fr *q_dev = pk->gp_scal, *qinv_dev = pk->gp_scal + nprod, *k_dev = pk->gp_scal + 2 * (size_t)nprod, *init_dev = pk->gp_scal + 3 * (size_t)nprod;
+    bool fast = !c->opt_gp_batch_invert;
+    if (fast) {
+        HIPCHK(c, hipMemcpyAsync(pk->d_gp_items, items.data(), nprod * sizeof(GpItem), hipMemcpyHostToDevice, st));
+        launch_gp_batch_scan(pk->d_gp_items, nprod, n, q_dev, st);
+        HIPCHK(c, hipMemcpyAsync(pk->gp_host, q_dev, nprod * sizeof(Fr), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        Fr *q = pk->gp_host, *qi = pk->gp_host + nprod;
+        Fr run = Fr::one();
+        for (uint32_t p = 0; p < nprod && fast; p++) {
+            if (q[p].is_zero()) fast = false;
+            qi[p] = run;
+            run = fe_mul(run, q[p]);
+        }
+        if (fast) {
+            Fr inv = fe_inv(run);
+            for (uint32_t p = nprod; p-- > 0;) {
+                const Fr t = fe_mul(inv, qi[p]);
+                inv = fe_mul(inv, q[p]);
+                qi[p] = t;
+            }
+            HIPCHK(c, hipMemcpyAsync(qinv_dev, qi, nprod * sizeof(Fr), hipMemcpyHostToDevice, st));
+            launch_gp_batch_apply(pk->d_gp_items, nprod, n, usable, qinv_dev, k_dev, init_dev, st);
+        }
+    }
+    if (!fast) {
+        for (uint32_t p = 0; p < nprod; p++) {
+            launch_frac(num[p], den[p], pk->t_frac, n, st);
+            const Fr* prev = chain[p] ? z[p - 1] + usable : nullptr;
+            launch_prefix_product(pk->t_frac, z[p], n, prev, Fr::one(), pk->t_a, pk->t_small, st);
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return hipGetLastError() == hipSuccess ? ZK_OK : ZK_EHIP;
+}
+}  // namespace
+
+ZK_API(zk_lookup_permute, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, zk_poly* permuted_input, zk_poly* permuted_table, size_t n_lookups), (c, h, advice, n_advice, permuted_input, permuted_table, n_lookups)) {
+    if (!c || !advice || !permuted_input || !permuted_table) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PhaseCtx P;
+    int rc = phase_open(c, h, advice, n_advice, P);
+    if (rc) return rc;
+    const Layout& lay = P.pk->lay;
+    if (n_lookups != lay.n_lookups) return ZK_EINVAL;
+    LkPtrs lp;
+    memset(&lp, 0, sizeof(lp));
+    for (uint32_t l = 0; l < lay.n_lookups; l++) {
+        Fr *a = phase_vec(c, permuted_input[l], lay.n), *s = phase_vec(c, permuted_table[l], lay.n);
+        if (!a || !s || a == s) return ZK_EINVAL;
+        for (const Fr* v : P.adv)
+            if (v == a || v == s) return ZK_EINVAL;
+        lp.ap[l] = a;
+        lp.sp[l] = s;
+    }
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemsetAsync(P.pk->lks.err, 0, 4, st));
+    for (uint32_t l = 0; l < lay.n_lookups; l++) lp.inp[l] = phase_lookup_input(P, l);
+    launch_lookup_permute(lp, lay.n_lookups, lay.usable, 1u << lay.lookup_bits, P.pk->lks, st);
+    uint32_t* err = reinterpret_cast<uint32_t*>(c->host_small);
+    HIPCHK(c, hipMemcpyAsync(err, P.pk->lks.err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return *err ? ZK_EWITNESS : ZK_OK;
+}
+
+ZK_API(zk_lookup_product, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, const zk_poly* permuted_input, const zk_poly* permuted_table, size_t n_lookups, const uint64_t beta[4], const uint64_t gamma[4], zk_poly* z_out), (c, h, advice, n_advice, permuted_input, permuted_table, n_lookups, beta, gamma, z_out)) {
+    if (!c || !advice || !permuted_input || !permuted_table || !beta || !gamma || !z_out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PhaseCtx P;
+    int rc = phase_open(c, h, advice, n_advice, P);
+    if (rc) return rc;
+    zk_pk_rec* pk = P.pk;
+    const Layout& lay = pk->lay;
+    if (n_lookups != lay.n_lookups) return ZK_EINVAL;
+    Fr b, g;
+    memcpy(&b, beta, 32);
+    memcpy(&g, gamma, 32);
+    std::vector<Fr*> num, den, z;
+    std::vector<uint32_t> chain;
+    for (uint32_t l = 0; l < lay.n_lookups; l++) {
+        const Fr *a = phase_vec(c, permuted_input[l], lay.n), *s = phase_vec(c, permuted_table[l], lay.n);
+        Fr* zl = phase_vec(c, z_out[l], lay.n);
+        if (!a || !s || !zl || zl == a || zl == s) return ZK_EINVAL;
+        for (const Fr* v : P.adv)
+            if (v == zl) return ZK_EINVAL;
+        const Fr* inp = phase_lookup_input(P, l);
+        launch_lk_numden(a, s, inp, pk->fixed_val[lay.fx_table], b, g, pk->gp_num[l], pk->gp_den[l], lay.n, c->stream);
+        num.push_back(pk->gp_num[l]);
+        den.push_back(pk->gp_den[l]);
+        z.push_back(zl);
+        chain.push_back(0);
+    }
+    return phase_grand_products(c, pk, num, den, z, chain);
+}
+
+ZK_API(zk_permutation_product, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, const uint64_t beta[4], const uint64_t gamma[4], zk_poly* z_out, size_t n_chunks), (c, h, advice, n_advice, beta, gamma, z_out, n_chunks)) {
+    if (!c || !advice || !beta || !gamma || !z_out) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PhaseCtx P;
+    int rc = phase_open(c, h, advice, n_advice, P);
+    if (rc) return rc;
+    zk_pk_rec* pk = P.pk;
+    const Layout& lay = pk->lay;
+    if (n_chunks != lay.n_chunks) return ZK_EINVAL;
+    Fr b, g;
+    memcpy(&b, beta, 32);
+    memcpy(&g, gamma, 32);
+    const Fr* tw = nullptr;
+    if ((rc = ctx_get_twiddles(c, lay.k, &tw))) return rc;
+    std::vector<Fr*> num, den, z;
+    std::vector<uint32_t> chain;
+    const Fr delta = fr_delta();
+    Fr dcur = Fr::one();
+    for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+        Fr* zc = phase_vec(c, z_out[ci], lay.n);
+        if (!zc) return ZK_EINVAL;
+        for (const Fr* v : P.adv)
+            if (v == zc) return ZK_EINVAL;
+        PermArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = lay.n;
+        const uint32_t lo = ci * lay.chunk_len, hi = std::min<uint32_t>((uint32_t)lay.perm_cols.size(), lo + lay.chunk_len);
+        a.ncols = hi - lo;
+        for (uint32_t p = lo; p < hi; p++) {
+            const Col& col = lay.perm_cols[p];
+            a.values[p - lo] = col.fixed ? pk->fixed_val[col.idx] : P.adv[col.idx];
+            a.sigma[p - lo] = pk->sigma_val[p];
+            a.delta[p - lo] = dcur;
+            dcur = fe_mul(dcur, delta);
+        }
+        a.tw = tw;
+        a.beta = b;
+        a.gamma = g;
+        a.num = pk->gp_num[ci];
+        a.den = pk->gp_den[ci];
+        launch_perm_numden(a, c->stream);
+        num.push_back(pk->gp_num[ci]);
+        den.push_back(pk->gp_den[ci]);
+        z.push_back(zc);
+        chain.push_back(ci > 0 ? 1u : 0u);
+    }
+    return phase_grand_products(c, pk, num, den, z, chain);
+}
+
+// a copy of one of the key's own polynomials (coefficient form) in a caller's vector: what a phase-driving host evaluates and
+// opens beside its own columns (the fixed and permutation polynomials of the ProvingKey)
+ZK_API(zk_pk_export_poly, (zk_ctx* c, zk_pk h, int which, size_t index, zk_poly dst), (c, h, which, index, dst)) {
+    if (!c) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->pks.find(h);
+    if (it == c->pks.end()) return ZK_EINVAL;
+    zk_pk_rec* pk = it->second;
+    if (pk->srs_gen != c->srs_gen) return ZK_ESTATE;
+    const std::vector<Fr*>* v = which == ZK_PK_FIXED_POLY ? &pk->fixed_poly : which == ZK_PK_SIGMA_POLY ? &pk->sigma_poly : nullptr;
+    if (!v || index >= v->size()) return ZK_EINVAL;
+    Fr* d = phase_vec(c, dst, pk->lay.n);
+    if (!d) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(d, (*v)[index], (size_t)pk->lay.n * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+// the vanishing argument's random polynomial: coefficient i = Fr::random of ChaCha20 block first_block + i under `key` — the
+// stream `ChaCha20Rng::from_seed(key)` yields when every draw is an Fr::random (one 64-byte block each), i.e. what the host's
+// RNG would give for draws first_block .. first_block + n - 1; the host then advances its own RNG by n draws
+ZK_API(zk_random_poly, (zk_ctx* c, const uint8_t chacha_key[32], uint64_t first_block, zk_poly out), (c, chacha_key, first_block, out)) {
+    if (!c || !chacha_key) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->polys.find(out);
+    if (it == c->polys.end() || it->second.n == 0 || it->second.n > ((size_t)1 << 28)) return ZK_EINVAL;
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    ChaChaKey key;
+    memcpy(key.w, chacha_key, 32);
+    launch_chacha_fr(key, first_block, it->second.ptr, (uint32_t)it->second.n, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+// out = sum_j coeffs[j] * in[j] (- *sub0 on coefficient 0): the multi-open provers' linear combinations and h(X) = sum x^(n i) h_i
+ZK_API(zk_poly_lincomb, (zk_ctx* c, zk_poly out, const zk_poly* in, const uint64_t* coeffs, size_t count, const uint64_t* sub0), (c, out, in, coeffs, count, sub0)) {
+    if (!c || !in || !coeffs || count == 0) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto oit = c->polys.find(out);
+    if (oit == c->polys.end() || oit->second.n > 0xffffffffu) return ZK_EINVAL;
+    const size_t n = oit->second.n;
+    std::vector<const Fr*> src(count);
+    for (size_t j = 0; j < count; j++) {
+        auto it = c->polys.find(in[j]);
+        if (it == c->polys.end() || it->second.n != n || it->second.ptr == oit->second.ptr) return ZK_EINVAL;
+        src[j] = it->second.ptr;
+    }
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    size_t done = 0;
+    bool first = true;
+    do {
+        LincombArgs a;
+        memset(&a, 0, sizeof(a));
+        a.out = oit->second.ptr;
+        a.n = (uint32_t)n;
+        const size_t take = std::min<size_t>(MAX_LC, count - done);
+        a.count = (uint32_t)take;
+        a.accumulate = first ? 0 : 1;
+        for (size_t j = 0; j < take; j++) {
+            a.in[j] = src[done + j];
+            a.len[j] = (uint32_t)n;
+            memcpy(&a.c[j], coeffs + 4 * (done + j), 32);
+            a.unit[j] = a.c[j] == Fr::one();
+        }
+        done += take;
+        if (done == count && sub0) {
+            a.sub0 = 1;
+            memcpy(&a.sub0_val, sub0, 32);
+        }
+        launch_lincomb(a, c->stream);
+        first = false;
+    } while (done < count);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
 // create_proof for `batch` independent proofs of one key in lock-step (prover_batch.h)
 ZK_API(zk_prove_batch, (zk_ctx* c, zk_pk h, size_t batch, const zk_poly* advice, size_t n_advice, const uint8_t* rng_seeds, int transcript, int scheme, uint8_t* proofs_out, size_t proof_stride, size_t* proof_len), (c, h, batch, advice, n_advice, rng_seeds, transcript, scheme, proofs_out, proof_stride, proof_len)) {
     if (!c || !advice || !rng_seeds || !proof_len || batch == 0 || batch > ZK_PROVE_BATCH_MAX) return ZK_EINVAL;
