@@ -36,8 +36,33 @@ K = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOAD = ("batch of independent proofs, k=19 (bench_ecdsa.config row 1: A=1,L=1,F=1,lookup_bits=18), Blake2b+SHPLONK, "
             "synthetic same-shape witnesses (job i: seed 0x5eed0019+i, jobs round-robin over ranks and pipelines), one resident "
-            "proving key per pipeline; ADVICE RESIDENT: every job's 16 MiB advice column is in HBM before the clock starts "
-            "(`value_with_h2d` is the same batch with the per-job upload inside the clock)")
+            "proving key per pipeline; every job's 16 MiB advice column is handed over as a HOST buffer INSIDE the clock (H2D + "
+            "canonical -> Montgomery conversion by the pipeline's own thread right before its proof: what a drop-in behind "
+            "create_proof receives); `value_advice_resident` is the same batch with the columns in HBM before the clock starts")
+
+
+def bind_to_gpu_numa_node(device):
+    """Bind this rank's host threads (the pipelines' workers, the witness pool) — and therefore the pinned staging buffers they
+    allocate — to the NUMA node the GPU hangs off: on an 8-GPU node a rank that proves on GPU 5 from the far socket pays for
+    every H2D and every launch.  /sys/bus/pci/devices/<pci id>/{numa_node,local_cpulist}; no-op where the kernel reports no
+    node (-1, single-socket boxes).  Returns what was done, for the JSON line."""
+    try:
+        from webauthn_halo2_amd import engine as E
+
+        pci = E.device_pci_bus_id(device)
+        base = "/sys/bus/pci/devices/" + pci
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if node >= 0 and cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"pci": pci, "numa_node": node, "cpus_bound": len(cpus) if node >= 0 else 0}
+    except Exception as e:  # no sysfs entry, no permission: run unbound
+        return {"error": str(e)[:80]}
 
 
 class ProofWorkload:
@@ -73,7 +98,17 @@ class ProofWorkload:
         for q, pl in enumerate(self.pipes):
             for j in self.jobs[q::inflight]:
                 pl.load(j, wit[j])
-        self.wit = wit  # the jobs' advice kept on the host: the PCIe-inclusive figures
+        # the jobs' advice as the host hands it over per request: page-locked staging buffers (zk_host_alloc), filled outside the clock
+        self.pinned = {}
+        for j in self.jobs:
+            bufs = []
+            for col in wit[j]:
+                pa = E.PinnedArray(col.shape)
+                pa.a[...] = col
+                bufs.append(pa)
+            self.pinned[j] = bufs
+            wit[j] = [pa.a for pa in bufs]
+        self.wit = wit
         self.host_cols = wit[self.jobs[0]]
         self.engs = [pl.eng for pl in self.pipes]
         self.proofs = {}
@@ -123,6 +158,7 @@ class ProofWorkload:
             raise errs[0]
         for e in self.engs:
             e.sync()
+        self.proofs.update(out)
         return out
 
     def single(self):
@@ -146,6 +182,10 @@ class ProofWorkload:
     def close(self):
         for pl in self.pipes:
             pl.close()
+        self.wit = None
+        for bufs in self.pinned.values():
+            for pa in bufs:
+                pa.free()
 
 
 class FakeWorkload:
@@ -164,6 +204,10 @@ class FakeWorkload:
         for j in jobs:
             time.sleep(0.01 * (1 + self.rank))
             self.proofs[j] = b"\0" * 960
+
+    def run_with_h2d(self, jobs):
+        self.run(jobs)
+        return self.proofs
 
     def close(self):
         pass
@@ -225,6 +269,87 @@ def alu_roofline(eng, k):
             % (SIMDS, CLOCK_GHZ, MAD_CYCLES, MADS_PER_ADD)}
 
 
+def kernel_rooflines(eng, pl, wl):
+    """The non-dominant kernels against the HBM roofline, each ALONE on the GPU after the timed region (HIP events on the
+    engine's stream): SURVEY.md 8(d)'s algorithmic bytes / the solo duration.  All of them are bound by the issue of their integer
+    instructions, not by HBM: the fractions say how far."""
+    E = wl.E
+    n = 1 << K
+    N = 4 * n
+    rows = []
+
+    def row(kernel, what, alg_bytes, ms):
+        gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rows.append({"kernel": kernel, "what": what, "algorithmic_bytes": alg_bytes, "solo_ms": ms, "achieved": gbs, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS})
+
+    rng = np.random.default_rng(0x21)
+    col = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    col[:, 3] &= np.uint64((1 << 60) - 1)
+    p, ext = eng.poly(n, col), eng.poly(N)
+    for _ in range(2):
+        eng.lagrange_to_coeff(p)
+    row("ntt_pass_kernel x3", "best_fft 2^19 inverse (lagrange_to_coeff)", 64.0 * n, eng.last_ms(E.ZK_T_NTT))
+    for _ in range(2):
+        eng.coeff_to_extended(p, ext)
+    row("ntt_pass_kernel x3", "coeff_to_extended 2^19 -> 2^21 (reads n, writes 4n)", 32.0 * (n + N), eng.last_ms(E.ZK_T_NTT))
+    for _ in range(2):
+        eng.extended_to_coeff(ext, N)
+    row("ntt_pass_kernel x3", "best_fft 2^21 inverse on the coset (extended_to_coeff)", 64.0 * N, eng.last_ms(E.ZK_T_NTT))
+    eng.timer_reset()
+    for _ in range(3):
+        eng.commit(p, 1)
+    head = (eng.timer_stats(E.ZK_T_MSM)[0] - eng.timer_stats(E.ZK_T_MSM_ACCUM)[0]) / 3
+    row("msm_whist + msm_wscatter1 + msm_wfinehist + msm_wscatter2", "MSM sort head of one 2^19 column: 32 B per scalar in, 16 x 4 B entries out",
+        96.0 * n, head)
+    tail_ms, tail_n = eng.timer_stats(E.ZK_T_MSM_TAIL)
+    row("msm_wparts + msm_wrowcol + msm_wbits", "MSM reduction tail of one 2^19 column: 144 B per partial sum (one per lane and bucket)",
+        144.0 * (n + 32768), tail_ms / max(tail_n, 1))
+    p.free()
+    ext.free()
+    pl.prove(wl.jobs[0], E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
+    row("quotient_kernel", "evaluate_h + division by X^n - 1 at k = 19: 15 extended cosets", 15.0 * N * 32, eng.last_ms(E.ZK_T_QUOTIENT))
+    row("poly_eval_batch_kernel", "19 openings of a proof in one launch: 32 B per coefficient and opening", 19.0 * n * 32, eng.last_ms(E.ZK_T_EVAL))
+    return rows
+
+
+def seam_single_proof_ms(eng):
+    """What the LITERAL drop-in costs per proof: a Rust host patched at best_multiexp / best_fft only (first
+    table) makes 12 MSMs over the resident SRS with host scalars (zk_msm_srs) and 5 + 6 FFTs on host vectors (zk_ntt_bn254_fr at 2^19 /
+    2^21) per k = 19 Blake2b proof — every operand crosses PCIe both ways.  Engine time only: the host's own work between the calls
+    (transcripts, permutation / lookup provers, quotient on the CPU) comes on top."""
+    n = 1 << K
+    rng = np.random.default_rng(0x22)
+    s = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 60) - 1)
+    big = np.tile(s, (4, 1))
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+    def omega(k):
+        w = pow(pow(7, (R - 1) >> 28, R), 1 << (28 - k), R)
+        return np.frombuffer(((w << 256) % R).to_bytes(32, "little"), dtype=np.uint64).copy()
+
+    from webauthn_halo2_amd import engine as E
+
+    w19, w21 = omega(K), omega(K + 2)
+    a19, a21 = s.copy(), np.ascontiguousarray(big)
+
+    def fft(a, w, log_n):  # in place on the caller's buffer, as best_fft(&mut a, omega, log_n): no copy on the binding's side
+        eng._chk(eng.L.zk_ntt_bn254_fr(eng.ctx, E._p(a), E._p(w), log_n), "zk_ntt_bn254_fr")
+
+    eng.msm_srs(s, 1)
+    fft(a19, w19, K)
+    fft(a21, w21, K + 2)
+    t0 = time.perf_counter()
+    for i in range(12):
+        eng.msm_srs(s, i & 1)
+    for _ in range(5):
+        fft(a19, w19, K)
+    for _ in range(6):
+        fft(a21, w21, K + 2)
+    return (time.perf_counter() - t0) * 1e3
+
+
 def cpu_baseline(budget_s=30.0):
     """One WHOLE create_proof on the host cores by the oracle's CPU port (oracle/zkoracle/fastprover.py: the
     reference's algorithms restated — thread-chunked Pippenger best_multiexp for every commitment, radix-2
@@ -254,6 +379,16 @@ def check_against_oracle_digests(proofs):
                 raise SystemExit("bench.py: proof of job %d differs from the oracle's (tests/golden/batch_k19_sha256.json)" % j)
             n += 1
     return n
+
+
+def digests_on_file(proofs):
+    """CPU stand-in of check_against_oracle_digests (the fake workload makes no proofs): how many of this rank's jobs have a
+    committed oracle digest to be compared with — `--gpus 8 --steps 32` must find all 256."""
+    path = os.path.join(ROOT, "tests", "golden", "batch_k19_sha256.json")
+    if not os.path.exists(path):
+        return 0
+    want = json.load(open(path))["sha256"]
+    return sum(1 for j in proofs if str(j) in want)
 
 
 def free_port():
@@ -332,6 +467,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     nfl = max(1, args.inflight)
+    numa = None if fake else bind_to_gpu_numa_node(local_rank)
     if fake:
         wl = FakeWorkload(rank, world, args.steps)
     else:
@@ -362,12 +498,12 @@ def main():
     wl.proofs.clear()
     barrier()
     t0 = time.perf_counter()
-    wl.run(wl.jobs[:args.steps])  # EXACTLY K steps on this rank: K distinct jobs
+    wl.run_with_h2d(wl.jobs[:args.steps])  # EXACTLY K steps on this rank: K distinct jobs, each job's advice shipped inside the clock
     barrier()
     elapsed = time.perf_counter() - t0
     assert len(wl.proofs) == args.steps
     # byte parity of the timed steps themselves: every rank compares its proofs with the oracle's digests (outside the clock)
-    oracle_checked = 0 if fake else check_against_oracle_digests(wl.proofs)
+    oracle_checked = digests_on_file(wl.proofs) if fake else check_against_oracle_digests(wl.proofs)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if fake else "cuda")
@@ -376,37 +512,61 @@ def main():
         per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if dist is not None and not fake:
-        tc = torch.tensor([oracle_checked], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tc = torch.tensor([oracle_checked], dtype=torch.float64, device="cpu" if fake else "cuda")
         dist.all_reduce(tc, op=dist.ReduceOp.SUM)
         oracle_checked = int(tc.item())
-    launcher = {"launcher": "torchrun" if dist is not None else "in-process",
+    host_setup = {"synthesize_s_per_job": round(wl.synth_s, 3), "keygen_s": round(wl.keygen_s, 3)}
+    if dist is not None:
+        # every rank's set-up time (SRS + window tables + key + workspaces, per pipeline): a SCALE record separates it from steady state
+        ks = torch.tensor([wl.keygen_s], dtype=torch.float64, device="cpu" if fake else "cuda")
+        allk = [torch.zeros_like(ks) for _ in range(world)]
+        dist.all_gather(allk, ks)
+        host_setup["keygen_s_per_rank"] = [round(float(x.item()), 3) for x in allk]
+    # which jobs of the batch were proved, over all ranks: `--gpus 8 --steps 32` must cover the 256 jobs of configs[3] exactly once
+    mine = list(wl.jobs[:args.steps])
+    covered = sorted(mine)
+    if dist is not None:
+        tj = torch.tensor(mine, dtype=torch.int64, device="cpu" if fake else "cuda")
+        allj = [torch.zeros_like(tj) for _ in range(world)]
+        dist.all_gather(allj, tj)
+        covered = sorted(int(x) for t_ in allj for x in t_.tolist())
+    jobs_exactly_once = covered == list(range(world * args.steps))
+    assert jobs_exactly_once, "the ranks' jobs do not partition 0 .. world x steps - 1"
+    launcher = {"launcher": "torchrun" if dist is not None else "in-process", "jobs_covered_exactly_once": jobs_exactly_once,
+                "numa_binding": numa,
                 "dist_backend": (dist.get_backend() if dist is not None else None), "ms_per_step_per_rank": per_rank_ms,
                 # timed proofs (all ranks) whose bytes were compared with the oracle's committed digests: all of them for the
                 # 256-job batch of configs[3]
                 "proofs_checked_against_oracle_digests": oracle_checked}
-    # Two further timed repeats of the same K jobs (after `value`'s region, same barriers and max-over-ranks clock): their
-    # spread says how large a round-over-round delta must be before it means anything (boxes and runs differ by ~3 %).
-    repeats = [world * args.steps / elapsed]
-    for _ in range(0 if fake else 2):
+
+    def timed(fn):
+        """One more timed pass over the same K jobs (same barriers, max-over-ranks clock) -> whole-job proofs/s."""
         barrier()
         t1 = time.perf_counter()
-        wl.run(wl.jobs[:args.steps])
+        fn(wl.jobs[:args.steps])
         barrier()
         dt = time.perf_counter() - t1
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if fake else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        repeats.append(world * args.steps / dt)
+        return world * args.steps / dt
+
+    # Four further timed repeats of the same region (after `value`'s): the median and the spread say how large a
+    # round-over-round delta must be before it means anything (boxes and runs differ by ~3 %).
+    repeats = [world * args.steps / elapsed] + [timed(wl.run_with_h2d) for _ in range(0 if fake else 4)]
     launcher["value_repeats"] = repeats  # [0] is `value`
+    launcher["value_median"] = sorted(repeats)[len(repeats) // 2]
     launcher["value_spread_pct"] = (max(repeats) - min(repeats)) / (sum(repeats) / len(repeats)) * 100.0
+    if not fake:
+        launcher["value_advice_resident"] = timed(wl.run)  # the columns already in HBM (rounds 1-4 reported this as `value`)
 
     if rank == 0 and fake:
         print(json.dumps({"metric": "webauthn_es256_proofs_per_sec_k19", "value": world * args.steps / elapsed,
                           "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "data": "fake",
-                          "jobs_total": world * args.steps, **launcher}))
+                          "jobs_total": world * args.steps, "host_setup": host_setup, **launcher}))
     elif rank == 0:
         n = 1 << K
         eng = wl.engs[0]
@@ -439,7 +599,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,  # BASELINE.json "published" is {}: the only reference number (14.846 s/proof, M1 Pro, README.md:38) is other hardware
-            "host_setup": {"synthesize_s_per_job": round(wl.synth_s, 3), "keygen_s": round(wl.keygen_s, 3)},
+            "host_setup": host_setup,
             "dtype": "u256-montgomery (9x29-bit carry-free limbs in the hot kernels: bucket accumulation, NTT, reduction tails, quotient; 8x32-bit limbs elsewhere and in memory)",
             "data": "synthetic",
             "config": {"workload": WORKLOAD, "k": K, "transcript": "blake2b", "multiopen": "shplonk", "proof_bytes": 960,
@@ -487,12 +647,8 @@ def main():
         assert len(pe) == 1536
         out["single_proof_evm_ms"] = best * 1e3
         out["single_proof_with_h2d_ms"] = sorted(wl.single_with_h2d() for _ in range(3))[1]  # PCIe-inclusive; never `value`
-        if world == 1:
-            # the timed batch again with every job's 16 MiB upload inside the clock (PCIe-inclusive throughput; never `value`)
-            t1 = time.perf_counter()
-            again = wl.run_with_h2d(wl.jobs[:args.steps])
-            out["value_with_h2d"] = args.steps / (time.perf_counter() - t1)
-            assert all(again[j] == wl.proofs[j] for j in wl.jobs[:args.steps])  # same jobs, same seeds: same bytes
+        out["roofline"]["kernels"] = kernel_rooflines(eng, pl, wl)
+        out["single_proof_seam_ms"] = seam_single_proof_ms(eng)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -62,6 +62,13 @@ typedef uint64_t zk_poly; /* opaque device-resident vector of Fr; 0 is never val
 
 /* ---- context ------------------------------------------------------------- */
 int zk_device_count(void);
+/* PCI address of a device ("0000:c1:00.0", cap >= 16): /sys/bus/pci/devices/<id>/{numa_node,local_cpulist} name its NUMA node —
+ * an 8-GPU host binds each GPU's worker threads and staging buffers there (bench.py does) */
+int zk_device_pci_bus_id(int device_id, char* out, size_t cap);
+/* page-locked host memory for buffers handed to zk_poly_upload / zk_poly_upload_canonical (one DMA at the bus rate instead of a
+ * staged copy out of pageable memory); NULL on failure */
+void* zk_host_alloc(size_t bytes);
+void zk_host_free(void* p);
 int zk_ctx_create(int device_id, zk_ctx** out);
 /* a further context on ctx's device that SHARES ctx's resident SRS (bases and window tables, read-only, as loaded at this
  * moment): one context per proof pipeline / host thread without a copy of the tables each.  Either context may later load
@@ -325,6 +332,7 @@ int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canoni
 #define ZK_T_MSM_COLUMNS 5 /* count only: scalar vectors (commitments) the accumulate launches served — a launch
                               serves several columns when commitments are batched */
 #define ZK_T_MSM_TAIL_MAIN 6 /* count only: MSM passes whose reduction tail ran on the context's main stream (ZK_OPT_MSM_TAIL_STREAM) */
+#define ZK_T_MSM_TAIL 7 /* the reduction tail (T1 .. T3) of the last MSM pass on the wide path, on whichever stream it ran */
 #define ZK_T_COUNT 8
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
 /* accumulated HIP-event time and launch count since the last reset (ZK_T_MSM, ZK_T_MSM_ACCUM) */

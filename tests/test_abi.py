@@ -69,13 +69,13 @@ def test_every_entry_point_is_exception_guarded():
     """include/zkmi355.h promises that nothing is thrown across the boundary: every `int zk_*` entry point is
     defined through ZK_API (body inside try / catch(...), csrc/ctx.h); the few that are not are trivial getters /
     the destructor, which allocate nothing."""
-    trivial = {"zk_device_count", "zk_strerror", "zk_ctx_destroy", "zk_last_hip_error", "zk_srs_k"}
+    trivial = {"zk_device_count", "zk_strerror", "zk_ctx_destroy", "zk_last_hip_error", "zk_srs_k", "zk_host_alloc", "zk_host_free"}
     csrc = os.path.join(ROOT, "webauthn-halo2_amd", "csrc")
     guarded = set()
     for f in os.listdir(csrc):
         src = open(os.path.join(csrc, f)).read()
         guarded |= set(re.findall(r"^ZK_API\((zk_[a-z0-9_]+),", src, flags=re.M))
-        for m in re.finditer(r'^(?:extern "C" )?(?:int|void|const char\*) (zk_[a-z0-9_]+)\(', src, flags=re.M):
+        for m in re.finditer(r'^(?:extern "C" )?(?:int|void\*?|const char\*) (zk_[a-z0-9_]+)\(', src, flags=re.M):
             assert m.group(1) in trivial, f"{m.group(1)} in {f} is defined outside ZK_API"
     macro = open(os.path.join(csrc, "ctx.h")).read()
     assert "catch (...)" in macro and "std::bad_alloc" in macro

@@ -69,3 +69,23 @@ def test_job_seeds_are_disjoint_across_ranks():
         assert sorted(seen) == jobs
     assert batch.job_seed(3) == 0x5EED0019 + 3
     del zk
+
+
+def test_eight_ranks_cover_the_256_job_batch_exactly_once():
+    """BASELINE configs[3] as the driver launches it on an 8-GPU node (`--gpus 8 --steps 32`), on CPU with the fake workload
+    (gloo, world size 8): the ranks' jobs partition 0 .. 255 — every job exactly once —, every one of them has a committed oracle
+    digest for its rank to compare the proof with (tests/golden/batch_k19_sha256.json), every rank's own clock and set-up time
+    travel in the line, and the slowest rank sets `value`."""
+    env = dict(os.environ, ZKMI355_BENCH_FAKE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "32", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 32 and j["jobs_total"] == 256
+    assert j["jobs_covered_exactly_once"] is True
+    assert j["proofs_checked_against_oracle_digests"] == 256
+    assert len(j["ms_per_step_per_rank"]) == 8 and len(j["host_setup"]["keygen_s_per_rank"]) == 8
+    assert j["ms_per_step"] >= max(j["ms_per_step_per_rank"]) - 1e-6  # rank 7 sleeps 80 ms per job

@@ -90,7 +90,8 @@ struct zk_ctx {
         MsmWorkspace* ws_run = nullptr;  // the one the MSM in flight uses
         hipStream_t tail = nullptr;      // the stream the tail of the MSM in flight runs on (the context's tail stream or its main stream)
         hipEvent_t head_done = nullptr, tail_done = nullptr;
-        hipEvent_t t_head[2] = {nullptr, nullptr}, t_acc[2] = {nullptr, nullptr};  // timing: whole head / accumulate kernel
+        hipEvent_t t_head[2] = {nullptr, nullptr};  // timing: the pass as enqueued on the main stream
+        hipEvent_t t_acc[4] = {nullptr, nullptr, nullptr, nullptr};  // timing: accumulate kernel [0, 1]; reduction tail [2, 3] (wide path)
         size_t n = 0;
         const G1Affine* table = nullptr;  // the window table of the MSM in flight (fixed-base mode)
         G1X* host_buf = nullptr;  // pinned

@@ -49,6 +49,7 @@ uint32_t msm_num_windows(uint32_t c);
 size_t msm_ws_max_n(const MsmWorkspace* ws);
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws);
 uint32_t msm_ws_window(const MsmWorkspace* ws);
+bool msm_ws_last_pass_wide(const MsmWorkspace* ws);
 // table[w * n + i] = 2^(c w) * bases[i] (affine), w < msm_num_windows(c)
 // (the wide path's tables — 15 / 16-bit windows, msm_table_is_internal — hold the points in the accumulation's internal form,
 // x * 2^261: they are read by the fixed-base MSM only)

@@ -312,10 +312,12 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
         out[0] = msm_finish_host(L.host_buf, L.nwin, L.cw);  // generic mode: Horner over the windows
     }
     // timers: head (recode .. accumulate, on the context stream) and the accumulate kernel alone
+    // (the head ends with the accumulate kernel: t_acc[1] — always complete once the tail is; an event recorded behind the tail's
+    // own on the same stream, as round 4 did, is often not: with the tails on the main stream most passes went uncounted)
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, L.t_head[0], L.t_head[1]) == hipSuccess) {
+    c->acc_n[ZK_T_MSM]++;
+    if (L.n > 0 && hipEventElapsedTime(&ms, L.t_head[0], L.t_acc[1]) == hipSuccess) {
         c->acc_ms[ZK_T_MSM] += ms;
-        c->acc_n[ZK_T_MSM]++;
         c->last_plain_ms[ZK_T_MSM] = ms;
     }
     if (L.n > 0 && hipEventElapsedTime(&ms, L.t_acc[0], L.t_acc[1]) == hipSuccess) {
@@ -323,6 +325,11 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
         c->acc_n[ZK_T_MSM_ACCUM]++;
         c->acc_n[ZK_T_MSM_COLUMNS] += L.batch;
         c->last_plain_ms[ZK_T_MSM_ACCUM] = ms;
+    }
+    if (L.n > 0 && L.fixed && msm_ws_last_pass_wide(L.ws_run) && hipEventElapsedTime(&ms, L.t_acc[2], L.t_acc[3]) == hipSuccess) {
+        c->acc_ms[ZK_T_MSM_TAIL] += ms;
+        c->acc_n[ZK_T_MSM_TAIL]++;
+        c->last_plain_ms[ZK_T_MSM_TAIL] = ms;
     }
     return ZK_OK;
 }
@@ -353,6 +360,28 @@ int zk_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// PCI address ("0000:c1:00.0") of a device: where its host-side neighbourhood is found (/sys/bus/pci/devices/<id>/numa_node,
+// local_cpulist) — a multi-GPU host binds each GPU's worker threads and staging memory to that NUMA node
+ZK_API(zk_device_pci_bus_id, (int device_id, char* out, size_t cap), (device_id, out, cap)) {
+    if (!out || cap < 16) return ZK_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ENODEV;
+    if (device_id < 0 || device_id >= ndev) return ZK_EINVAL;
+    if (hipDeviceGetPCIBusId(out, (int)cap, device_id) != hipSuccess) return ZK_EHIP;
+    return ZK_OK;
+}
+
+// page-locked host memory for the buffers a host hands to zk_poly_upload*: the copy is then one DMA at the bus rate instead of
+// the runtime's staged copy out of pageable memory (allocate on the thread that is bound to the GPU's NUMA node)
+void* zk_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void zk_host_free(void* p) {
+    if (p) hipHostFree(p);
 }
 
 const char* zk_strerror(int code) {
@@ -400,7 +429,7 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
         L.tail = c->tail_stream;
         if (hipEventCreate(&L.t_head[0]) != hipSuccess ||
             hipEventCreate(&L.t_head[1]) != hipSuccess || hipEventCreate(&L.t_acc[0]) != hipSuccess ||
-            hipEventCreate(&L.t_acc[1]) != hipSuccess || hipEventCreateWithFlags(&L.head_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&L.t_acc[1]) != hipSuccess || hipEventCreate(&L.t_acc[2]) != hipSuccess || hipEventCreate(&L.t_acc[3]) != hipSuccess || hipEventCreateWithFlags(&L.head_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.tail_done, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc(&L.host_buf, (size_t)MSM_MAX_BATCH * 15 * 4 * sizeof(G1X)) != hipSuccess) {
             zk_ctx_destroy(c);
@@ -470,10 +499,10 @@ void zk_ctx_destroy(zk_ctx* c) {
         if (L.ws) msm_workspace_destroy(L.ws);
         if (L.ws_gen) msm_workspace_destroy(L.ws_gen);
         if (L.host_buf) hipHostFree(L.host_buf);
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < 2; j++)
             if (L.t_head[j]) hipEventDestroy(L.t_head[j]);
+        for (int j = 0; j < 4; j++)
             if (L.t_acc[j]) hipEventDestroy(L.t_acc[j]);
-        }
         if (L.head_done) hipEventDestroy(L.head_done);
         if (L.tail_done) hipEventDestroy(L.tail_done);
     }

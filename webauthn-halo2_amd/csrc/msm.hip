@@ -107,6 +107,7 @@ struct MsmWorkspace {
     bool w_redo_valid;          // the last pass on this workspace ran the wide path's unchecked accumulation over n > 0 scalars: the word
                                 // behind its sums in the host buffer is that pass's redo count (msm_wide_redo_count); any other pass —
                                 // the standard plan on a wide workspace, an empty one — leaves no such word
+    bool w_last_wide;           // the last pass on this workspace took the wide path (its tail's timing events were recorded)
     bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
     // per-bucket totals and level-2 cursors exist twice: pass i counts in set i & 1 while its first kernel — 131 K lanes with
     // to spare (the fine histogram: two thousand workgroups) — zeroes the other set for pass i + 1 (in the 16 waves of the last
@@ -186,6 +187,7 @@ uint32_t msm_num_windows(uint32_t c) { return nwin_for(c); }
 size_t msm_ws_max_n(const MsmWorkspace* ws) { return ws->max_n; }
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws) { return ws->max_batch; }
 uint32_t msm_ws_window(const MsmWorkspace* ws) { return ws->c; }
+bool msm_ws_last_pass_wide(const MsmWorkspace* ws) { return ws->w_last_wide; }
 
 // ---------------------------------------------------------------- recode ---
 
@@ -2001,6 +2003,7 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
         if ((e = hipStreamWaitEvent(tail_st, head_done, 0)) != hipSuccess) return e;
         ts = tail_st;
     }
+    if (accum_events && accum_events[2]) hipEventRecord(accum_events[2], ts);  // the reduction tail (T1 .. T3) alone
     if (n > 0) {
         // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_wscatter1_kernel)
         const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * g.bins + 64;
@@ -2015,6 +2018,7 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     G1X* out_dev = nullptr;
     if ((e = hipHostGetDevicePointer((void**)&out_dev, host_window_sums, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(msm_wbits_kernel, dim3(9 + row_bits, batch), dim3(64), 0, ts, ws->w_rc, nb, out_dev, ws->counts);
+    if (accum_events && accum_events[3]) hipEventRecord(accum_events[3], ts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     ws->w_clean = true;
     ws->w_redo_valid = n > 0 && !bases_may_be_identity;  // (the checked loop lists nothing; an empty pass never reset counts[1])
@@ -2071,6 +2075,7 @@ hipError_t msm_run(MsmWorkspace* ws, const Fr* const* scalars_list, uint32_t bat
     const uint32_t c = ws->c, nwin = ws->nwin, nb = ws->nb;
     const bool fixed = table != nullptr;
     ws->w_redo_valid = false;
+    ws->w_last_wide = fixed && ws->wide && table_stride == ws->max_n;
     if (fixed && ws->wide && table_stride == ws->max_n)
         return msm_run_wide(ws, scalars_list, batch, n, st, host_window_sums, nwin_out, c_out, accum_events, table, table_stride, tail_st,
                             head_done, bases_may_be_identity);

@@ -15,7 +15,7 @@ _LIB = None
 
 ZK_BASIS_MONOMIAL = 0
 ZK_BASIS_LAGRANGE = 1
-ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS, ZK_T_MSM_TAIL_MAIN = 0, 1, 2, 3, 4, 5, 6
+ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS, ZK_T_MSM_TAIL_MAIN, ZK_T_MSM_TAIL = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
@@ -23,6 +23,40 @@ ZK_SERDE_PROCESSED, ZK_SERDE_RAW_BYTES, ZK_SERDE_RAW_BYTES_UNCHECKED = 0, 1, 2
 ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT, ZK_OPT_MSM_TAIL_STREAM = 1, 2, 3, 4, 5
 ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS, ZK_OPT_XFORM_STREAM = 6, 7, 8
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
+
+
+def device_pci_bus_id(device=0):
+    """PCI address of a device, e.g. '0000:c1:00.0' (zk_device_pci_bus_id)."""
+    buf = ctypes.create_string_buffer(32)
+    rc = load_library().zk_device_pci_bus_id(device, buf, len(buf))
+    if rc:
+        raise ZkError(rc, "zk_device_pci_bus_id")
+    return buf.value.decode().lower()
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (zk_host_alloc): the buffers a host hands to upload / upload_canonical.
+    Keep the object alive while `a` is in use; free() (or garbage collection) returns the memory."""
+
+    def __init__(self, shape, dtype=np.uint64):
+        self.L = load_library()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.L.zk_host_alloc(nbytes)
+        if not self.ptr:
+            raise ZkError(-2, "zk_host_alloc")
+        self.a = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.a = None
+            self.L.zk_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class CircuitParamsC(ctypes.Structure):
@@ -58,6 +92,9 @@ def load_library():
     u32 = ctypes.c_uint32
     sig = {
         "zk_device_count": ([], ctypes.c_int),
+        "zk_device_pci_bus_id": ([ctypes.c_int, ctypes.c_char_p, sz], ctypes.c_int),
+        "zk_host_alloc": ([sz], vp),
+        "zk_host_free": ([vp], None),
         "zk_ctx_create": ([ctypes.c_int, ctypes.POINTER(vp)], ctypes.c_int),
         "zk_ctx_create_shared": ([vp, ctypes.POINTER(vp)], ctypes.c_int),
         "zk_ctx_destroy": ([vp], None),
