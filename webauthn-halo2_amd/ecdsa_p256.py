@@ -42,9 +42,10 @@ _SLOTS_LOCK = threading.Lock()
 _STATE_LOCK = threading.RLock()  # set-up / tear-down of a device's resident state (gen_srs with a new degree, shutdown)
 # Proof pipelines per device = requests proved CONCURRENTLY on it (the reference: one Rocket worker thread per request,
 # proving-server/src/main.rs:457-472).  Each is a context of its own (own key, own workspace, shared SRS and window tables).
-# Two is the measured optimum for the server's default shape: 144 / 195 / 173 / 183 proofs/s at k = 17 with 1 / 2 / 3 / 4
-# (tools/inflight_k17.py, DESIGN.md §5 "Streams and hardware queues"); k = 19 batches want four (batch.py, bench.py).
-PIPELINES_PER_DEVICE = 2
+# Four is the measured optimum for the server's default shape since round 5: 143 / 184 / 208 / 224 / 208 proofs/s at k = 17 with
+# 1 / 2 / 3 / 4 / 6 (tools/inflight_k17.py, profiles/r5_k17_inflight.txt; round 4: 144 / 195 / 173 / 183), and what k = 19 batches
+# want too (batch.py, bench.py).  A request that arrives alone still proves alone: pipeline 0 is taken first.
+PIPELINES_PER_DEVICE = 4
 _MAX_SLOT_SETS = 4  # parked request-slot sets per column count: the server's usual number of requests in flight per device
 
 
