@@ -84,3 +84,55 @@ def test_tail_placement_follows_device_activity_whatever_the_entry_point():
         p.free()
     for e in engs[::-1]:
         e.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["transforms-on-their-own-stream", "transforms-on-the-main-stream"])
+def test_transform_stream_placement_does_not_change_proofs(mode):
+    """ZK_OPT_XFORM_STREAM pins where a proof's column transforms run (auto: a stream of their own for a lone k >= 18 proof,
+    decided once per proof): the oracle's bytes either way, for a lone proof and for two pipelines proving side by side, at a
+    multi-column and a one-column shape whose commitments run on the window tables."""
+    import threading as th
+
+    from zkoracle import plonk, prover
+    from zkoracle.hashes import ChaCha20Rng
+
+    for (A, L, F, k, lb) in ((3, 2, 1, 10, 8), (1, 1, 1, 10, 9)):
+        p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb)
+        asg = zk.circuit.synthesize(p, 0x5EED0019)
+        sh = plonk.Shape(k, A, L, F, lb)
+        opk = prover.keygen(prover.Circuit(sh, asg.fixed, asg.copies, asg.advice))
+        fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
+        engs = [zk.Engine(0)]
+        engs[0].set_option(E.ZK_OPT_XFORM_STREAM, mode)
+        engs[0].srs_setup(k)
+        engs.append(zk.Engine(0, share_with=engs[0]))
+        pks, cols = [], []
+        for e in engs:
+            pks.append(e.keygen(p, fixed, asg.copies))
+            hs = []
+            for col in asg.advice:
+                h = e.poly(1 << k)
+                e.upload_canonical(h, asg.to_limbs(col))
+                hs.append(h)
+            cols.append(hs)
+        seed = bytes([40 + mode]) * 32
+        want = {kind: prover.create_proof(opk, asg.advice, ChaCha20Rng(seed), kind) for kind in ("blake2b", "evm")}
+        tk = {"blake2b": E.ZK_TRANSCRIPT_BLAKE2B, "evm": E.ZK_TRANSCRIPT_EVM}
+        for kind in want:
+            assert engs[0].prove(pks[0], cols[0], seed, tk[kind]) == want[kind]
+        bad = []
+
+        def work(i):
+            for r in range(40):
+                kind = "evm" if r & 1 else "blake2b"
+                if engs[i].prove(pks[i], cols[i], seed, tk[kind]) != want[kind]:
+                    bad.append((i, r))
+
+        ths = [th.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not bad, bad
+        for e in engs[::-1]:
+            e.close()

@@ -880,9 +880,11 @@ struct Prover {
     // kernels that made it — and the quotient waits for them (xform_join).
     // Auto: a lone context and columns of 2^18 rows or more (measured, tools/single_ab.py OPTS=8=1 / 8=2, same box: k = 19 12.10 ->
     // 11.47 ms, EVM 13.66 -> 13.03; k = 17 6.55 -> 6.67: there the transforms are too short to pay for the cross-stream events)
-    bool xform_side() const {
-        return !batch_member && (c->opt_xform_stream == 1 || (c->opt_xform_stream == 0 && lay.k >= 18 && ctx_activity_touch(c) <= 1));
-    }
+    // Decided ONCE per proof (begin()): a proof whose transforms changed streams half-way would have the two streams' NTTs
+    // share the context's ping-pong scratch without an order between them (round 5's first form decided per call: under four
+    // pipelines the count dips to one now and then, and 1 proof in ~ 1 500 came out wrong — tools/soak.py)
+    bool xside = false;
+    bool xform_side() const { return xside; }
     void xform_join() {
         if (!c->xform_pending) return;
         c->xform_pending = false;
@@ -1079,6 +1081,7 @@ struct Prover {
     // ------------------------------------------------------------------ run ---
     // domain constants, and the transcript's first word
     int begin() {
+        xside = !batch_member && (c->opt_xform_stream == 1 || (c->opt_xform_stream == 0 && lay.k >= 18 && ctx_activity_touch(c) <= 1));
         if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
         omega = fr_omega(lay.k);
         omega_inv = fe_inv(omega);
