@@ -103,6 +103,10 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         0 auto (beside the MSM passes on a stream of their own while this is the only active context
                                         of the process on the device — a lone proof —, in order on the main stream otherwise: see
                                         ZK_OPT_MSM_TAIL_STREAM on hardware queues), 1 always the side stream, 2 always the main stream */
+#define ZK_OPT_MSM_STREAM 9          /* zk_prove: where a proof's MSM passes (sort head + accumulation) run: 0 auto (a stream of their own
+                                        for a lone proof — with ZK_OPT_XFORM_STREAM's auto rule: main, tail, transform and MSM stream are
+                                        the runtime's four hardware queues —, so that the glue kernels of the next phase do not queue
+                                        behind an accumulation), 1 always that stream, 2 always the main stream */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

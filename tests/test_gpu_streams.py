@@ -88,8 +88,8 @@ def test_tail_placement_follows_device_activity_whatever_the_entry_point():
 
 @pytest.mark.parametrize("mode", [1, 2], ids=["transforms-on-their-own-stream", "transforms-on-the-main-stream"])
 def test_transform_stream_placement_does_not_change_proofs(mode):
-    """ZK_OPT_XFORM_STREAM pins where a proof's column transforms run (auto: a stream of their own for a lone k >= 18 proof,
-    decided once per proof): the oracle's bytes either way, for a lone proof and for two pipelines proving side by side, at a
+    """ZK_OPT_XFORM_STREAM / ZK_OPT_MSM_STREAM pin where a proof's column transforms and MSM passes run (auto: streams of their
+    own for a lone k >= 18 proof, decided once per proof): the oracle's bytes either way, for a lone proof and for two pipelines proving side by side, at a
     multi-column and a one-column shape whose commitments run on the window tables."""
     import threading as th
 
@@ -104,6 +104,7 @@ def test_transform_stream_placement_does_not_change_proofs(mode):
         fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
         engs = [zk.Engine(0)]
         engs[0].set_option(E.ZK_OPT_XFORM_STREAM, mode)
+        engs[0].set_option(E.ZK_OPT_MSM_STREAM, mode)  # the MSM passes on their own stream too (or both on the main stream)
         engs[0].srs_setup(k)
         engs.append(zk.Engine(0, share_with=engs[0]))
         pks, cols = [], []

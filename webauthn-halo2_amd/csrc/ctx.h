@@ -78,6 +78,13 @@ struct zk_ctx {
     // runs those NTTs beside its MSM passes instead of between them — both are bound by the issue of their own instruction
     // streams and leave each other's stalls to fill.  ev_rows: the last flush of staged blinding rows on the main stream (what
     // a column's transforms wait for); ev_xform: the last transform enqueued (what the quotient waits for).
+    // The context's MSM stream (round 5, experiment ZK_OPT_MSM_STREAM): a lone proof's MSM passes (sort head + accumulation) run
+    // here, behind an event taken on the main stream when the pass is begun (its inputs are complete), so that the glue kernels
+    // of the next phase — lookup permutation, grand products with their host round trip — do not queue behind an accumulation
+    hipStream_t msm_stream = nullptr;
+    hipEvent_t ev_msm_in = nullptr;
+    bool msm_side = false;          // set by the prover for the duration of a proof
+    uint32_t opt_msm_stream = 0;    // ZK_OPT_MSM_STREAM: 0 auto, 1 side stream, 2 main stream
     hipStream_t xform_stream = nullptr;
     hipEvent_t ev_rows = nullptr, ev_xform = nullptr;
     bool xform_pending = false;

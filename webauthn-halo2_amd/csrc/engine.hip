@@ -276,11 +276,18 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     const uint32_t above = c->opt_tail_main_above ? c->opt_tail_main_above : 2u;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE; measured default (ctx.h)
     L.tail = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && (uint32_t)active > above) ? c->stream : c->tail_stream;
     if (L.tail == c->stream) c->acc_n[ZK_T_MSM_TAIL_MAIN]++;
-    HIPCHK(c, hipEventRecord(L.t_head[0], c->stream));
-    HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, c->stream, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
+    hipStream_t hs = c->stream;  // where the pass's head and accumulation run
+    if (c->msm_side && c->msm_stream) {
+        hs = c->msm_stream;
+        HIPCHK(c, hipEventRecord(c->ev_msm_in, c->stream));  // everything the main stream holds so far: the pass's inputs among it
+        HIPCHK(c, hipStreamWaitEvent(hs, c->ev_msm_in, 0));
+        if (L.tail == c->stream) L.tail = c->tail_stream;    // (never a tail behind the main stream's later kernels)
+    }
+    HIPCHK(c, hipEventRecord(L.t_head[0], hs));
+    HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, hs, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
                       L.head_done, !table || ident));
     HIPCHK(c, hipEventRecord(L.tail_done, L.tail));
-    HIPCHK(c, hipEventRecord(L.t_head[1], c->stream));
+    HIPCHK(c, hipEventRecord(L.t_head[1], hs));
     c->msm_launches++;
     L.n = n;
     L.batch = batch;
@@ -419,6 +426,7 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
             return ZK_EHIP;
         }
     if (hipStreamCreate(&c->tail_stream) != hipSuccess || hipStreamCreate(&c->xform_stream) != hipSuccess ||
+        hipStreamCreate(&c->msm_stream) != hipSuccess || hipEventCreateWithFlags(&c->ev_msm_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_xform, hipEventDisableTiming) != hipSuccess) {
         zk_ctx_destroy(c);
@@ -473,6 +481,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
         c->opt_tail_main_above = parent->opt_tail_main_above;
         c->opt_batch_pass_cols = parent->opt_batch_pass_cols;
         c->opt_xform_stream = parent->opt_xform_stream;
+        c->opt_msm_stream = parent->opt_msm_stream;
         c->srs_gen++;
     }
     *out = c;
@@ -486,6 +495,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
     if (c->xform_stream) hipStreamSynchronize(c->xform_stream);
+    if (c->msm_stream) hipStreamSynchronize(c->msm_stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
     for (auto& kv : c->twiddles_ninv) hipFree(kv.second);
@@ -514,6 +524,8 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (int i = 0; i < ZK_T_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) hipEventDestroy(c->ev[i][j]);
+    if (c->ev_msm_in) hipEventDestroy(c->ev_msm_in);
+    if (c->msm_stream) hipStreamDestroy(c->msm_stream);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     if (c->ev_xform) hipEventDestroy(c->ev_xform);
     if (c->xform_stream) hipStreamDestroy(c->xform_stream);
@@ -584,6 +596,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_MSM_TAIL_MAIN_ABOVE:
             if (value > 64) return ZK_EINVAL;
             c->opt_tail_main_above = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_MSM_STREAM:
+            if (value > 2) return ZK_EINVAL;
+            c->opt_msm_stream = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_XFORM_STREAM:
             if (value > 2) return ZK_EINVAL;

@@ -21,7 +21,7 @@ ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS, 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
 ZK_SERDE_PROCESSED, ZK_SERDE_RAW_BYTES, ZK_SERDE_RAW_BYTES_UNCHECKED = 0, 1, 2
 ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT, ZK_OPT_MSM_TAIL_STREAM = 1, 2, 3, 4, 5
-ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS, ZK_OPT_XFORM_STREAM = 6, 7, 8
+ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS, ZK_OPT_XFORM_STREAM, ZK_OPT_MSM_STREAM = 6, 7, 8, 9
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
 
