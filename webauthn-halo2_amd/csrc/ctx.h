@@ -168,6 +168,7 @@ int ctx_bind(zk_ctx* c);
 void ctx_activity_register(zk_ctx* c);
 void ctx_activity_unregister(zk_ctx* c);
 int ctx_activity_touch(zk_ctx* c);
+int ctx_lone_streams(zk_ctx* c);  // creates the transform / MSM streams of a lone proof on first use
 void ctx_release_spares(zk_ctx* c);  // frees the vectors zk_poly_free parked (caller holds c->mu, device bound)
 int ctx_ensure_scratch(zk_ctx* c, size_t n);
 int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out);

@@ -201,6 +201,13 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     return ZK_OK;
 }
 
+// the two further streams a LONE proof spreads over (ctx.h xform_stream, msm_stream), made when the first such proof asks
+int ctx_lone_streams(zk_ctx* c) {
+    if (!c->xform_stream && hipStreamCreate(&c->xform_stream) != hipSuccess) return ZK_EHIP;
+    if (!c->msm_stream && hipStreamCreate(&c->msm_stream) != hipSuccess) return ZK_EHIP;
+    return ZK_OK;
+}
+
 // ---- how busy the device is, as far as this process can see: contexts that enqueued an MSM pass within the last few
 // milliseconds.  Every context owns a slot of its device's table and stamps it in ctx_msm_begin_batch — the one place every
 // MSM pass goes through, whoever asked for it (zk_prove, zk_commit / zk_commit_batch, zk_msm_srs, zk_msm_bn254, zk_keygen,
@@ -274,7 +281,9 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     // where this pass's reduction tail runs (ctx.h tail_stream): the side stream for up to two proofs in flight on the device
     const int active = ctx_activity_touch(c);
     const uint32_t above = c->opt_tail_main_above ? c->opt_tail_main_above : 2u;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE; measured default (ctx.h)
-    L.tail = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && (uint32_t)active > above) ? c->stream : c->tail_stream;
+    const bool tail_on_main = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && (uint32_t)active > above);
+    if ((!tail_on_main || c->msm_side) && !c->tail_stream) HIPCHK(c, hipStreamCreate(&c->tail_stream));  // made on first use (see zk_ctx_create)
+    L.tail = tail_on_main ? c->stream : c->tail_stream;
     if (L.tail == c->stream) c->acc_n[ZK_T_MSM_TAIL_MAIN]++;
     hipStream_t hs = c->stream;  // where the pass's head and accumulation run
     if (c->msm_side && c->msm_stream) {
@@ -425,8 +434,10 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
             zk_ctx_destroy(c);
             return ZK_EHIP;
         }
-    if (hipStreamCreate(&c->tail_stream) != hipSuccess || hipStreamCreate(&c->xform_stream) != hipSuccess ||
-        hipStreamCreate(&c->msm_stream) != hipSuccess || hipEventCreateWithFlags(&c->ev_msm_in, hipEventDisableTiming) != hipSuccess ||
+    // (the transform and MSM streams of a lone proof are made on first use — ctx_lone_streams: the HIP runtime spreads a
+    // process's streams over its four hardware queues as they are created, and with four streams per context the MAIN streams of
+    // four pipelines all landed on one queue: 100 -> 88 proofs/s, accumulate launches serialised at 0.70 ms, found by bench.py)
+    if (hipEventCreateWithFlags(&c->ev_msm_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_xform, hipEventDisableTiming) != hipSuccess) {
         zk_ctx_destroy(c);
@@ -434,7 +445,7 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
     }
     for (int i = 0; i < zk_ctx::MSM_LANES; i++) {
         zk_ctx::MsmLane& L = c->lanes[i];
-        L.tail = c->tail_stream;
+        L.tail = c->stream;
         if (hipEventCreate(&L.t_head[0]) != hipSuccess ||
             hipEventCreate(&L.t_head[1]) != hipSuccess || hipEventCreate(&L.t_acc[0]) != hipSuccess ||
             hipEventCreate(&L.t_acc[1]) != hipSuccess || hipEventCreate(&L.t_acc[2]) != hipSuccess || hipEventCreate(&L.t_acc[3]) != hipSuccess || hipEventCreateWithFlags(&L.head_done, hipEventDisableTiming) != hipSuccess ||

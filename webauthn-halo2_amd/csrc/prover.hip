@@ -1085,6 +1085,7 @@ struct Prover {
         // the MSM passes of a lone proof on the context's MSM stream (ctx.h): same rule, same once-per-proof decision; measured
         // (tools/single_ab.py OPTS=9=1 / 9=2, four alternations on one box): 11.40-11.55 -> 11.29-11.38 ms, same bytes
         c->msm_side = !batch_member && (c->opt_msm_stream == 1 || (c->opt_msm_stream == 0 && xside && c->opt_xform_stream == 0));
+        if ((xside || c->msm_side) && (rc = ctx_lone_streams(c))) return rc;
         if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
         omega = fr_omega(lay.k);
         omega_inv = fe_inv(omega);
