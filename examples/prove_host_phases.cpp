@@ -10,7 +10,7 @@
 //     permutation argument   zk_permutation_product
 //     vanishing argument     zk_random_poly (the host hands over its ChaCha20 key and position), zk_quotient, zk_extended_to_coeff
 //     domain                 zk_lagrange_to_coeff, zk_coeff_to_extended
-//     openings               zk_eval, zk_poly_lincomb, zk_kate_division   (ProverGWC)
+//     openings               zk_eval, zk_poly_lincomb, zk_kate_division   (ProverGWC and ProverSHPLONK)
 // No column crosses PCIe after the advice upload: the blinding rows go up as 7-row ranges (zk_poly_upload_range).  The proof
 // is byte-identical to zk_prove's with the same key, advice and seed (tests/test_gpu_host_phases.py) — here the seed feeds
 // THIS file's ChaCha20Rng, drawn in halo2's order.
@@ -20,11 +20,13 @@
 // halo2_proofs::transcript for that; nothing of the engine's prover (csrc/prover.hip) is used.
 //
 // usage: prove_host_phases <srs.bin> <pk.bin> <advice.bin> <proof.out> k num_advice num_lookup_advice num_fixed lookup_bits idle
-//                          <transcript: blake2b|evm> <rng seed: 64 hex digits>          (multi-open: GWC)
+//                          <transcript: blake2b|evm> <rng seed: 64 hex digits> [gwc|shplonk]
+//   multi-open: the reference's pairings by default — GWC under the EVM transcript (ecdsa_p256.rs:368), SHPLONK under Blake2b (:418)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -85,8 +87,8 @@ static void commit_write(Transcript& tr, const std::vector<zk_poly>& polys, int 
 }
 
 int main(int argc, char** argv) {
-    if (argc != 13) {
-        fprintf(stderr, "usage: %s srs.bin pk.bin advice.bin proof.out k A L F lookup_bits idle blake2b|evm seedhex\n", argv[0]);
+    if (argc != 13 && argc != 14) {
+        fprintf(stderr, "usage: %s srs.bin pk.bin advice.bin proof.out k A L F lookup_bits idle blake2b|evm seedhex [gwc|shplonk]\n", argv[0]);
         return 2;
     }
     zk_circuit_params prm;
@@ -98,6 +100,7 @@ int main(int argc, char** argv) {
     prm.lookup_bits = (uint32_t)atoi(argv[9]);
     prm.num_idle_gate_columns = (uint32_t)atoi(argv[10]);
     const bool evm = strcmp(argv[11], "evm") == 0;
+    const bool shplonk = argc == 14 ? strcmp(argv[13], "shplonk") == 0 : !evm;
     uint8_t seed[32];
     if (strlen(argv[12]) != 64) return 2;
     for (int i = 0; i < 32; i++) {
@@ -266,7 +269,7 @@ int main(int argc, char** argv) {
             c[i] = p;
             p = fe_mul(p, xn);
         }
-        CHECK(zk_poly_lincomb(ctx, h_comb, h_piece.data(), reinterpret_cast<const uint64_t*>(c.data()), n_h, nullptr));
+        CHECK(zk_poly_lincomb(ctx, h_comb, h_piece.data(), reinterpret_cast<const uint64_t*>(c.data()), n_h, nullptr, 0));
     }
     struct Q {
         zk_poly poly;
@@ -326,37 +329,189 @@ int main(int argc, char** argv) {
         queries.push_back(ev[n_written]);  // h
         queries.push_back(ev[i_rand]);     // the random polynomial
     }
-    const Fr v = tr.squeeze();
-    std::vector<std::pair<int, std::vector<Q>>> sets;
-    for (const Q& q : queries) {
-        bool found = false;
-        for (auto& s : sets)
-            if (s.first == q.rot) {
-                s.second.push_back(q);
-                found = true;
-                break;
+    if (!shplonk) {
+        const Fr v = tr.squeeze();
+        std::vector<std::pair<int, std::vector<Q>>> sets;
+        for (const Q& q : queries) {
+            bool found = false;
+            for (auto& s : sets)
+                if (s.first == q.rot) {
+                    s.second.push_back(q);
+                    found = true;
+                    break;
+                }
+            if (!found) sets.push_back({q.rot, {q}});
+        }
+        std::vector<zk_poly> wit;
+        for (auto& s : sets) {
+            // (sum_i v^i p_i(X) - sum_i v^i e_i) / (X - x w^rot).  A polynomial opened twice in one set (none here) would appear twice.
+            std::vector<zk_poly> in;
+            std::vector<Fr> c;
+            Fr pv = Fr::one(), eb = Fr::zero();
+            for (const Q& q : s.second) {
+                in.push_back(q.poly);
+                c.push_back(pv);
+                eb = fe_add(eb, fe_mul(pv, q.eval));
+                pv = fe_mul(pv, v);
             }
-        if (!found) sets.push_back({q.rot, {q}});
-    }
-    std::vector<zk_poly> wit;
-    for (auto& s : sets) {
-        // (sum_i v^i p_i(X) - sum_i v^i e_i) / (X - x w^rot).  A polynomial opened twice in one set (none here) would appear twice.
+            zk_poly w = alloc(n);
+            CHECK(zk_poly_lincomb(ctx, w, in.data(), reinterpret_cast<const uint64_t*>(c.data()), in.size(), limbs(eb), 1));
+            const Fr pt = xrot(x, s.first);
+            CHECK(zk_kate_division(ctx, w, limbs(pt), w));
+            wit.push_back(w);
+        }
+        commit_write(tr, wit, ZK_BASIS_MONOMIAL);
+    } else {
+        // ---- 7'. multi-open (ProverSHPLONK): polynomials grouped by their set of rotations; h(X) = sum_i v^i (sum_j y^j (P_ij - R_ij)) / Z_i
+        struct CR {
+            zk_poly poly;
+            std::vector<int> rots;
+            std::vector<Fr> evals;
+        };
+        std::vector<CR> com;
+        for (const Q& q : queries) {
+            size_t at = com.size();
+            for (size_t i = 0; i < com.size(); i++)
+                if (com[i].poly == q.poly) at = i;
+            if (at == com.size()) com.push_back(CR{q.poly, {}, {}});
+            com[at].rots.push_back(q.rot);
+            com[at].evals.push_back(q.eval);
+        }
+        auto canon_less = [&](int ra, int rb) {  // BTreeSet<Fr>: the points ordered by their canonical integer value
+            const Fr a = fe_from_mont(xrot(x, ra)), b = fe_from_mont(xrot(x, rb));
+            for (int i = 7; i >= 0; i--)
+                if (a.v[i] != b.v[i]) return a.v[i] < b.v[i];
+            return false;
+        };
+        struct RS {
+            std::vector<int> rots;
+            std::vector<size_t> coms;
+        };
+        std::vector<RS> rsets;
+        std::vector<int> all_rots;
+        for (size_t ci = 0; ci < com.size(); ci++) {
+            CR& cr = com[ci];
+            std::vector<size_t> order(cr.rots.size());
+            for (size_t i = 0; i < order.size(); i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return canon_less(cr.rots[a], cr.rots[b]); });
+            std::vector<int> r2;
+            std::vector<Fr> e2;
+            for (size_t i : order) {
+                r2.push_back(cr.rots[i]);
+                e2.push_back(cr.evals[i]);
+            }
+            cr.rots = r2;
+            cr.evals = e2;
+            for (int r : cr.rots)
+                if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
+            size_t hit = rsets.size();
+            for (size_t si = 0; si < rsets.size(); si++)
+                if (rsets[si].rots == cr.rots) hit = si;
+            if (hit == rsets.size()) rsets.push_back(RS{cr.rots, {}});
+            rsets[hit].coms.push_back(ci);
+        }
+        std::sort(all_rots.begin(), all_rots.end(), canon_less);
+        const Fr yc = tr.squeeze(), v = tr.squeeze();
+        // the Lagrange basis over a set's points as coefficient vectors, one inversion for all denominators (lagrange_interpolate)
+        auto lagrange_basis = [&](const std::vector<Fr>& pts) {
+            const size_t m = pts.size();
+            std::vector<std::vector<Fr>> basis(m);
+            std::vector<Fr> den(m, Fr::one());
+            for (size_t j = 0; j < m; j++) {
+                std::vector<Fr> num(1, Fr::one());
+                for (size_t i = 0; i < m; i++) {
+                    if (i == j) continue;
+                    std::vector<Fr> nn(num.size() + 1, Fr::zero());
+                    for (size_t t = 0; t < num.size(); t++) {
+                        nn[t + 1] = fe_add(nn[t + 1], num[t]);
+                        nn[t] = fe_sub(nn[t], fe_mul(pts[i], num[t]));
+                    }
+                    num.swap(nn);
+                    den[j] = fe_mul(den[j], fe_sub(pts[j], pts[i]));
+                }
+                basis[j] = num;
+            }
+            for (size_t j = 0; j < m; j++) {
+                const Fr dj = fe_inv(den[j]);
+                for (Fr& cf : basis[j]) cf = fe_mul(cf, dj);
+            }
+            return basis;
+        };
+        std::vector<std::vector<Fr>> low(com.size());  // every polynomial's remainder over its set's points
+        std::vector<zk_poly> sbuf;
+        for (RS& rs : rsets) {
+            std::vector<Fr> pts;
+            for (int r : rs.rots) pts.push_back(xrot(x, r));
+            const std::vector<std::vector<Fr>> basis = lagrange_basis(pts);
+            std::vector<zk_poly> in;
+            std::vector<Fr> c, rsum(pts.size(), Fr::zero());
+            Fr py = Fr::one();
+            for (size_t ci : rs.coms) {
+                std::vector<Fr>& lo = low[ci];
+                lo.assign(pts.size(), Fr::zero());
+                for (size_t j = 0; j < pts.size(); j++)
+                    for (size_t t = 0; t < pts.size(); t++) lo[t] = fe_add(lo[t], fe_mul(basis[j][t], com[ci].evals[j]));
+                in.push_back(com[ci].poly);
+                c.push_back(py);
+                for (size_t t = 0; t < pts.size(); t++) rsum[t] = fe_add(rsum[t], fe_mul(py, lo[t]));
+                py = fe_mul(py, yc);
+            }
+            zk_poly sb = alloc(n);
+            CHECK(zk_poly_lincomb(ctx, sb, in.data(), reinterpret_cast<const uint64_t*>(c.data()), in.size(),
+                                  reinterpret_cast<const uint64_t*>(rsum.data()), rsum.size()));
+            for (const Fr& pt : pts) CHECK(zk_kate_division(ctx, sb, limbs(pt), sb));  // exact: the numerator vanishes on the set
+            sbuf.push_back(sb);
+        }
+        zk_poly hx = alloc(n);
+        {
+            std::vector<Fr> c;
+            Fr pv = Fr::one();
+            for (size_t si = 0; si < rsets.size(); si++) {
+                c.push_back(pv);
+                pv = fe_mul(pv, v);
+            }
+            CHECK(zk_poly_lincomb(ctx, hx, sbuf.data(), reinterpret_cast<const uint64_t*>(c.data()), sbuf.size(), nullptr, 0));
+        }
+        commit_write(tr, {hx}, ZK_BASIS_MONOMIAL);
+        const Fr u = tr.squeeze();
+        // L(X) = sum_i v^i z_i(u) sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X);  the proof's last point commits to L(X) / ((X - u) z_0(u))
+        auto vanishing_eval = [&](const std::vector<Fr>& pts, const Fr& at) {
+            Fr acc = Fr::one();
+            for (const Fr& p : pts) acc = fe_mul(acc, fe_sub(at, p));
+            return acc;
+        };
         std::vector<zk_poly> in;
-        std::vector<Fr> c;
-        Fr pv = Fr::one(), eb = Fr::zero();
-        for (const Q& q : s.second) {
-            in.push_back(q.poly);
-            c.push_back(pv);
-            eb = fe_add(eb, fe_mul(pv, q.eval));
+        std::vector<Fr> c, z_diffs;
+        Fr sub = Fr::zero(), pv = Fr::one();
+        for (RS& rs : rsets) {
+            std::vector<Fr> diffs;
+            for (int r : all_rots)
+                if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) diffs.push_back(xrot(x, r));
+            const Fr zi = vanishing_eval(diffs, u);
+            z_diffs.push_back(zi);
+            Fr py = Fr::one();
+            for (size_t ci : rs.coms) {
+                const Fr coef = fe_mul(fe_mul(pv, zi), py);
+                in.push_back(com[ci].poly);
+                c.push_back(coef);
+                Fr ru = Fr::zero();  // R_ij(u)
+                for (size_t t = low[ci].size(); t-- > 0;) ru = fe_add(fe_mul(ru, u), low[ci][t]);
+                sub = fe_add(sub, fe_mul(coef, ru));
+                py = fe_mul(py, yc);
+            }
             pv = fe_mul(pv, v);
         }
-        zk_poly w = alloc(n);
-        CHECK(zk_poly_lincomb(ctx, w, in.data(), reinterpret_cast<const uint64_t*>(c.data()), in.size(), limbs(eb)));
-        const Fr pt = xrot(x, s.first);
-        CHECK(zk_kate_division(ctx, w, limbs(pt), w));
-        wit.push_back(w);
+        std::vector<Fr> all_pts;
+        for (int r : all_rots) all_pts.push_back(xrot(x, r));
+        in.push_back(hx);
+        c.push_back(fe_neg(vanishing_eval(all_pts, u)));
+        zk_poly lx = alloc(n), fin = alloc(n);
+        CHECK(zk_poly_lincomb(ctx, lx, in.data(), reinterpret_cast<const uint64_t*>(c.data()), in.size(), limbs(sub), 1));
+        CHECK(zk_kate_division(ctx, lx, limbs(u), lx));
+        const Fr zinv = fe_inv(z_diffs[0]);
+        CHECK(zk_poly_lincomb(ctx, fin, &lx, limbs(zinv), 1, nullptr, 0));
+        commit_write(tr, {fin}, ZK_BASIS_MONOMIAL);
     }
-    commit_write(tr, wit, ZK_BASIS_MONOMIAL);
 
     FILE* out = fopen(argv[4], "wb");
     if (!out || fwrite(tr.out.data(), 1, tr.out.size(), out) != tr.out.size()) {

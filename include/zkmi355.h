@@ -181,10 +181,12 @@ int zk_poly_copy(zk_ctx* ctx, zk_poly dst, zk_poly src);
 int zk_poly_upload_range(zk_ctx* ctx, zk_poly p, size_t first, const uint64_t* host_mont, size_t count);
 /* dst[dst_first ..] = src[src_first .. src_first + count) (the h pieces: n-coefficient slices of the quotient) */
 int zk_poly_copy_range(zk_ctx* ctx, zk_poly dst, size_t dst_first, zk_poly src, size_t src_first, size_t count);
-/* out = sum_j coeffs[j] * in[j], minus *sub0 (may be NULL) on coefficient 0; all vectors of one length, out none of the inputs:
- * the linear combinations of the multi-open provers (sum_i v^i (p_i(X) - e_i)) and of h(X) = sum_i x^(n i) h_i(X) */
+/* out = sum_j coeffs[j] * in[j] - (sub_low[0] + sub_low[1] X + .. + sub_low[n_low - 1] X^(n_low - 1)), n_low <= 8 (0: nothing
+ * subtracted); all vectors of one length, out none of the inputs: the linear combinations of the multi-open provers — GWC's
+ * sum_i v^i (p_i(X) - e_i) (n_low = 1), SHPLONK's sum_j y^j (P_j(X) - R_j(X)) with the remainders R_j of degree < |rotation set| —
+ * and h(X) = sum_i x^(n i) h_i(X) */
 int zk_poly_lincomb(zk_ctx* ctx, zk_poly out, const zk_poly* in, const uint64_t* coeffs_mont /* count x 4 */, size_t count,
-                    const uint64_t sub0_mont[4]);
+                    const uint64_t* sub_low_mont /* n_low x 4 */, size_t n_low);
 
 /* replaces ParamsKZG::commit / commit_lagrange (MSM against the resident SRS) + to_affine */
 int zk_commit(zk_ctx* ctx, zk_poly p, int basis, uint64_t out_affine_mont[8]);

@@ -1,7 +1,7 @@
 """examples/prove_host_phases.cpp — a host that owns the transcript, the RNG and the blinding and builds a whole proof from the
 PHASE-LEVEL C ABI only (zk_commit_batch, zk_lookup_permute, zk_lookup_product, zk_permutation_product, zk_random_poly,
-zk_lagrange_to_coeff, zk_coeff_to_extended, zk_quotient, zk_extended_to_coeff, zk_eval, zk_poly_lincomb, zk_kate_division): the
-resident integration of INTEGRATION.md §2 executed.  Its bytes are zk_prove's for the same key, advice and
+zk_lagrange_to_coeff, zk_coeff_to_extended, zk_quotient, zk_extended_to_coeff, zk_eval, zk_poly_lincomb, zk_kate_division), with
+either multi-open scheme (ProverGWC, ProverSHPLONK): the resident integration of INTEGRATION.md §2 executed.  Its bytes are zk_prove's for the same key, advice and
 seed — and, at the proving server's k = 17 shape with the EVM transcript + GWC, the fixture the reference's own Yul verifier
 accepts (tests/golden/engine_proof_k17_evm.json, tests/test_oracle_verifier.py)."""
 import json
@@ -37,17 +37,18 @@ def _run(tmp_path, p, seed, witness_seed, kinds):
         h = eng.poly(1 << p.degree)
         eng.upload_canonical(h, col)
         polys.append(h)
-    want = {kind: eng.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM if kind == "evm" else E.ZK_TRANSCRIPT_BLAKE2B, E.ZK_SCHEME_GWC)
-            for kind in kinds}
+    scheme_id = {"gwc": E.ZK_SCHEME_GWC, "shplonk": E.ZK_SCHEME_SHPLONK}
+    want = {(kind, scheme): eng.prove(pk, polys, seed, E.ZK_TRANSCRIPT_EVM if kind == "evm" else E.ZK_TRANSCRIPT_BLAKE2B, scheme_id[scheme])
+            for kind, scheme in kinds}
     eng.close()  # the host below is a process of its own with its own context
     got = {}
-    for kind in kinds:
-        out = tmp_path / ("proof_%s.bin" % kind)
+    for kind, scheme in kinds:
+        out = tmp_path / ("proof_%s_%s.bin" % (kind, scheme))
         r = subprocess.run([HOST, str(tmp_path / "srs.bin"), str(tmp_path / "pk.bin"), str(tmp_path / "advice.bin"), str(out),
                             str(p.degree), str(p.num_advice), str(p.num_lookup_advice), str(p.num_fixed), str(p.lookup_bits),
-                            str(p.idle_gate_columns), kind, seed.hex()], capture_output=True, text=True, timeout=600)
+                            str(p.idle_gate_columns), kind, seed.hex(), scheme], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
-        got[kind] = out.read_bytes()
+        got[(kind, scheme)] = out.read_bytes()
     return got, want
 
 
@@ -56,14 +57,16 @@ def _run(tmp_path, p, seed, witness_seed, kinds):
 def test_phase_level_host_proves_what_zk_prove_proves(tmp_path, shape):
     k, A, L, F, lb, idle = shape
     p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb, idle_gate_columns=idle)
-    got, want = _run(tmp_path, p, bytes(range(7, 39)), 0x5EED0019, ("evm", "blake2b"))
-    for kind in got:
-        assert got[kind] == want[kind], kind
+    # the reference's pairings (EVM + GWC: /prove_evm; Blake2b + SHPLONK: /prove and the bench) and the two crossed ones
+    got, want = _run(tmp_path, p, bytes(range(7, 39)), 0x5EED0019,
+                     (("evm", "gwc"), ("blake2b", "shplonk"), ("blake2b", "gwc"), ("evm", "shplonk")))
+    for key in got:
+        assert got[key] == want[key], key
 
 
 def test_phase_level_host_reproduces_the_yul_accepted_k17_proof(tmp_path):
     d = json.load(open(os.path.join(ROOT, "tests", "golden", "engine_proof_k17_evm.json")))
-    got, want = _run(tmp_path, zk.circuit.K17, bytes.fromhex(d["rng_seed"]), 0x5EED0019, ("evm",))
-    assert len(got["evm"]) == 2720
-    assert got["evm"] == want["evm"]
-    assert got["evm"].hex() == d["proof"]
+    got, want = _run(tmp_path, zk.circuit.K17, bytes.fromhex(d["rng_seed"]), 0x5EED0019, (("evm", "gwc"), ("blake2b", "shplonk")))
+    assert len(got[("evm", "gwc")]) == 2720 and len(got[("blake2b", "shplonk")]) == 1920  # ecdsa_bench.csv:4: both sizes of the k = 17 row
+    assert got == want
+    assert got[("evm", "gwc")].hex() == d["proof"]

@@ -1967,9 +1967,10 @@ ZK_API(zk_random_poly, (zk_ctx* c, const uint8_t chacha_key[32], uint64_t first_
     return ZK_OK;
 }
 
-// out = sum_j coeffs[j] * in[j] (- *sub0 on coefficient 0): the multi-open provers' linear combinations and h(X) = sum x^(n i) h_i
-ZK_API(zk_poly_lincomb, (zk_ctx* c, zk_poly out, const zk_poly* in, const uint64_t* coeffs, size_t count, const uint64_t* sub0), (c, out, in, coeffs, count, sub0)) {
-    if (!c || !in || !coeffs || count == 0) return ZK_EINVAL;
+// out = sum_j coeffs[j] * in[j] - (sub_low[0] + sub_low[1] X + ..): the multi-open provers' linear combinations (GWC subtracts the
+// combined evaluation, SHPLONK the combined remainder polynomial of a rotation set) and h(X) = sum x^(n i) h_i
+ZK_API(zk_poly_lincomb, (zk_ctx* c, zk_poly out, const zk_poly* in, const uint64_t* coeffs, size_t count, const uint64_t* sub_low, size_t n_low), (c, out, in, coeffs, count, sub_low, n_low)) {
+    if (!c || !in || !coeffs || count == 0 || n_low > 8 || (n_low && !sub_low)) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     auto oit = c->polys.find(out);
     if (oit == c->polys.end() || oit->second.n > 0xffffffffu) return ZK_EINVAL;
@@ -1999,9 +2000,9 @@ ZK_API(zk_poly_lincomb, (zk_ctx* c, zk_poly out, const zk_poly* in, const uint64
             a.unit[j] = a.c[j] == Fr::one();
         }
         done += take;
-        if (done == count && sub0) {
-            a.sub0 = 1;
-            memcpy(&a.sub0_val, sub0, 32);
+        if (done == count && n_low) {  // the low-degree polynomial subtracted from the first n_low coefficients
+            a.sub_low_n = (uint32_t)n_low;
+            memcpy(a.sub_low, sub_low, n_low * 32);
         }
         launch_lincomb(a, c->stream);
         first = false;
