@@ -43,6 +43,7 @@ struct zk_ctx {
     std::map<uint32_t, Fr*> twiddles;      // log_n -> w_{2^log_n}^i table (standard form: quotient, permutation kernels)
     std::map<uint32_t, Fr*> coset_points;  // zeta * w^i (standard form): the x of the quotient's permutation terms
     std::map<uint32_t, Fr*> twiddles_ntt;  // the same powers in the NTT's internal form (x 2^261, ntt.hip)
+    std::map<uint32_t, Fr> ninv;           // 1 / 2^log_n (host constant of the inverse transforms)
     std::map<uint32_t, Fr*> twiddles_ninv; // w^i / 2^log_n (standard form): the last pass of an inverse transform (ntt.hip NTT_FOLD)
     // SRS (the pointers below alias the members of `srs`, the owner)
     std::shared_ptr<SrsBlock> srs;

@@ -24,7 +24,7 @@ G1Affine g1_jac_to_affine_host(const G1Jac& p) {
         r.y = Fq::zero();
         return r;
     }
-    const Fq zi = fe_inv(p.z);
+    const Fq zi = fe_inv_fast(p.z);
     const Fq zi2 = fe_sqr(zi);
     r.x = fe_mul(p.x, zi2);
     r.y = fe_mul(p.y, fe_mul(zi2, zi));
@@ -1231,7 +1231,11 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
         job.pre[2] = c->zeta2;
     }
     if (inverse) {  // x 1/N, and for the coset also zeta^-(i mod 3) = {1, zeta^2, zeta}
-        const Fr ninv = fe_inv(fr_from_u64(N));
+        // 1 / N: a constant of the transform size, inverted once per context (19 us of Fermat on the launching thread per
+        // inverse transform before)
+        auto nit = c->ninv.find(log_n);
+        if (nit == c->ninv.end()) nit = c->ninv.emplace(log_n, fe_inv_fast(fr_from_u64(N))).first;
+        const Fr ninv = nit->second;
         job.has_post = 1;
         job.post[0] = ninv;
         job.post[1] = coset ? fe_mul(ninv, c->zeta2) : ninv;

@@ -56,10 +56,111 @@ inline Fr fr_root_of_unity_2_28() {
     return fe_pow(fr_from_u64(7), t);
 }
 
+// (the table is made once per process: the root alone is a 226-bit exponentiation, 19 us of host time that used to sit in front
+// of every proof and every seam call)
 inline Fr fr_omega(uint32_t k) {  // primitive 2^k-th root: ROOT^(2^(28-k))
-    Fr w = fr_root_of_unity_2_28();
-    for (uint32_t i = k; i < 28; i++) w = fe_sqr(w);
-    return w;
+    struct Table {
+        Fr w[29];
+        Table() {
+            w[28] = fr_root_of_unity_2_28();
+            for (int i = 27; i >= 0; i--) w[i] = fe_sqr(w[i + 1]);
+        }
+    };
+    static const Table t;  // (thread-safe since C++11)
+    return t.w[k <= 28 ? k : 28];
+}
+
+// ---- host-side inversion: binary extended Euclid on 4 x 64-bit limbs ----------------------------------------------------------
+// fe_inv (field.hip.h) is Fermat's a^(p-2): ~ 380 Montgomery products, ~ 19 us on a host core — and a lone proof makes some twenty
+// of them between its GPU phases (one per MSM pass for the affine forms, the grand products' batch inverse, SHPLONK's Lagrange
+// bases), the GPU idle meanwhile.  The inverse of an element is unique, so any algorithm gives the same bytes; this one takes
+// ~ 3 us.  Host only (data-dependent loops).
+namespace hostinv {
+struct U256 {
+    uint64_t w[4];
+};
+inline bool is_one(const U256& a) { return a.w[0] == 1 && !(a.w[1] | a.w[2] | a.w[3]); }
+inline bool is_zero(const U256& a) { return !(a.w[0] | a.w[1] | a.w[2] | a.w[3]); }
+inline bool ge(const U256& a, const U256& b) {
+    for (int i = 3; i >= 0; i--)
+        if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    return true;
+}
+inline uint64_t add(U256& a, const U256& b) {  // a += b, returns the carry out
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (unsigned __int128)a.w[i] + b.w[i];
+        a.w[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    return (uint64_t)c;
+}
+inline void sub(U256& a, const U256& b) {  // a -= b (a >= b)
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint64_t bi = b.w[i], t = a.w[i] - bi, r = t - borrow;
+        borrow = (a.w[i] < bi) | (t < borrow);
+        a.w[i] = r;
+    }
+}
+inline void shr1(U256& a, uint64_t top) {  // (top : a) >> 1
+    for (int i = 0; i < 3; i++) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 63);
+    a.w[3] = (a.w[3] >> 1) | (top << 63);
+}
+inline void halve_mod(U256& x, const U256& p) {  // x / 2 mod p (p odd, x < p)
+    if (x.w[0] & 1) {
+        const uint64_t c = add(x, p);
+        shr1(x, c);
+    } else {
+        shr1(x, 0);
+    }
+}
+inline void sub_mod(U256& a, const U256& b, const U256& p) {  // a = a - b mod p (a, b < p)
+    if (ge(a, b)) {
+        sub(a, b);
+    } else {
+        add(a, p);  // (no carry out of 256 bits: a + p - b < 2p < 2^255)
+        sub(a, b);
+    }
+}
+}  // namespace hostinv
+
+// the inverse of a Montgomery image a R, as a Montgomery image (a^-1 R); 0 -> 0 like fe_inv
+template <class PRM>
+inline Fe<PRM> fe_inv_fast(const Fe<PRM>& a) {
+    using namespace hostinv;
+    U256 p, u, v, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+    for (int i = 0; i < 4; i++) {
+        p.w[i] = (uint64_t)PRM::P[2 * i] | ((uint64_t)PRM::P[2 * i + 1] << 32);
+        u.w[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+    }
+    if (is_zero(u)) return Fe<PRM>::zero();
+    v = p;
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u.w[0] & 1)) {
+            shr1(u, 0);
+            halve_mod(x1, p);
+        }
+        while (!(v.w[0] & 1)) {
+            shr1(v, 0);
+            halve_mod(x2, p);
+        }
+        if (ge(u, v)) {
+            sub(u, v);
+            sub_mod(x1, x2, p);
+        } else {
+            sub(v, u);
+            sub_mod(x2, x1, p);
+        }
+    }
+    const U256& r = is_one(u) ? x1 : x2;  // (a R)^-1 = a^-1 R^-1 as a plain integer
+    Fe<PRM> t;
+    for (int i = 0; i < 4; i++) {
+        t.v[2 * i] = (uint32_t)r.w[i];
+        t.v[2 * i + 1] = (uint32_t)(r.w[i] >> 32);
+    }
+    const Fe<PRM> r2 = Fe<PRM>::r2();
+    return fe_mul(t, fe_mul(r2, r2));  // x R^3 / R: a^-1 R^-1 R^2 = a^-1 R
 }
 
 // halo2curves bn256 Fr::ZETA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23 [RECALLED constant; it is a

@@ -67,9 +67,12 @@ bool commit(zk_ctx* c, const Fr* poly, size_t len, int basis, G1Affine* out) {
 Fr fr_pow(Fr a, uint64_t e) { return fe_pow_u64(a, e); }
 
 Fr fr_delta() {  // 7^(2^28): generator of the odd-order subgroup
-    Fr d = fr_from_u64(7);
-    for (int i = 0; i < 28; i++) d = fe_sqr(d);
-    return d;
+    static const Fr delta = [] {
+        Fr d = fr_from_u64(7);
+        for (int i = 0; i < 28; i++) d = fe_sqr(d);
+        return d;
+    }();
+    return delta;
 }
 
 void fr_to_le_bytes(const Fr& mont, uint8_t out[32]) {
@@ -114,7 +117,7 @@ std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& pts) {
         pre[j] = run;
         run = fe_mul(run, den[j]);
     }
-    Fr inv = fe_inv(run);
+    Fr inv = fe_inv_fast(run);
     for (size_t j = m; j-- > 0;) {
         const Fr dj = fe_mul(inv, pre[j]);
         inv = fe_mul(inv, den[j]);
@@ -131,7 +134,7 @@ void jac_batch_to_affine(const G1Jac* js, uint32_t cnt, G1Affine* af) {
         pre[q] = run;
         if (!js[q].z.is_zero()) run = fe_mul(run, js[q].z);
     }
-    Fq inv = fe_inv(run);
+    Fq inv = fe_inv_fast(run);
     for (uint32_t q = cnt; q-- > 0;) {
         if (js[q].z.is_zero()) {
             af[q].x = Fq::zero();
@@ -618,12 +621,12 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
     q.gamma = fe_mul(gamma, k32);
     q.delta = fe_mul(fr_delta(), k32);
     // 1 / ((zeta w_ext^i)^n - 1): zeta^n * (w_ext^n)^i, w_ext^n is a primitive 4th root
-    const Fr zn = fe_pow_u64(c->zeta, lay.n);
-    const Fr w4 = fe_pow_u64(fr_omega(lay.ext_k), lay.n);
-    if (!pk->t_inv_ready) {  // constants of the key's domain: inverted once, not once per proof
+    if (!pk->t_inv_ready) {  // constants of the key's domain: made once, not once per proof
+        const Fr zn = fe_pow_u64(c->zeta, lay.n);
+        const Fr w4 = fe_pow_u64(fr_omega(lay.ext_k), lay.n);
         Fr cur = zn;
         for (int i = 0; i < 4; i++) {
-            pk->t_inv[i] = fe_inv(fe_sub(cur, Fr::one()));
+            pk->t_inv[i] = fe_inv_fast(fe_sub(cur, Fr::one()));
             cur = fe_mul(cur, w4);
         }
         pk->t_inv_ready = true;
@@ -1088,7 +1091,7 @@ struct Prover {
         if ((xside || c->msm_side) && (rc = ctx_lone_streams(c))) return rc;
         if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
         omega = fr_omega(lay.k);
-        omega_inv = fe_inv(omega);
+        omega_inv = fe_inv_fast(omega);
         tr->common_scalar(pk->transcript_repr);
         return ZK_OK;
     }
@@ -1327,7 +1330,7 @@ struct Prover {
                     run = fe_mul(run, q[p]);
                 }
                 if (fast) {
-                    Fr inv = fe_inv(run);
+                    Fr inv = fe_inv_fast(run);
                     for (uint32_t p = nprod; p-- > 0;) {
                         const Fr t = fe_mul(inv, qi[p]);
                         inv = fe_mul(inv, q[p]);
@@ -1648,7 +1651,7 @@ struct Prover {
         lincomb_many(pk->t_a, terms, true, sub);
         HT("L launched");
         launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
-        launch_scale(pk->t_b, fe_inv(z_diffs[0]), n, st);
+        launch_scale(pk->t_b, fe_inv_fast(z_diffs[0]), n, st);
         *out = pk->t_b;
         return rc;
     }
@@ -1801,7 +1804,7 @@ int phase_grand_products(zk_ctx* c, zk_pk_rec* pk, const std::vector<Fr*>& num, 
             run = fe_mul(run, q[p]);
         }
         if (fast) {
-            Fr inv = fe_inv(run);
+            Fr inv = fe_inv_fast(run);
             for (uint32_t p = nprod; p-- > 0;) {
                 const Fr t = fe_mul(inv, qi[p]);
                 inv = fe_mul(inv, q[p]);

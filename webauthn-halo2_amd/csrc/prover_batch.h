@@ -380,7 +380,7 @@ struct BatchRun {
                     run = fe_mul(run, qv[p]);
                 }
                 if (fast) {
-                    Fr inv = fe_inv(run);
+                    Fr inv = fe_inv_fast(run);
                     for (uint32_t p = np; p-- > 0;) {
                         const Fr t = fe_mul(inv, qi[p]);
                         inv = fe_mul(inv, qv[p]);
