@@ -488,7 +488,7 @@ def main():
                 torch.cuda.synchronize()
 
     for _ in range(1 if fake else max(1, (args.warmup * nfl + len(wl.warm) - 1) // len(wl.warm))):
-        wl.run(wl.warm)
+        wl.run_with_h2d(wl.warm)  # the timed region's own path: upload from the pinned staging buffer, then prove
     single_ms = None
     if not fake:
         barrier()
