@@ -99,6 +99,23 @@ def test_pass_width_does_not_change_proofs(cols, shape):
     eng.close()
 
 
+def test_more_lookups_than_one_permutation_launch_takes():
+    """Five proofs x twelve lookups = 60 lookups: more than one argument block of the lookup-permutation launches holds (56), so
+    the batch's lookups go through two groups of launches on consecutive slices of the scratch; 5 x 37 grand products in one scan."""
+    eng = zk.Engine(0)
+    B = 5
+    pk, sets, asgs, opk = _setup(eng, SHAPES["manycols"], [0x5EED0200 + i for i in range(B)])
+    rng_seeds = [bytes([90 + i]) * 32 for i in range(B)]
+    for kind in ("blake2b", "evm"):
+        got = eng.prove_batch(pk, sets, rng_seeds, KIND[kind])
+        for j in range(B):
+            assert got[j] == prover.create_proof(opk, asgs[j].advice, ChaCha20Rng(rng_seeds[j]), kind), (kind, j)
+    with pytest.raises(zk.ZkError) as e:  # 7 x 37 grand products: beyond the one-workgroup chain scan
+        eng.prove_batch(pk, sets + sets[:2], rng_seeds + rng_seeds[:2])
+    assert e.value.code == -1
+    eng.close()
+
+
 def test_batch_rejects_a_bad_witness_as_a_whole_and_recovers():
     """One proof's lookup input is off the table: the batch fails with ZK_EWITNESS (halo2: ConstraintSystemFailure), nothing
     is left in flight, and the same context proves the good jobs afterwards."""
