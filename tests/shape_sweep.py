@@ -52,6 +52,42 @@ def check_mid(eng, shape, wseed=None):
     eng.pk_free(pk)
 
 
+def check_batch(eng, shape, wseed=None, B=3):
+    """zk_prove_batch (lock-step) against zk_prove — whose bytes the checks above pin to the oracle — on B witnesses of the shape."""
+    import numpy as np
+
+    A, L, F, k, lb, idle = shape
+    n_adv = A if A == 1 else A + L
+    nprod = -(-(F + n_adv) // (3 if A == 1 else 2)) + (1 if A == 1 else L)
+    B = min(B, 256 // nprod)  # all grand products of a batch go through one 256-lane chain scan
+    if B < 2:
+        return
+    p = t.zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=L, num_fixed=F, lookup_bits=lb, idle_gate_columns=idle)
+    base = wseed if wseed is not None else 0x5EED2000 + 977 * A + k
+    asgs = [t.zk.circuit.synthesize(p, base + 13 * i) for i in range(B)]
+    eng.srs_setup(k)
+    pk = eng.keygen(p, np.stack([asgs[0].to_limbs(c) for c in asgs[0].fixed]), asgs[0].copies)
+    sets = []
+    for asg in asgs:
+        hs = []
+        for col in asg.advice:
+            h = eng.poly(1 << k)
+            eng.upload_canonical(h, asg.to_limbs(col))
+            hs.append(h)
+        sets.append(hs)
+    seeds = [bytes([k, (A + i) & 255, L, F]) * 8 for i in range(B)]
+    try:
+        for kind in ("blake2b", "evm"):
+            got = eng.prove_batch(pk, sets, seeds, t.KIND[kind])
+            for j in range(B):
+                assert got[j] == eng.prove(pk, sets[j], seeds[j], t.KIND[kind]), (shape, kind, j)
+    finally:
+        for hs in sets:
+            for h in hs:
+                h.free()
+        eng.pk_free(pk)
+
+
 def main():
     seed, count = int(sys.argv[1], 0), int(sys.argv[2])
     mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
@@ -63,6 +99,7 @@ def main():
                 t0 = time.time()
                 try:
                     check_mid(eng, shape, wseed=seed + 1000 * shape[3] + i)
+                    check_batch(eng, shape, wseed=seed + 1000 * shape[3] + i)
                     print("ok  ", shape, "witness", i, "%.1f s" % (time.time() - t0), flush=True)
                 except Exception as e:  # noqa: BLE001
                     bad += 1
@@ -74,6 +111,7 @@ def main():
         t0 = time.time()
         try:
             (check_mid if mid else t.test_random_shapes_byte_identical_to_oracle)(eng, shape)
+            check_batch(eng, shape if mid else (shape + (0,))[:6])
             print("ok  ", shape, "%.1f s" % (time.time() - t0), flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
