@@ -13,9 +13,19 @@ p = circuit.K17
 jobs = list(range(8))
 wit = batch.synthesize_jobs(p, jobs)
 fixed, copies = batch.structure(p)
+OPTS = [tuple(int(x) for x in o.split("=")) for o in os.environ.get("OPTS", "").split(",") if o]  # OPTS=5=1,2=4: zk_ctx_set_option
+
+
+def factory(dev):
+    e = E.Engine(dev)
+    for o, v in OPTS:
+        e.set_option(o, v)
+    return e
+
+
 for spec in (sys.argv[1:] or ["1", "2", "3", "4"]):
     npipe, ls = (int(x) for x in (spec.split("x") + ["1"])[:2])
-    pipes = [batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True)]
+    pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True)]
     for _ in range(npipe - 1):
         pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
     for pl in pipes:
@@ -37,6 +47,6 @@ for spec in (sys.argv[1:] or ["1", "2", "3", "4"]):
     [t.start() for t in ths]
     [t.join() for t in ths]
     dt = time.perf_counter() - t0
-    print(f"k=17 EVM, {npipe} pipelines x lock-step {ls}: {npipe * reps / dt:6.1f} proofs/s ({dt / reps * 1e3:.2f} ms per proof and pipeline)", flush=True)
+    print(f"k=17 EVM OPTS={os.environ.get('OPTS', '-')}, {npipe} pipelines x lock-step {ls}: {npipe * reps / dt:6.1f} proofs/s ({dt / reps * 1e3:.2f} ms per proof and pipeline)", flush=True)
     for pl in pipes[::-1]:
         pl.close()
