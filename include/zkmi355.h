@@ -65,6 +65,9 @@ int zk_device_count(void);
 /* PCI address of a device ("0000:c1:00.0", cap >= 16): /sys/bus/pci/devices/<id>/{numa_node,local_cpulist} name its NUMA node —
  * an 8-GPU host binds each GPU's worker threads and staging buffers there (bench.py does) */
 int zk_device_pci_bus_id(int device_id, char* out, size_t cap);
+/* free and total device memory in bytes (hipMemGetInfo): a host sizes the number of resident proof pipelines by it (a k = 19
+ * pipeline is ~ 5.3 GiB beside the first one's 6.4, docs in DESIGN.md section 2) */
+int zk_device_mem_info(int device_id, size_t* free_bytes, size_t* total_bytes);
 /* page-locked host memory for buffers handed to zk_poly_upload / zk_poly_upload_canonical (one DMA at the bus rate instead of a
  * staged copy out of pageable memory); NULL on failure */
 void* zk_host_alloc(size_t bytes);
@@ -98,7 +101,8 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         pipelines 103.7 proofs/s on one stream each against 99.1 with a side stream each) */
 #define ZK_OPT_MSM_TAIL_MAIN_ABOVE 6 /* the auto threshold above, 1..64; 0 restores the measured default (2, for the runtime's default
                                         of four hardware queues: two contexts x two streams fill them) */
-#define ZK_OPT_BATCH_PASS_COLUMNS 7  /* zk_prove_batch: columns per MSM pass, 1..256; 0 = min(2 x batch, 8) */
+#define ZK_OPT_BATCH_PASS_COLUMNS 7  /* zk_prove_batch: columns per MSM pass, 1..256; 0 = max(min(2 x batch, 8), the single prover's pass width).
+                                         The lanes' MSM workspaces grow to that width on their next pass and KEEP it for the life of the context */
 #define ZK_OPT_XFORM_STREAM 8        /* zk_prove: where a proof's column transforms (values -> coefficients -> extended coset) run:
                                         0 auto (beside the MSM passes on a stream of their own while this is the only active context
                                         of the process on the device — a lone proof —, in order on the main stream otherwise: see
@@ -343,6 +347,11 @@ int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canoni
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
 /* accumulated HIP-event time and launch count since the last reset (ZK_T_MSM, ZK_T_MSM_ACCUM) */
 int zk_timer_reset(zk_ctx* ctx);
+/* shader-clock probe: one wave spins for `millis` (1..2000) on a chain of dependent multiply-adds; out[0] = ticks of the shader-clock
+ * counter (s_memtime), out[1] = ticks of the constant 100 MHz counter (s_memrealtime) over the same interval, out[2] = multiply-adds
+ * issued, out[3] = scratch.  sclk = out[0] / out[1] x 100 MHz.  Called on a context of its own while other contexts prove, it
+ * reads the clock the chip sustains UNDER that load (bench.py: roofline.valu_issue) */
+int zk_clock_probe(zk_ctx* ctx, uint32_t millis, uint64_t out[4]);
 int zk_timer_stats(zk_ctx* ctx, int which, double* total_ms, uint64_t* count);
 
 #ifdef __cplusplus

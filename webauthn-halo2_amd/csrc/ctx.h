@@ -63,8 +63,8 @@ struct zk_ctx {
     uint32_t opt_msm_window = 0, opt_msm_batch = 0, opt_ntt_max_r = 0, opt_gp_batch_invert = 0;
     uint32_t opt_tail_stream = 0;  // ZK_OPT_MSM_TAIL_STREAM: 0 auto, 1 always the context's tail stream, 2 always the main stream
     uint32_t opt_tail_main_above = 0;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE: auto mode puts the tails on the main stream with MORE than this many contexts active on the device (0 = the measured default, 2)
-    uint32_t opt_batch_pass_cols = 0;  // ZK_OPT_BATCH_PASS_COLUMNS: columns per MSM pass of a lock-step batch (0 = min(2 B, 8))
-    uint32_t msm_min_cols = 0;         // the lanes' fixed-base workspaces take at least this many columns per pass (raised by zk_prove_batch)
+    uint32_t opt_batch_pass_cols = 0;  // ZK_OPT_BATCH_PASS_COLUMNS: columns per MSM pass of a lock-step batch (0 = max(min(2 B, 8), the single prover's pass width))
+    uint32_t msm_min_cols = 0;         // the lanes' fixed-base workspaces take at least this many columns per pass (raised by zk_prove_batch, never lowered: the wider workspaces are kept)
     int act_slot = -1;             // this context's slot in its device's activity table (engine.hip ctx_activity_*)
     // The context's TAIL stream (round 4: one, shared by the lanes; rounds 2-3 had one per lane).  Where a pass's reduction tail
     // runs is decided per pass (ctx_msm_begin_batch): on this stream while at most two contexts are ACTIVE on the device (have

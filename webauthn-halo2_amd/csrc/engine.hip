@@ -389,6 +389,19 @@ ZK_API(zk_device_pci_bus_id, (int device_id, char* out, size_t cap), (device_id,
     return ZK_OK;
 }
 
+// free / total memory of a device: what a host sizes its number of resident pipelines by (ecdsa_p256.py)
+ZK_API(zk_device_mem_info, (int device_id, size_t* free_bytes, size_t* total_bytes), (device_id, free_bytes, total_bytes)) {
+    if (!free_bytes || !total_bytes) return ZK_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ENODEV;
+    if (device_id < 0 || device_id >= ndev) return ZK_EINVAL;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device_id) != hipSuccess) return ZK_EHIP;
+    const hipError_t e = hipMemGetInfo(free_bytes, total_bytes);
+    hipSetDevice(prev);
+    return e == hipSuccess ? ZK_OK : ZK_EHIP;
+}
+
 // page-locked host memory for the buffers a host hands to zk_poly_upload*: the copy is then one DMA at the bus rate instead of
 // the runtime's staged copy out of pageable memory (allocate on the thread that is bound to the GPU's NUMA node)
 void* zk_host_alloc(size_t bytes) {
@@ -571,6 +584,46 @@ ZK_API(zk_last_kernel_ms, (zk_ctx* c, int which, float* out_ms), (c, which, out_
     if (rc) return rc;
     HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
     HIPCHK(c, hipEventElapsedTime(out_ms, c->ev[which][0], c->ev[which][1]));
+    return ZK_OK;
+}
+
+// ---- shader-clock probe (bench.py's roofline.valu_issue): ONE wave spins for `ticks` of the constant 100 MHz counter
+// (s_memrealtime) on a chain of dependent v_mad_u64_u32 and reports what the shader-clock counter (s_memtime) advanced by in
+// the same interval.  Run on a context of its own WHILE the workload proves, it reads the clock the chip sustains under that
+// load (a lone probe on an idle chip reads the boost clock).  out[0] = shader-clock ticks, out[1] = 100 MHz ticks, out[2] =
+// multiply-adds of the chain (one wave, nothing to interleave with: ticks / mads = the multiplier's dependent latency)
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t ticks, uint64_t* __restrict__ out) {
+    uint64_t acc = threadIdx.x + 1;
+    uint32_t a = 0x9e3779b9u + threadIdx.x, b = 0x7f4a7c15u;
+    const uint64_t r0 = wall_clock64();
+    const uint64_t c0 = clock64();
+    uint64_t iters = 0;
+    while (wall_clock64() - r0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 256; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+        iters += 256;
+    }
+    const uint64_t c1 = clock64();
+    const uint64_t r1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+        out[2] = iters;
+        out[3] = acc;  // (keeps the chain alive)
+    }
+}
+
+ZK_API(zk_clock_probe, (zk_ctx* c, uint32_t millis, uint64_t out[4]), (c, millis, out)) {
+    if (!c || !out || millis == 0 || millis > 2000) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_bind(c);
+    if (rc) return rc;
+    uint64_t* d = reinterpret_cast<uint64_t*>(c->small);         // device scratch of the context (8 field elements)
+    uint64_t* h = reinterpret_cast<uint64_t*>(c->host_small);    // its pinned twin
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, (uint64_t)millis * 100000ull, d);
+    HIPCHK(c, hipMemcpyAsync(h, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, h, 4 * sizeof(uint64_t));
     return ZK_OK;
 }
 

@@ -140,6 +140,83 @@ template <bool SER>
 __device__ __forceinline__ void mad29c(uint64_t& acc, uint32_t a, uint32_t c) { acc += (uint64_t)a * c; }
 #endif
 static constexpr bool MUL29_SER = ZK_MUL29_ASM != 0;
+// ZK_MUL29_ASM = 2: the serial form with a whole column's multiply-adds in ONE asm statement.  hipcc's hazard recogniser
+// assumes that any inline asm may have the gfx940 "dst_sel forwarding" hazard and puts an s_nop behind every statement whose
+// result the next instruction reads: 1 358 s_nop per mixed addition with one statement per multiply-add (hipcc -S of
+// msm_wacc_fast_kernel), about 300 with one per column part.  v_mad_u64_u32 has no such hazard.
+static constexpr bool MUL29_BLOCK = ZK_MUL29_ASM == 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+// acc += sum_{i < cnt} x[i] * y[i], cnt <= 9 a constant after unrolling (the switch folds)
+__device__ __forceinline__ void madcol_v(uint64_t& acc, int cnt, const uint32_t (&x)[9], const uint32_t (&y)[9]) {
+    switch (cnt) {
+    case 1: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]) : "vcc"); break;
+    case 2: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc"); break;
+    case 3: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]) : "vcc"); break;
+    case 4: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc"); break;
+    case 5: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]) : "vcc"); break;
+    case 6: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]) : "vcc"); break;
+    case 7: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]) : "vcc"); break;
+    case 8: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t" "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc"); break;
+    case 9: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t" "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t" "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t" : "+v"(acc) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]) : "vcc"); break;
+    default: break;
+    }
+}
+// the same with y in scalar registers (compile-time constants: the limbs of p)
+__device__ __forceinline__ void madcol_c(uint64_t& acc, int cnt, const uint32_t (&x)[9], const uint32_t (&y)[9]) {
+    switch (cnt) {
+    case 1: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]) : "vcc"); break;
+    case 2: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]) : "vcc"); break;
+    case 3: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]) : "vcc"); break;
+    case 4: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]) : "vcc"); break;
+    case 5: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]) : "vcc"); break;
+    case 6: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]) : "vcc"); break;
+    case 7: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]) : "vcc"); break;
+    case 8: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t" "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]) : "vcc"); break;
+    case 9: asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t" "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t" "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t" "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t" "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t" "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t" "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t" "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t" "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t" : "+v"(acc) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]) : "vcc"); break;
+    default: break;
+    }
+}
+#else
+__device__ __forceinline__ void madcol_v(uint64_t& acc, int cnt, const uint32_t (&x)[9], const uint32_t (&y)[9]) {
+    for (int i = 0; i < cnt; i++) acc += (uint64_t)x[i] * y[i];
+}
+__device__ __forceinline__ void madcol_c(uint64_t& acc, int cnt, const uint32_t (&x)[9], const uint32_t (&y)[9]) {
+    for (int i = 0; i < cnt; i++) acc += (uint64_t)x[i] * y[i];
+}
+#endif
+// column helpers: sum_{i = lo}^{hi} a_i b_{k - i} and sum_{i = lo}^{hi} m_i p_{k - i}, one statement each in the block form
+template <class PRM, bool SER>
+__device__ __forceinline__ void col_ab(uint64_t& acc, const uint32_t (&a)[9], const uint32_t (&b)[9], int k, int lo, int hi) {
+    if constexpr (SER && MUL29_BLOCK) {
+        uint32_t x[9], y[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = lo + i <= hi ? lo + i : lo;
+            x[i] = a[j];
+            y[i] = b[k - j];
+        }
+        madcol_v(acc, hi - lo + 1, x, y);
+    } else {
+#pragma unroll
+        for (int i = lo; i <= hi; i++) mad29<SER>(acc, a[i], b[k - i]);
+    }
+}
+template <class PRM, bool SER>
+__device__ __forceinline__ void col_mp(uint64_t& acc, const uint32_t (&m)[9], int k, int lo, int hi) {
+    if constexpr (SER && MUL29_BLOCK) {
+        uint32_t x[9], y[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = lo + i <= hi ? lo + i : lo;
+            x[i] = m[j];
+            y[i] = Lim29<PRM>::P[k - j];
+        }
+        madcol_c(acc, hi - lo + 1, x, y);
+    } else {
+#pragma unroll
+        for (int i = lo; i <= hi; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+    }
+}
 
 // a * b * 2^-261 mod p, lazily: result limbs < 2^29, value < p * (1 + k_a k_b / 169.4)
 template <class PRM, bool SER = MUL29_SER>
@@ -149,20 +226,16 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-        for (int i = 0; i < k; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+        col_ab<PRM, SER>(acc, a.l, b.l, k, 0, k);
+        if (k) col_mp<PRM, SER>(acc, m, k, 0, k - 1);
         m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
         mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+        col_ab<PRM, SER>(acc, a.l, b.l, k, k - 8, 8);
+        col_mp<PRM, SER>(acc, m, k, k - 8, 8);
         r.l[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
@@ -181,24 +254,18 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-        for (int i = 0; i <= k; i++) mad29<SER>(acc, c.l[i], d.l[k - i]);
-#pragma unroll
-        for (int i = 0; i < k; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+        col_ab<PRM, SER>(acc, a.l, b.l, k, 0, k);
+        col_ab<PRM, SER>(acc, c.l, d.l, k, 0, k);
+        if (k) col_mp<PRM, SER>(acc, m, k, 0, k - 1);
         m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
         mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29<SER>(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29<SER>(acc, c.l[i], d.l[k - i]);
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+        col_ab<PRM, SER>(acc, a.l, b.l, k, k - 8, 8);
+        col_ab<PRM, SER>(acc, c.l, d.l, k, k - 8, 8);
+        col_mp<PRM, SER>(acc, m, k, k - 8, 8);
         r.l[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
@@ -217,17 +284,32 @@ __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
 #pragma unroll
     for (int k = 0; k < 17; k++) {
         // sum_{i + j = k, i < j} (2 a_i) a_j + [k even] a_{k/2}^2
+        if constexpr (SER && MUL29_BLOCK) {
+            uint32_t x[9], y[9];
+            int cnt = 0;
 #pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) mad29<SER>(acc, a2[i], a.l[k - i]);
-        if ((k & 1) == 0) mad29<SER>(acc, a.l[k / 2], a.l[k / 2]);
+            for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) {
+                x[cnt] = a2[i];
+                y[cnt] = a.l[k - i];
+                cnt++;
+            }
+            if ((k & 1) == 0) {
+                x[cnt] = a.l[k / 2];
+                y[cnt] = a.l[k / 2];
+                cnt++;
+            }
+            madcol_v(acc, cnt, x, y);
+        } else {
+#pragma unroll
+            for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) mad29<SER>(acc, a2[i], a.l[k - i]);
+            if ((k & 1) == 0) mad29<SER>(acc, a.l[k / 2], a.l[k / 2]);
+        }
         if (k < 9) {
-#pragma unroll
-            for (int i = 0; i < k; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+            if (k) col_mp<PRM, SER>(acc, m, k, 0, k - 1);
             m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
             mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         } else {
-#pragma unroll
-            for (int i = k - 8; i < 9; i++) mad29c<SER>(acc, m[i], Lim29<PRM>::P[k - i]);
+            col_mp<PRM, SER>(acc, m, k, k - 8, 8);
             r.l[k - 9] = (uint32_t)acc & M29;
         }
         acc >>= 29;

@@ -36,9 +36,12 @@
 #include <vector>
 
 // This file's products on the carry-free field keep the source order of their multiply-adds (field29.hip.h ZK_MUL29_ASM):
-// the accumulation runs four waves per SIMD (below), enough to hide a serial column, and saves the 64-bit join per column
+// the accumulation runs four waves per SIMD (below), enough to hide a serial column, and saves the 64-bit join per column.
+// Round 6: = 2, a column part per asm statement instead of a multiply-add per statement — hipcc's hazard recogniser puts an
+// s_nop behind every asm statement whose result the next instruction reads (1 358 per mixed addition, 283 now): the lone 2^19
+// accumulation 0.572 -> 0.553 / 0.580 -> 0.566 ms, two columns 1.058 -> 1.040 / 1.069 -> 1.033 (profiles/r6_ab_block_asm.txt)
 #ifndef ZK_MUL29_ASM
-#define ZK_MUL29_ASM 1
+#define ZK_MUL29_ASM 2
 #endif
 // ... except in the reduction kernels, which run about one wave per SIMD: their additions wait on that serial chain, not on
 // issue slots, and take the compiler's form (g1x29_add<false>; tools/tail_times.sh, per lone k = 19 proof: msm_wrowcol

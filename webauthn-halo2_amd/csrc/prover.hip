@@ -726,6 +726,9 @@ ZK_API(zk_pk_set_transcript_repr, (zk_ctx* c, zk_pk h, const uint64_t transcript
         if (i == 0) return ZK_EINVAL;
     }
     it->second->transcript_repr = v;
+    // the lock-step members are by-value copies of the record (pk_make_member): every key-half field that can change after
+    // they were made has to be written through to them, or proofs j > 0 of the next batch would hash the stale value
+    for (zk_pk_rec* m : it->second->members) m->transcript_repr = v;
     return ZK_OK;
 }
 
@@ -1671,6 +1674,31 @@ struct Prover {
 
 }  // namespace
 
+// Leaves the context as every entry point expects to find it — no commitment in flight, the side streams drained and their
+// flags cleared, the main stream idle — on EVERY way out of a whole-proof call, including an exception thrown inside the
+// prover (std::bad_alloc from its vectors: ZK_API turns it into ZK_EINTERNAL after this destructor has run)
+namespace {
+struct ProveQuiesce {
+    zk_ctx* c;
+    explicit ProveQuiesce(zk_ctx* ctx) : c(ctx) {}
+    ProveQuiesce(const ProveQuiesce&) = delete;
+    ProveQuiesce& operator=(const ProveQuiesce&) = delete;
+    void settle() {
+        ctx_msm_drain(c);  // an early error may leave commitments in flight
+        if (c->msm_side) {
+            hipStreamSynchronize(c->msm_stream);
+            c->msm_side = false;
+        }
+        if (c->xform_pending) {  // (an early error before the quotient: transforms still in flight)
+            hipStreamSynchronize(c->xform_stream);
+            c->xform_pending = false;
+        }
+        hipStreamSynchronize(c->stream);
+    }
+    ~ProveQuiesce() { settle(); }
+};
+}  // namespace
+
 ZK_API(zk_proof_size, (zk_ctx* c, zk_pk pkh, int transcript, int scheme, size_t* out), (c, pkh, transcript, scheme, out)) {
     if (!c || !out) return ZK_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
@@ -1714,17 +1742,10 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     Blake2bTranscript b2;
     Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
     Prover p(c, pk, rng_seed, tr);
-    rc = p.run(adv.data(), scheme);
-    ctx_msm_drain(c);  // an early error may leave commitments in flight
-    if (c->msm_side) {
-        hipStreamSynchronize(c->msm_stream);
-        c->msm_side = false;
+    {
+        ProveQuiesce quiesce(c);  // (declared after the prover: it settles the streams while the prover's host buffers are alive)
+        rc = p.run(adv.data(), scheme);
     }
-    if (c->xform_pending) {  // (an early error before the quotient: transforms still in flight)
-        hipStreamSynchronize(c->xform_stream);
-        c->xform_pending = false;
-    }
-    hipStreamSynchronize(c->stream);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;
     *proof_len = tr->out.size();
@@ -1826,6 +1847,21 @@ int phase_grand_products(zk_ctx* c, zk_pk_rec* pk, const std::vector<Fr*>& num, 
 }
 }  // namespace
 
+namespace {
+// every output vector of a phase call is written by its own blocks of a batched launch: the same vector twice among the
+// outputs, or an output that another item of the call reads, is a data race that yields garbage — refused before anything is
+// launched
+bool phase_outputs_ok(const std::vector<const Fr*>& outs, const std::vector<const Fr*>& ins) {
+    for (size_t i = 0; i < outs.size(); i++) {
+        for (size_t j = i + 1; j < outs.size(); j++)
+            if (outs[i] == outs[j]) return false;
+        for (const Fr* v : ins)
+            if (outs[i] == v) return false;
+    }
+    return true;
+}
+}  // namespace
+
 ZK_API(zk_lookup_permute, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, zk_poly* permuted_input, zk_poly* permuted_table, size_t n_lookups), (c, h, advice, n_advice, permuted_input, permuted_table, n_lookups)) {
     if (!c || !advice || !permuted_input || !permuted_table) return ZK_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1836,14 +1872,16 @@ ZK_API(zk_lookup_permute, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_a
     if (n_lookups != lay.n_lookups) return ZK_EINVAL;
     LkPtrs lp;
     memset(&lp, 0, sizeof(lp));
+    std::vector<const Fr*> outs, ins(P.adv.begin(), P.adv.end());
     for (uint32_t l = 0; l < lay.n_lookups; l++) {
         Fr *a = phase_vec(c, permuted_input[l], lay.n), *s = phase_vec(c, permuted_table[l], lay.n);
-        if (!a || !s || a == s) return ZK_EINVAL;
-        for (const Fr* v : P.adv)
-            if (v == a || v == s) return ZK_EINVAL;
+        if (!a || !s) return ZK_EINVAL;
         lp.ap[l] = a;
         lp.sp[l] = s;
+        outs.push_back(a);
+        outs.push_back(s);
     }
+    if (!phase_outputs_ok(outs, ins)) return ZK_EINVAL;  // (a'[l] = s'[m], a repeated handle, an advice column as an output)
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemsetAsync(P.pk->lks.err, 0, 4, st));
     for (uint32_t l = 0; l < lay.n_lookups; l++) lp.inp[l] = phase_lookup_input(P, l);
@@ -1868,17 +1906,24 @@ ZK_API(zk_lookup_product, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_a
     memcpy(&g, gamma, 32);
     std::vector<Fr*> num, den, z;
     std::vector<uint32_t> chain;
+    std::vector<const Fr*> outs, ins(P.adv.begin(), P.adv.end()), av, sv;
     for (uint32_t l = 0; l < lay.n_lookups; l++) {
         const Fr *a = phase_vec(c, permuted_input[l], lay.n), *s = phase_vec(c, permuted_table[l], lay.n);
         Fr* zl = phase_vec(c, z_out[l], lay.n);
-        if (!a || !s || !zl || zl == a || zl == s) return ZK_EINVAL;
-        for (const Fr* v : P.adv)
-            if (v == zl) return ZK_EINVAL;
+        if (!a || !s || !zl) return ZK_EINVAL;
+        av.push_back(a);
+        sv.push_back(s);
+        ins.push_back(a);
+        ins.push_back(s);
+        outs.push_back(zl);
+        z.push_back(zl);
+    }
+    if (!phase_outputs_ok(outs, ins)) return ZK_EINVAL;  // (before the first launch: a repeated z, or a z that some lookup reads)
+    for (uint32_t l = 0; l < lay.n_lookups; l++) {
         const Fr* inp = phase_lookup_input(P, l);
-        launch_lk_numden(a, s, inp, pk->fixed_val[lay.fx_table], b, g, pk->gp_num[l], pk->gp_den[l], lay.n, c->stream);
+        launch_lk_numden(av[l], sv[l], inp, pk->fixed_val[lay.fx_table], b, g, pk->gp_num[l], pk->gp_den[l], lay.n, c->stream);
         num.push_back(pk->gp_num[l]);
         den.push_back(pk->gp_den[l]);
-        z.push_back(zl);
         chain.push_back(0);
     }
     return phase_grand_products(c, pk, num, den, z, chain);
@@ -1902,11 +1947,17 @@ ZK_API(zk_permutation_product, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_
     std::vector<uint32_t> chain;
     const Fr delta = fr_delta();
     Fr dcur = Fr::one();
+    {
+        std::vector<const Fr*> outs, ins(P.adv.begin(), P.adv.end());
+        for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
+            const Fr* zc = phase_vec(c, z_out[ci], lay.n);
+            if (!zc) return ZK_EINVAL;
+            outs.push_back(zc);
+        }
+        if (!phase_outputs_ok(outs, ins)) return ZK_EINVAL;  // (before the first launch: a repeated z, an advice column as z)
+    }
     for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
         Fr* zc = phase_vec(c, z_out[ci], lay.n);
-        if (!zc) return ZK_EINVAL;
-        for (const Fr* v : P.adv)
-            if (v == zc) return ZK_EINVAL;
         PermArgs a;
         memset(&a, 0, sizeof(a));
         a.n = lay.n;
@@ -2056,10 +2107,9 @@ ZK_API(zk_prove_batch, (zk_ctx* c, zk_pk h, size_t batch, const zk_poly* advice,
     }
     {
         BatchRun run(c, pk, P, cap);
+        ProveQuiesce quiesce(c);
         rc = run.run(adv.data(), scheme);
     }
-    ctx_msm_drain(c);  // an early error may leave commitments in flight
-    hipStreamSynchronize(c->stream);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;
     const size_t len = trs[0]->out.size();

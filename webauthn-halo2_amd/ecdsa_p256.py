@@ -47,6 +47,24 @@ _STATE_LOCK = threading.RLock()  # set-up / tear-down of a device's resident sta
 # want too (batch.py, bench.py).  A request that arrives alone still proves alone: pipeline 0 is taken first.
 PIPELINES_PER_DEVICE = 4
 _MAX_SLOT_SETS = 4  # parked request-slot sets per column count: the server's usual number of requests in flight per device
+# Resident bytes per pipeline by degree (tools/mem_footprint.py: SRS + window tables are shared, every pipeline keeps its own
+# key, prover workspace and three MSM lanes), plus the request-slot sets it may park (_MAX_SLOT_SETS advice sets of 32 B x n)
+_PIPELINE_BYTES = {17: 2.0 * 2**30, 18: 3.2 * 2**30, 19: 5.3 * 2**30, 20: 10.5 * 2**30, 21: 21.0 * 2**30}
+
+
+def pipelines_for(degree: int, device: int = 0) -> int:
+    """How many pipelines a device gets at this degree: PIPELINES_PER_DEVICE, fewer when they would not leave a quarter of the
+    device's FREE memory to everything else (another process's contexts, lock-step members: 1.4 GiB each at k = 19)."""
+    from .engine import device_mem_info
+
+    want = max(1, PIPELINES_PER_DEVICE)
+    per = _PIPELINE_BYTES.get(degree, _PIPELINE_BYTES[21] * (1 << max(0, degree - 21)) if degree > 21 else _PIPELINE_BYTES[17])
+    per += _MAX_SLOT_SETS * 32 * (1 << degree)
+    try:
+        free, _ = device_mem_info(device)
+    except Exception:
+        return want
+    return max(1, min(want, int(0.75 * free // per)))
 
 
 def _config_for(degree: int) -> circuit.CircuitParams:
@@ -75,6 +93,27 @@ def _drain(st):
     st["free"] = None
 
 
+class _Hold:
+    """Every pipeline of a device taken out of its free queue for the duration of a `with` block (requests in flight finish
+    first, new ones wait): a key can be freed and replaced without a request proving under it.  The indices go back into the
+    same queue object, pipeline 0 on top."""
+
+    def __init__(self, st):
+        self.q, self.n = st.get("free"), 1 + len(st["extra"])
+
+    def __enter__(self):
+        if self.q is not None:
+            for _ in range(self.n):
+                self.q.get()
+        return self
+
+    def __exit__(self, *exc):
+        if self.q is not None:
+            for i in range(self.n - 1, -1, -1):
+                self.q.put(i)
+        return False
+
+
 def gen_srs(degree: int, device: int = 0) -> Engine:
     """halo2-base `gen_srs(k)`: ParamsKZG::setup(k, ChaCha20Rng::from_seed([0; 32])), kept resident."""
     with _STATE_LOCK:
@@ -101,7 +140,7 @@ def _gen_srs_locked(degree, device):
         st["extra"] = []
         st["eng"].srs_setup(degree, bytes(32))
         st["k"] = degree
-        st["extra"] = [{"eng": Engine(device, share_with=st["eng"]), "keys": {}, "slots": {}} for _ in range(max(1, PIPELINES_PER_DEVICE) - 1)]
+        st["extra"] = [{"eng": Engine(device, share_with=st["eng"]), "keys": {}, "slots": {}} for _ in range(pipelines_for(degree, device) - 1)]
         st["free"] = queue.LifoQueue()
         for i in range(len(st["extra"]), -1, -1):  # pipeline 0 (the first context) on top: a lone request takes it
             st["free"].put(i)
@@ -137,24 +176,28 @@ def download_keys(degree: int, proving_key_path=None, verifying_key_path=None, d
     (registered under `proving_key_path`; a key already registered under that name is freed first); the
     verifying key is written to `verifying_key_path` if given, as the reference writes it
     (`vk.to_bytes(SerdeFormat::RawBytes)`, ecdsa_p256.rs:266-270: the VerifyingKey::write image of zk_vk_write)."""
-    eng = gen_srs(degree, device)
     p = _config_for(degree)
     asg = circuit.synthesize(p, 0)  # structure only: fixed columns and copy constraints
     fixed = np.stack([asg.to_limbs(c) for c in asg.fixed])
-    st = _STATE[device]
-    keys = st["keys"]
-    name = proving_key_path or "<default>"
-    if name in keys:  # /setup called again: the resident key (GBs at k = 17 / 19) is replaced, not leaked
-        eng.pk_free(keys.pop(name)[1])
-    pk = eng.keygen(p, fixed, asg.copies)
-    keys[name] = (p, pk)
-    for m in st["extra"]:  # every further pipeline of the device holds the key too (its own workspace comes with it)
-        if name in m["keys"]:
-            m["eng"].pk_free(m["keys"].pop(name))
-        m["keys"][name] = m["eng"].keygen(p, fixed, asg.copies)
-    if verifying_key_path:
-        with open(verifying_key_path, "wb") as f:
-            f.write(eng.vk_write(pk).tobytes())
+    with _STATE_LOCK:  # (one set-up / tear-down of a device's state at a time)
+        eng = _gen_srs_locked(degree, device)
+        st = _STATE[device]
+        keys = st["keys"]
+        name = proving_key_path or "<default>"
+        # /setup called again while requests are proving: they finish under the old key first — the pipelines are held while the
+        # resident key (GBs at k = 17 / 19) is freed and replaced, not leaked and not pulled from under a proof
+        with _Hold(st):
+            if name in keys:
+                eng.pk_free(keys.pop(name)[1])
+            pk = eng.keygen(p, fixed, asg.copies)
+            keys[name] = (p, pk)
+            for m in st["extra"]:  # every further pipeline of the device holds the key too (its own workspace comes with it)
+                if name in m["keys"]:
+                    m["eng"].pk_free(m["keys"].pop(name))
+                m["keys"][name] = m["eng"].keygen(p, fixed, asg.copies)
+        if verifying_key_path:
+            with open(verifying_key_path, "wb") as f:
+                f.write(eng.vk_write(pk).tobytes())
     return pk
 
 

@@ -34,6 +34,15 @@ def device_pci_bus_id(device=0):
     return buf.value.decode().lower()
 
 
+def device_mem_info(device=0):
+    """(free, total) bytes of a device's memory (zk_device_mem_info)."""
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = load_library().zk_device_mem_info(device, ctypes.byref(free), ctypes.byref(total))
+    if rc:
+        raise ZkError(rc, "zk_device_mem_info")
+    return free.value, total.value
+
+
 class PinnedArray:
     """A numpy array over page-locked host memory (zk_host_alloc): the buffers a host hands to upload / upload_canonical.
     Keep the object alive while `a` is in use; free() (or garbage collection) returns the memory."""
@@ -93,6 +102,7 @@ def load_library():
     sig = {
         "zk_device_count": ([], ctypes.c_int),
         "zk_device_pci_bus_id": ([ctypes.c_int, ctypes.c_char_p, sz], ctypes.c_int),
+        "zk_device_mem_info": ([ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)], ctypes.c_int),
         "zk_host_alloc": ([sz], vp),
         "zk_host_free": ([vp], None),
         "zk_ctx_create": ([ctypes.c_int, ctypes.POINTER(vp)], ctypes.c_int),
@@ -130,6 +140,7 @@ def load_library():
         "zk_kate_division": ([vp, ctypes.c_uint64, u64p, ctypes.c_uint64], ctypes.c_int),
         "zk_timer_reset": ([vp], ctypes.c_int),
         "zk_timer_stats": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_clock_probe": ([vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, sz, ctypes.POINTER(ctypes.c_uint32), sz,
                        ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_pk_set_transcript_repr": ([vp, ctypes.c_uint64, u64p], ctypes.c_int),
@@ -475,6 +486,12 @@ class Engine:
         t, n = ctypes.c_double(), ctypes.c_uint64()
         self._chk(self.L.zk_timer_stats(self.ctx, which, ctypes.byref(t), ctypes.byref(n)), "zk_timer_stats")
         return t.value, n.value
+
+    def clock_probe(self, millis=100):
+        """(shader-clock ticks, 100 MHz ticks, dependent multiply-adds issued) over ~`millis` ms of one spinning wave (zk_clock_probe)."""
+        out = (ctypes.c_uint64 * 4)()
+        self._chk(self.L.zk_clock_probe(self.ctx, millis, out), "zk_clock_probe")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def last_ms(self, which):
         v = ctypes.c_float()
