@@ -7,6 +7,9 @@ runs on the GPU box), tests/test_gpu_prover.py proves a slice of the batch throu
 
 Run in the build container (about 15 s per job on 8 cores; resumable: jobs already in the file are skipped):
     python tests/golden/make_batch_hashes.py [first [count]]
+    python tests/golden/make_batch_hashes.py 0 40 k17evm      -> batch_k17_evm_sha256.json
+Round 6: `k17evm` makes the same table for the PROVING SERVER's configuration (k = 17, EVM transcript + GWC, 2 720-byte proofs,
+proving-server/src/main.rs:17,64-79): the 40 jobs bench.py's `k17_evm_proofs_per_sec` proves and compares.
 Only expected outputs are stored; the inputs are regenerated from the seeds."""
 import hashlib
 import json
@@ -29,9 +32,14 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "batch_k19_sha256
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    p = zk.circuit.K19
+    k17 = len(sys.argv) > 3 and sys.argv[3] == "k17evm"
+    global OUT
+    p = zk.circuit.K17 if k17 else zk.circuit.K19
+    kind, size = ("evm", 2720) if k17 else ("blake2b", 960)
+    if k17:
+        OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "batch_k17_evm_sha256.json")
     sh = plonk.Shape(p.degree, p.num_advice, p.num_lookup_advice, p.num_fixed, p.lookup_bits)
-    out = json.load(open(OUT)) if os.path.exists(OUT) else {"degree": p.degree, "transcript": "blake2b", "multiopen": "shplonk", "sha256": {}}
+    out = json.load(open(OUT)) if os.path.exists(OUT) else {"degree": p.degree, "transcript": kind, "multiopen": "gwc" if k17 else "shplonk", "sha256": {}}
     asg0 = zk.circuit.synthesize(p, 0)
     pk = fp.keygen(sh, asg0.fixed, asg0.copies)
     for j in range(first, first + count):
@@ -39,10 +47,10 @@ def main():
             continue
         t0 = time.time()
         asg = zk.circuit.synthesize(p, batch.job_seed(j))
-        proof = fp.create_proof(pk, asg.advice, ChaCha20Rng(batch.job_rng_seed(j)), "blake2b")
-        assert len(proof) == 960
+        proof = fp.create_proof(pk, asg.advice, ChaCha20Rng(batch.job_rng_seed(j)), kind)
+        assert len(proof) == size
         if j % 16 == 0:
-            assert plonk.verify(pk.vk, proof, "blake2b"), j
+            assert plonk.verify(pk.vk, proof, kind), j
         out["sha256"][str(j)] = hashlib.sha256(proof).hexdigest()
         with open(OUT + ".tmp", "w") as f:
             json.dump(out, f, indent=0, sort_keys=True)

@@ -266,3 +266,58 @@ def test_keygen_refuses_selector_layouts_halo2_would_compress_differently():
         eng.keygen(many_idle, limbs(good[:F + 1 + 1]), copies2)  # 2 * 2 > 3
     assert e.value.code == -8
     eng.close()
+
+
+def test_phase_calls_refuse_repeated_output_handles():
+    """Round-5 advice: the batched launches behind zk_lookup_permute / zk_lookup_product / zk_permutation_product write every output
+    vector from its own blocks — the same vector twice among the outputs (or an output that another item of the call reads) is a
+    data race, so it is ZK_EINVAL before anything is launched; distinct handles pass."""
+    import ctypes
+
+    eng = zk.Engine(0)
+    L = eng.L
+    A, Lk, F, k, lb = 3, 2, 1, 8, 6  # two lookups, two permutation chunks
+    p = zk.circuit.CircuitParams(degree=k, num_advice=A, num_lookup_advice=Lk, num_fixed=F, lookup_bits=lb)
+    asg = zk.circuit.synthesize(p, 0x5EED0019)
+    eng.srs_setup(k)
+    pk = eng.keygen(p, np.stack([asg.to_limbs(c) for c in asg.fixed]), asg.copies)
+    n = 1 << k
+    adv = []
+    for col in asg.advice:
+        h = eng.poly(n)
+        eng.upload_canonical(h, asg.to_limbs(col))
+        adv.append(h)
+    outs = [eng.poly(n) for _ in range(6)]
+    u64 = ctypes.c_uint64
+
+    def arr(hs):
+        return (u64 * len(hs))(*[h.h for h in hs])
+
+    advh = arr(adv)
+    one = (u64 * 4)(1, 0, 0, 0)
+    vp = ctypes.c_void_p
+    sz = ctypes.c_size_t
+    L.zk_lookup_permute.argtypes = [vp, u64, ctypes.POINTER(u64), sz, ctypes.POINTER(u64), ctypes.POINTER(u64), sz]
+    L.zk_lookup_product.argtypes = [vp, u64, ctypes.POINTER(u64), sz, ctypes.POINTER(u64), ctypes.POINTER(u64), sz, ctypes.POINTER(u64),
+                                    ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.zk_permutation_product.argtypes = [vp, u64, ctypes.POINTER(u64), sz, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), sz]
+    for f in (L.zk_lookup_permute, L.zk_lookup_product, L.zk_permutation_product):
+        f.restype = ctypes.c_int
+    EINVAL = -1
+    # a'[0] == s'[1]; a'[0] == a'[1]; an advice column among the outputs
+    assert L.zk_lookup_permute(eng.ctx, pk, advh, len(adv), arr([outs[0], outs[1]]), arr([outs[2], outs[0]]), 2) == EINVAL
+    assert L.zk_lookup_permute(eng.ctx, pk, advh, len(adv), arr([outs[0], outs[0]]), arr([outs[2], outs[3]]), 2) == EINVAL
+    assert L.zk_lookup_permute(eng.ctx, pk, advh, len(adv), arr([outs[0], adv[0]]), arr([outs[2], outs[3]]), 2) == EINVAL
+    assert L.zk_lookup_permute(eng.ctx, pk, advh, len(adv), arr(outs[0:2]), arr(outs[2:4]), 2) == 0
+    # zL twice; a zL that another lookup of the call reads as its a'
+    ai, si = arr(outs[0:2]), arr(outs[2:4])
+    assert L.zk_lookup_product(eng.ctx, pk, advh, len(adv), ai, si, 2, one, one, arr([outs[4], outs[4]])) == EINVAL
+    assert L.zk_lookup_product(eng.ctx, pk, advh, len(adv), ai, si, 2, one, one, arr([outs[4], outs[0]])) == EINVAL
+    assert L.zk_lookup_product(eng.ctx, pk, advh, len(adv), ai, si, 2, one, one, arr(outs[4:6])) == 0
+    # the permutation's z of two chunks in one vector
+    nchunks = (F + A + Lk + 1) // 2
+    assert nchunks >= 2
+    zs = [eng.poly(n) for _ in range(nchunks)]
+    assert L.zk_permutation_product(eng.ctx, pk, advh, len(adv), one, one, arr([zs[0]] * nchunks), nchunks) == EINVAL
+    assert L.zk_permutation_product(eng.ctx, pk, advh, len(adv), one, one, arr(zs), nchunks) == 0
+    eng.close()

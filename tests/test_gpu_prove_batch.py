@@ -172,3 +172,22 @@ def test_k19_lockstep_batches_equal_committed_oracle_digests():
         assert hashlib.sha256(pf).hexdigest() == want[str(j)], j
     for pl in pipes[::-1]:
         pl.close()
+
+
+def test_transcript_repr_set_between_batches_reaches_every_member():
+    """zk_pk_set_transcript_repr AFTER a batch has made the key's member records (by-value copies of the key record): the next
+    batch's proofs j > 0 must hash the new value too — every proof equals zk_prove under the same key (round-5 advice: the
+    members kept the value they were copied with, and proofs 1 .. B - 1 silently stopped verifying)."""
+    eng = zk.Engine(0)
+    B = 3
+    pk, sets, asgs, opk = _setup(eng, SHAPES["k17like"], [0x5EED0300 + i for i in range(B)])
+    rng_seeds = [bytes([60 + i]) * 32 for i in range(B)]
+    first = eng.prove_batch(pk, sets, rng_seeds, E.ZK_TRANSCRIPT_EVM)  # (creates the members)
+    assert first == [eng.prove(pk, sets[j], rng_seeds[j], E.ZK_TRANSCRIPT_EVM) for j in range(B)]
+    other = np.array([0x1234, 0x5678, 0x9ABC, 0x0DEF], dtype=np.uint64)  # any Montgomery image < r
+    eng.pk_set_transcript_repr(pk, other)
+    for tr in (E.ZK_TRANSCRIPT_EVM, E.ZK_TRANSCRIPT_BLAKE2B):
+        lone = [eng.prove(pk, sets[j], rng_seeds[j], tr) for j in range(B)]
+        assert eng.prove_batch(pk, sets, rng_seeds, tr) == lone
+        assert lone[0] != first[0]  # (the new value is in the transcript)
+    eng.close()
