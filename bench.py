@@ -468,40 +468,50 @@ def clock_under_load(wl, device, jobs):
     return res
 
 
+UBENCH_NOMINAL_GHZ = 2.4  # tools/ubench_isa.hip turns its measured time into "cycles" with hipDeviceProp.clockRate = 2.4 GHz
+
+
 def valu_issue_roofline(ms_per_proof, clock):
     """VALU issue as the first-class roofline of this path (round-5 review): none of the kernels is bound by HBM, all of them by
     the issue of their own integer instructions.  Instructions per proof and per kernel = SQ_INSTS_VALU of the committed counter
-    pass of this workload (profiles/*_proof_k19_pmc_valu.csv, tools/pmc_valu.sh: the difference of a 40-proof and an 8-proof run);
-    a kernel's instructions are priced at the mix-weighted issue cycles of its own text (profiles/*_isa_mix.csv, tools/isa_mix.py,
-    class rates measured in profiles/r2_ubench_isa.txt); the chip offers SIMDS x sclk issue cycles per second, sclk measured in
-    THIS run under load.  floor_ms = the proof's instruction stream at 100 % issue; frac = floor_ms / measured ms per proof."""
+    pass of this workload (profiles/*_proof_k19_pmc_valu.csv, tools/pmc_valu.sh: the difference of a 5-proof and a 1-proof run);
+    a kernel's instructions are priced at the mix-weighted issue TIME of its own text (profiles/*_isa_mix.csv, tools/isa_mix.py):
+    the class rates of profiles/r2_ubench_isa.txt are times per wave-instruction per SIMD measured with every SIMD issuing (the
+    file prints them as cycles of the nominal 2.4 GHz; the chip's effective clock under such load is whatever it was then and is
+    now — the calibration carries it).  floor_ms = the proof's instruction stream at 100 % issue on 1 024 SIMDs; frac = floor_ms /
+    measured ms per proof.  The clocks measured in this run (zk_clock_probe) are reported beside it."""
     import csv
 
     pmc, mix = _newest("*_proof_k19_pmc_valu.csv"), _newest("*_isa_mix.csv")
-    if not pmc or not mix or not clock or not clock.get("sclk_mhz"):
+    if not pmc or not mix:
         return None
     cpi = {_kname(r["kernel"]): float(r["issue_cycles_per_valu_instruction"]) for r in csv.DictReader(open(mix))}
-    rows, instr, cycles = [], 0.0, 0.0
+    rows, instr, cycles, gui, dur = [], 0.0, 0.0, 0.0, 0.0
     for r in csv.DictReader(open(pmc)):
         k = _kname(r["kernel"])
         i = float(r["SQ_INSTS_VALU_per_proof"])
         c = cpi.get(k, 2.5)
         instr += i
         cycles += i * c
+        if "msm_wacc_fast" in k:
+            gui, dur = float(r.get("GRBM_GUI_ACTIVE_per_proof", 0) or 0), float(r.get("duration_ns_per_proof_under_the_profiler", 0) or 0)
         rows.append({"kernel": k, "launches_per_proof": float(r["launches_per_proof"]), "instr_per_proof": i,
-                     "issue_cycles_per_instr": c, "simd_cycles_per_proof": i * c})
+                     "issue_cycles_per_instr_at_2.4GHz": c, "simd_ns_per_proof": i * c / UBENCH_NOMINAL_GHZ})
     if not instr:
         return None
     for r in rows:
-        r["share_of_cycles"] = r["simd_cycles_per_proof"] / cycles
-    sclk_hz = clock["sclk_mhz"] * 1e6
-    floor_ms = cycles / (SIMDS * sclk_hz) * 1e3
-    return {"bound": "int-valu issue (wave64 instructions per SIMD)", "instr_per_proof": instr, "simd_cycles_per_proof": cycles,
-            "mix_weighted_cycles_per_instr": cycles / instr, "simds": SIMDS, "sclk_mhz": clock["sclk_mhz"],
-            "issue_slots_per_s": SIMDS * sclk_hz / (cycles / instr), "floor_ms": floor_ms, "ms_per_proof": ms_per_proof,
-            "frac": floor_ms / ms_per_proof, "by_kernel": sorted(rows, key=lambda r: -r["simd_cycles_per_proof"])[:16],
-            "source": "instructions: %s (committed counter pass, NOT this run); class rates: %s + profiles/r2_ubench_isa.txt; "
-                      "clock: this run" % (os.path.basename(pmc), os.path.basename(mix))}
+        r["share_of_issue_time"] = r["simd_ns_per_proof"] * UBENCH_NOMINAL_GHZ / cycles
+    floor_ms = cycles / UBENCH_NOMINAL_GHZ / SIMDS * 1e-6
+    return {"bound": "int-valu issue (wave64 instructions per SIMD)", "instr_per_proof": instr,
+            "mix_weighted_ns_per_instr": cycles / instr / UBENCH_NOMINAL_GHZ, "simds": SIMDS,
+            "issue_slots_per_s": SIMDS / (cycles / instr / UBENCH_NOMINAL_GHZ * 1e-9), "floor_ms": floor_ms, "ms_per_proof": ms_per_proof,
+            "frac": floor_ms / ms_per_proof,
+            "sclk_mhz_probe_under_load": (clock or {}).get("sclk_mhz"), "sclk_mhz_probe_idle": (clock or {}).get("idle_mhz"),
+            "sclk_mhz_grbm_accumulate_under_profiler": (gui / 8.0 / dur * 1e3) if dur else None,
+            "by_kernel": sorted(rows, key=lambda r: -r["simd_ns_per_proof"])[:16],
+            "source": "instructions: %s (committed counter pass, NOT this run); class rates: %s + profiles/r2_ubench_isa.txt (times per "
+                      "wave-instruction per SIMD, printed there as cycles at the nominal 2.4 GHz); clocks: zk_clock_probe in this run, "
+                      "GRBM_GUI_ACTIVE / 8 XCDs / kernel time in the counter pass" % (os.path.basename(pmc), os.path.basename(mix))}
 
 
 def k17_worker(args):
@@ -717,23 +727,32 @@ def main():
     jobs_exactly_once = covered == list(range(world * args.steps))
     assert jobs_exactly_once, "the ranks' jobs do not partition 0 .. world x steps - 1"
     launcher = {"launcher": "torchrun" if dist is not None else "in-process", "jobs_covered_exactly_once": jobs_exactly_once,
+                "ranks_share_device": bool(args.one_device and world > 1),
                 "numa_binding": numa,
                 "dist_backend": (dist.get_backend() if dist is not None else None), "ms_per_step_per_rank": per_rank_ms,
                 # timed proofs (all ranks) whose bytes were compared with the oracle's committed digests: all of them for the
                 # 256-job batch of configs[3]
                 "proofs_checked_against_oracle_digests": oracle_checked}
 
-    def timed(fn):
+    pass_ranks = [per_rank_ms]  # every timed pass's per-rank clocks; the line carries the median pass's
+
+    def timed(fn, record=True):
         """One more timed pass over the same K jobs (same barriers, max-over-ranks clock) -> whole-job proofs/s."""
         barrier()
         t1 = time.perf_counter()
         fn(wl.jobs[:args.steps])
         barrier()
         dt = time.perf_counter() - t1
+        mine_ms = [dt / args.steps * 1e3]
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
+            ev = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(ev, tt)
+            mine_ms = [float(x.item()) / args.steps * 1e3 for x in ev]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        if record:
+            pass_ranks.append(mine_ms)
         return world * args.steps / dt
 
     # Four further timed repeats of the same region (after `value`'s): the median and the spread say how large a
@@ -742,12 +761,14 @@ def main():
     # one rounds 1-5 reported, in practice the slowest: clocks and caches settle during it — stays beside it as `value_first`.
     repeats = [world * args.steps / elapsed] + [timed(wl.run_with_h2d) for _ in range(0 if fake else 4)]
     value = sorted(repeats)[len(repeats) // 2]
+    launcher["ms_per_step_per_rank"] = pass_ranks[repeats.index(value)]  # the median pass's (first pass: ms_per_step_per_rank_first)
+    launcher["ms_per_step_per_rank_first"] = per_rank_ms
     launcher["value_first"] = repeats[0]
     launcher["value_repeats"] = repeats
     launcher["value_median"] = value
     launcher["value_spread_pct"] = (max(repeats) - min(repeats)) / (sum(repeats) / len(repeats)) * 100.0
     if not fake:
-        launcher["value_advice_resident"] = timed(wl.run)  # the columns already in HBM (rounds 1-4 reported this as `value`)
+        launcher["value_advice_resident"] = timed(wl.run, record=False)  # the columns already in HBM (rounds 1-4 reported this as `value`)
 
     if rank == 0 and fake:
         print(json.dumps({"metric": "webauthn_es256_proofs_per_sec_k19", "value": value,

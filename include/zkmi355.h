@@ -46,7 +46,8 @@ extern "C" {
 #define ZK_ESTATE (-5)   /* missing prerequisite (SRS / key not loaded) */
 #define ZK_EWITNESS (-6) /* witness violates the circuit (lookup input not in table): halo2's
                             Error::ConstraintSystemFailure */
-#define ZK_EINTERNAL (-7) /* a C++ exception was stopped at the boundary (nothing is ever thrown across it) */
+#define ZK_EINTERNAL (-7) /* a C++ exception was stopped at the boundary (nothing is ever thrown across it), or — under ZK_OPT_STREAM_AUDIT — the
+                            stream audit found an enqueue that is not ordered after the buffers it touches (zk_audit_report) */
 #define ZK_ELAYOUT (-8)  /* zk_keygen / zk_pk_read: the selector columns do not fit the layout the key is built for — halo2's
                             compress_selectors would combine them differently (two used gate selectors that share no row, a used
                             selector that is never enabled, an "idle" one that is; or 2 * num_idle_gate_columns > num_advice:
@@ -111,6 +112,18 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         for a lone proof — with ZK_OPT_XFORM_STREAM's auto rule: main, tail, transform and MSM stream are
                                         the runtime's four hardware queues —, so that the glue kernels of the next phase do not queue
                                         behind an accumulation), 1 always that stream, 2 always the main stream */
+#define ZK_OPT_MSM_T1 10             /* first kernel of the MSM reduction tail (the sum of a bucket's partial sums): 0 auto — one lane per
+                                        bucket (fewest instructions, longer dependent chain) for a pass whose tail runs on its head's stream,
+                                        i.e. while three or more proofs are in flight on the device, parts of <= 8 partial sums + a segmented
+                                        tree (shorter chain) otherwise; 1 always per bucket; 2 always per part.  Same bytes either way */
+#define ZK_OPT_STREAM_AUDIT 11       /* debug: 1 switches on the happens-before ledger of the context's streams (csrc/audit.h): every enqueue
+                                        names the buffers it reads and writes, and one whose stream is not ordered after the buffer's last
+                                        writer (or, for a write, its last readers) makes the entry point return ZK_EINTERNAL instead of ZK_OK —
+                                        the class of bug that yields wrong proof bytes once in a thousand runs shows on the first run that takes
+                                        the faulty path.  zk_audit_report tells what was found.  0 (default) switches it off; 2 = the
+                                        audit's self-test: on, AND zk_prove takes a knowingly unordered path (its column transforms alternate
+                                        between two streams per call without ordering their shared scratch — round 5's first form): every
+                                        proof whose transforms come in more than one call must then return ZK_EINTERNAL */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------
@@ -346,6 +359,9 @@ int zk_poly_upload_canonical(zk_ctx* ctx, zk_poly p, const uint64_t* host_canoni
 #define ZK_T_COUNT 8
 int zk_last_kernel_ms(zk_ctx* ctx, int which, float* out_ms);
 /* accumulated HIP-event time and launch count since the last reset (ZK_T_MSM, ZK_T_MSM_ACCUM) */
+/* ZK_OPT_STREAM_AUDIT: counts[0] = ordering checks made since the option was switched on, counts[1] = violations; msg (may be NULL)
+ * receives the description of the first violation (empty if none) */
+int zk_audit_report(zk_ctx* ctx, uint64_t counts[2], char* msg, size_t cap);
 int zk_timer_reset(zk_ctx* ctx);
 /* shader-clock probe: one wave spins for `millis` (1..2000) on a chain of dependent multiply-adds; out[0] = ticks of the shader-clock
  * counter (s_memtime), out[1] = ticks of the constant 100 MHz counter (s_memrealtime) over the same interval, out[2] = multiply-adds

@@ -643,6 +643,21 @@ def cpu_baseline(k, budget_s=30.0):
         T["srs_setup_s"] = t_srs
         return T
 
+    def config0():
+        """BASELINE.json configs[0]: bench_secp256r1_ecdsa at k = 17 (bench_ecdsa.config row 3: A = 4, L = 1, F = 1, lookup_bits
+        16), Blake2b + SHPLONK, CPU only — the one configuration the reference itself runs without a GPU (cargo test in
+        halo2-circuits/, ecdsa_p256.rs:553-564); here the oracle's port of it, one whole proof of 1 920 bytes."""
+        p = circuit.K17
+        asg = circuit.synthesize(p, 0x5EED0019)
+        sh = Shape(p.degree, p.num_advice, p.num_lookup_advice, p.num_fixed, p.lookup_bits)
+        cm = Committer(p.degree, "msm")
+        pk = keygen(sh, asg.fixed, asg.copies, cm)
+        cm.seconds, cm.count = 0.0, 0
+        T = {}
+        proof = create_proof(pk, [arr(c) for c in asg.advice], ChaCha20Rng(bytes(32)), "blake2b", committer=cm, timings=T)
+        assert len(proof) == 1920  # halo2-circuits/src/results/ecdsa_bench.csv row k = 17
+        return T
+
     cores = os.cpu_count() or 1
     cal = calibrate(18)  # at (nearly) the workload's size: the best team size depends on the chunk length
     t17 = one(17) if k > 17 else None
@@ -655,14 +670,22 @@ def cpu_baseline(k, budget_s=30.0):
         T = t17
         total = t17["total"] * scale
         sample = "one whole k=17 proof (%.2f s), scaled x%.2f to k=%d by row count (MSM ~ n, FFT ~ n log n)" % (t17["total"], scale, k)
+    per_leg = {"msm": cal["msm_threads"], "fft": cal["fft_threads"], "vector_ops": cal["vector_threads"]}
+    t0c = config0()
+    k17 = {"value": 1.0 / t0c["total"], "unit": "proofs/s", "proof_s": t0c["total"], "cores": per_leg, "kind": "port",
+           "sample": "one whole k=17 proof of BASELINE configs[0] (A=4, L=1, F=1, Blake2b + SHPLONK, 1 920 bytes): MSM x %d %.2f s, FFT %.2f s, "
+                     "evaluate_h %.2f s, multi-open %.2f s; oracle CPU port (the reference's own cargo test cannot be built here)"
+                     % (t0c.get("msm_count", 0), t0c.get("msm", 0.0), t0c.get("fft", 0.0), t0c.get("evaluate_h", 0.0), t0c.get("multiopen", 0.0))}
     return {
         "value": 1.0 / total,
         "unit": "proofs/s",
-        # threads actually used, per leg (the MSM leg is ~55 % of the proof's time); `cores` = the largest team.  The host has
+        # threads actually used, PER LEG (the MSM leg is ~55 % of the proof's time; round 5 reported their maximum).  The host has
         # `host_cores`; `threads.sweep` holds the measured time of each leg at every team size tried ({all cores, 64, 32, 16}),
         # i.e. why fewer than all cores are used where they are (thread-chunked Pippenger loses window efficiency on small chunks)
-        "cores": max(cal["msm_threads"], cal["fft_threads"], cal["vector_threads"]),
-        "cores_per_leg": {"msm": cal["msm_threads"], "fft": cal["fft_threads"], "vector_ops": cal["vector_threads"]},
+        "cores": per_leg,
+        "cores_max": max(per_leg.values()),
+        "cores_per_leg": per_leg,
+        "k17": k17,
         "threads": cal,
         "kind": "port",
         "proof_s": total,

@@ -226,3 +226,36 @@ def test_wide_commit_with_25_bit_table_indexes(windowed):
     assert cops.affine_arr_to_ints(eng.commit(pb, 0))[0] == tau_commit(b)
     pa.free()
     pb.free()
+
+
+@pytest.mark.parametrize("k", [13, 16])
+def test_t1_per_bucket_and_per_part_give_the_same_commitments(windowed, k):
+    """ZK_OPT_MSM_T1 (round 6): the reduction tail's first kernel as one lane per bucket (msm_wbucket_kernel; buckets with more
+    than 24 partial sums stay with the part kernel) against parts of <= 8 + a segmented tree (msm_wparts_kernel) — the tau-oracle's
+    commitments either way, for uniformly random columns (every bucket small), witness-like ones (a few giant buckets: both
+    kernels of the per-bucket form take part), the all-in-one-bucket column and the zero column, alone and in one batched pass."""
+    from webauthn_halo2_amd import engine as E
+
+    eng = windowed(16)
+    n = 1 << k
+    eng.srs_setup(k)
+    rng = np.random.default_rng(77 + k)
+    pr = random.Random(k)
+    mix = cops.fr_mont([pr.randrange(1 << 18) if pr.random() < 0.5 else pr.randrange(F.R) if pr.random() < 0.6 else 0 for _ in range(n)])
+    boolc = cops.fr_mont([pr.randrange(2) for _ in range(n)])
+    ones = cops.fr_mont([sum(1 << (16 * w) for w in range(15))] * n)
+    data = [rand_col(rng, n), rand_col(rng, n), mix, boolc, ones, np.zeros((n, 4), dtype=np.uint64)]
+    polys = [eng.poly(n, d) for d in data]
+    want = [tau_commit(d) for d in data]
+    try:
+        for mode in (1, 2, 0):
+            eng.set_option(E.ZK_OPT_MSM_T1, mode)
+            for j, p in enumerate(polys):
+                assert cops.affine_arr_to_ints(eng.commit(p, 0))[0] == want[j], (mode, k, j)
+            got = eng.commit_batch(polys, 0)
+            for j in range(len(polys)):
+                assert cops.affine_arr_to_ints(got[j:j + 1])[0] == want[j], (mode, k, "batch", j)
+    finally:
+        eng.set_option(E.ZK_OPT_MSM_T1, 0)
+        for p in polys:
+            p.free()

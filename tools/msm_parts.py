@@ -10,6 +10,9 @@ k = int(os.environ.get("K", "19"))
 n = 1 << k
 rng = np.random.default_rng(7)
 eng = zk.Engine(0)
+for o in os.environ.get("OPTS", "").split(","):  # OPTS=10=1,5=2: zk_ctx_set_option before the SRS is loaded
+    if o:
+        eng.set_option(*[int(x) for x in o.split("=")])
 eng.srs_setup(k)
 cols = []
 for i in range(2):
@@ -17,7 +20,7 @@ for i in range(2):
     a[:, 3] &= 0x0FFFFFFFFFFFFFFF
     cols.append(eng.poly(n, a))
 want = [eng.commit(c, 1).copy() for c in cols]
-tag = os.path.basename(os.environ.get("ZKMI355_LIB", "base"))
+tag = os.path.basename(os.environ.get("ZKMI355_LIB", "base")) + (" OPTS=" + os.environ["OPTS"] if os.environ.get("OPTS") else "")
 for cnt in (1, 2):
     eng.timer_reset()
     t0 = time.perf_counter()

@@ -9,6 +9,7 @@
 
 #include "../../include/zkmi355.h"
 #include "engine.h"
+#include "audit.h"
 #include "hostutil.h"
 
 using namespace zk;
@@ -39,6 +40,8 @@ struct zk_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     int last_hip = 0;
+    StreamAudit audit;  // ZK_OPT_STREAM_AUDIT (audit.h): the happens-before ledger of this context's streams, off by default
+    bool audit_fault = false;  // ZK_OPT_STREAM_AUDIT = 2: the audit's self-test (the prover takes a knowingly unordered path)
     std::mutex mu;
     std::map<uint32_t, Fr*> twiddles;      // log_n -> w_{2^log_n}^i table (standard form: quotient, permutation kernels)
     std::map<uint32_t, Fr*> coset_points;  // zeta * w^i (standard form): the x of the quotient's permutation terms
@@ -86,6 +89,7 @@ struct zk_ctx {
     hipEvent_t ev_msm_in = nullptr;
     bool msm_side = false;          // set by the prover for the duration of a proof
     uint32_t opt_msm_stream = 0;    // ZK_OPT_MSM_STREAM: 0 auto, 1 side stream, 2 main stream
+    uint32_t opt_msm_t1 = 0;        // ZK_OPT_MSM_T1: 0 auto, 1 one lane per bucket, 2 parts + segmented tree (msm.hip msm_wbucket_kernel)
     hipStream_t xform_stream = nullptr;
     hipEvent_t ev_rows = nullptr, ev_xform = nullptr;
     bool xform_pending = false;
@@ -140,6 +144,32 @@ struct zk_ctx {
 
 // Every `extern "C"` entry point is defined through ZK_API: the body runs inside a try block, so that no C++
 // exception (std::bad_alloc from the host-side containers, anything else) crosses the C boundary.
+// the cross-stream calls of the engine go through these: the HIP call, and the ledger's twin of it when the audit is on
+static inline hipError_t aud_record(zk_ctx* c, hipEvent_t ev, hipStream_t st) {
+    const hipError_t e = hipEventRecord(ev, st);
+    c->audit.record(ev, st);
+    return e;
+}
+static inline hipError_t aud_wait(zk_ctx* c, hipStream_t st, hipEvent_t ev) {
+    const hipError_t e = hipStreamWaitEvent(st, ev, 0);
+    c->audit.wait(st, ev);
+    return e;
+}
+static inline hipError_t aud_sync(zk_ctx* c, hipStream_t st) {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) c->audit.host_stream(st);
+    return e;
+}
+static inline hipError_t aud_esync(zk_ctx* c, hipEvent_t ev) {
+    const hipError_t e = hipEventSynchronize(ev);
+    if (e == hipSuccess) c->audit.host_event(ev);
+    return e;
+}
+// an entry point's verdict under the audit: a violation recorded while it ran turns ZK_OK into ZK_EINTERNAL
+static inline int aud_verdict(zk_ctx* c, uint64_t violations_before, int rc) {
+    return (rc == ZK_OK && c->audit.on && c->audit.violations != violations_before) ? ZK_EINTERNAL : rc;
+}
+
 #define ZK_API(name, params, args)                          \
     static int name##_impl params;                          \
     extern "C" int name params {                            \

@@ -43,7 +43,7 @@ int ctx_bind(zk_ctx* c) {
 
 int ctx_ensure_scratch(zk_ctx* c, size_t n) {
     if (c->scratch_n >= n) return ZK_OK;
-    if (c->xform_stream) hipStreamSynchronize(c->xform_stream);  // (transforms in flight use the buffer)
+    if (c->xform_stream) aud_sync(c, c->xform_stream);  // (transforms in flight use the buffer)
     if (c->scratch) hipFree(c->scratch);
     c->scratch = nullptr;
     c->scratch_n = 0;
@@ -67,7 +67,7 @@ int ctx_get_twiddles(zk_ctx* c, uint32_t log_n, const Fr** out) {
     const size_t n = (size_t)1 << log_n;
     if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     launch_twiddles(tw, fr_omega(log_n), (uint32_t)n, c->stream);
-    hipStreamSynchronize(c->stream);  // made once per context and size; read from any of the context's streams afterwards
+    aud_sync(c, c->stream);  // made once per context and size; read from any of the context's streams afterwards
     c->twiddles[log_n] = tw;
     *out = tw;
     return ZK_OK;
@@ -84,7 +84,7 @@ int ctx_get_twiddles_ntt(zk_ctx* c, uint32_t log_n, const Fr** out) {
     const size_t n = (size_t)1 << log_n;
     if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     launch_twiddles_internal(tw, fr_omega(log_n), (uint32_t)n, c->stream);
-    hipStreamSynchronize(c->stream);  // made once per context and size; read from any of the context's streams afterwards
+    aud_sync(c, c->stream);  // made once per context and size; read from any of the context's streams afterwards
     c->twiddles_ntt[log_n] = tw;
     *out = tw;
     return ZK_OK;
@@ -101,7 +101,7 @@ int ctx_get_twiddles_ninv(zk_ctx* c, uint32_t log_n, const Fr** out) {
     const size_t n = (size_t)1 << log_n;
     if (hipMalloc(&tw, n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
     launch_twiddles_scaled(tw, fr_omega(log_n), fe_inv(fr_from_u64(n)), (uint32_t)n, c->stream);
-    hipStreamSynchronize(c->stream);  // made once per context and size; read from any of the context's streams afterwards
+    aud_sync(c, c->stream);  // made once per context and size; read from any of the context's streams afterwards
     c->twiddles_ninv[log_n] = tw;
     *out = tw;
     return ZK_OK;
@@ -178,8 +178,8 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     // columns per pass the workspace must take: the single prover's batches, or a lock-step batch's wider passes
     const uint32_t cols = table_window ? std::max(batch_for(c, want), std::min<uint32_t>(c->msm_min_cols, MSM_MAX_BATCH)) : 1u;
     if (slot && (msm_ws_max_n(slot) != want || msm_ws_window(slot) != cw || msm_ws_max_batch(slot) < cols)) {
-        hipStreamSynchronize(c->stream);  // (a pass of the lane that has been collected may still have kernels of its tail queued behind others)
-        if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
+        aud_sync(c, c->stream);  // (a pass of the lane that has been collected may still have kernels of its tail queued behind others)
+        if (c->tail_stream) aud_sync(c, c->tail_stream);
         msm_workspace_destroy(slot);
         slot = nullptr;
     }
@@ -288,15 +288,29 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     hipStream_t hs = c->stream;  // where the pass's head and accumulation run
     if (c->msm_side && c->msm_stream) {
         hs = c->msm_stream;
-        HIPCHK(c, hipEventRecord(c->ev_msm_in, c->stream));  // everything the main stream holds so far: the pass's inputs among it
-        HIPCHK(c, hipStreamWaitEvent(hs, c->ev_msm_in, 0));
+        HIPCHK(c, aud_record(c, c->ev_msm_in, c->stream));  // everything the main stream holds so far: the pass's inputs among it
+        HIPCHK(c, aud_wait(c, hs, c->ev_msm_in));
         if (L.tail == c->stream) L.tail = c->tail_stream;    // (never a tail behind the main stream's later kernels)
     }
-    HIPCHK(c, hipEventRecord(L.t_head[0], hs));
+    HIPCHK(c, aud_record(c, L.t_head[0], hs));
+    msm_ws_set_t1_mode(ws, c->opt_msm_t1);
     HIPCHK(c, msm_run(ws, d_scalars, batch, d_bases, n, hs, L.host_buf, &L.nwin, &L.cw, L.t_acc, table, stride, L.tail,
                       L.head_done, !table || ident));
-    HIPCHK(c, hipEventRecord(L.tail_done, L.tail));
-    HIPCHK(c, hipEventRecord(L.t_head[1], hs));
+    if (c->audit.on) {
+        // the ledger's twin of what msm_run enqueued: head + accumulation on hs (reads the columns, fills the lane's workspace),
+        // the head_done hand-off, the tail on L.tail (reads the workspace, writes the lane's pinned result buffer)
+        const void* rd[MSM_MAX_BATCH];
+        for (uint32_t q = 0; q < batch; q++) rd[q] = d_scalars[q];
+        const void* wr[1] = {ws};
+        c->audit.op_v(hs, rd, batch, wr, 1, "MSM pass: sort head + accumulation");
+        if (L.tail != hs) {
+            c->audit.record(L.head_done, hs);
+            c->audit.wait(L.tail, L.head_done);
+        }
+        c->audit.op(L.tail, {ws}, {ws, L.host_buf}, "MSM pass: reduction tail");
+    }
+    HIPCHK(c, aud_record(c, L.tail_done, L.tail));
+    HIPCHK(c, aud_record(c, L.t_head[1], hs));
     c->msm_launches++;
     L.n = n;
     L.batch = batch;
@@ -314,11 +328,13 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
     if (lane < 0 || lane >= zk_ctx::MSM_LANES || !c->lanes[lane].busy) return ZK_EINVAL;
     zk_ctx::MsmLane& L = c->lanes[lane];
     L.busy = false;
-    HIPCHK(c, hipEventSynchronize(L.tail_done));
+    HIPCHK(c, aud_esync(c, L.tail_done));
+    c->audit.host_read(L.host_buf, "MSM pass: the host collects the sums");
     if (L.fixed && L.n > 0 && msm_wide_redo_count(L.ws_run, L.host_buf, L.batch)) {
         // a degenerate basis (equal or opposite points): the unchecked accumulation reported lanes to redo with the checked loop
         HIPCHK(c, msm_wide_redo(L.ws_run, L.batch, L.n, L.tail, L.host_buf, L.table));
-        HIPCHK(c, hipStreamSynchronize(L.tail));
+        c->audit.op(L.tail, {L.ws_run}, {L.ws_run, L.host_buf}, "MSM pass: checked redo + tail");
+        HIPCHK(c, aud_sync(c, L.tail));
     }
     if (L.fixed) {
         // fixed-base mode: one independent result per column
@@ -353,7 +369,7 @@ int ctx_msm_end_batch(zk_ctx* c, int lane, G1Jac* out) {
 void ctx_msm_drain(zk_ctx* c) {
     for (int q = 0; q < zk_ctx::MSM_LANES; q++)
         if (c->lanes[q].busy) {
-            hipEventSynchronize(c->lanes[q].tail_done);
+            aud_esync(c, c->lanes[q].tail_done);
             c->lanes[q].busy = false;
         }
 }
@@ -506,6 +522,7 @@ ZK_API(zk_ctx_create_shared, (zk_ctx* parent, zk_ctx** out), (parent, out)) {
         c->opt_batch_pass_cols = parent->opt_batch_pass_cols;
         c->opt_xform_stream = parent->opt_xform_stream;
         c->opt_msm_stream = parent->opt_msm_stream;
+        c->opt_msm_t1 = parent->opt_msm_t1;
         c->srs_gen++;
     }
     *out = c;
@@ -516,10 +533,10 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
     ctx_activity_unregister(c);
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
-    if (c->xform_stream) hipStreamSynchronize(c->xform_stream);
-    if (c->msm_stream) hipStreamSynchronize(c->msm_stream);
+    if (c->stream) aud_sync(c, c->stream);
+    if (c->tail_stream) aud_sync(c, c->tail_stream);
+    if (c->xform_stream) aud_sync(c, c->xform_stream);
+    if (c->msm_stream) aud_sync(c, c->msm_stream);
     for (auto& kv : c->twiddles) hipFree(kv.second);
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
     for (auto& kv : c->twiddles_ninv) hipFree(kv.second);
@@ -565,7 +582,7 @@ ZK_API(zk_sync, (zk_ctx* c), (c)) {
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_bind(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -582,7 +599,7 @@ ZK_API(zk_last_kernel_ms, (zk_ctx* c, int which, float* out_ms), (c, which, out_
     }
     int rc = ctx_bind(c);
     if (rc) return rc;
-    HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
+    HIPCHK(c, aud_esync(c, c->ev[which][1]));
     HIPCHK(c, hipEventElapsedTime(out_ms, c->ev[which][0], c->ev[which][1]));
     return ZK_OK;
 }
@@ -622,8 +639,21 @@ ZK_API(zk_clock_probe, (zk_ctx* c, uint32_t millis, uint64_t out[4]), (c, millis
     uint64_t* h = reinterpret_cast<uint64_t*>(c->host_small);    // its pinned twin
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, (uint64_t)millis * 100000ull, d);
     HIPCHK(c, hipMemcpyAsync(h, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     memcpy(out, h, 4 * sizeof(uint64_t));
+    return ZK_OK;
+}
+
+ZK_API(zk_audit_report, (zk_ctx* c, uint64_t counts[2], char* msg, size_t cap), (c, counts, msg, cap)) {
+    if (!c || !counts) return ZK_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    counts[0] = c->audit.checks;
+    counts[1] = c->audit.violations;
+    if (msg && cap) {
+        const size_t len = std::min(cap - 1, c->audit.first.size());
+        memcpy(msg, c->audit.first.data(), len);
+        msg[len] = 0;
+    }
     return ZK_OK;
 }
 
@@ -664,6 +694,17 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_MSM_STREAM:
             if (value > 2) return ZK_EINVAL;
             c->opt_msm_stream = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_MSM_T1:
+            if (value > 2) return ZK_EINVAL;
+            c->opt_msm_t1 = (uint32_t)value;
+            return ZK_OK;
+        case ZK_OPT_STREAM_AUDIT:
+            if (value > 2) return ZK_EINVAL;
+            c->audit.reset();
+            c->audit.streams[0] = c->stream;
+            c->audit.on = value != 0;
+            c->audit_fault = value == 2;
             return ZK_OK;
         case ZK_OPT_XFORM_STREAM:
             if (value > 2) return ZK_EINVAL;
@@ -713,7 +754,7 @@ ZK_API(zk_msm_bn254, (zk_ctx* c, const uint64_t* scalars, const uint64_t* bases,
         if (hipMemcpyAsync(d_b, bases, n * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     }
     if (rc == ZK_OK) rc = ctx_msm_device(c, d_s, d_b, n, &res);
-    hipStreamSynchronize(c->stream);
+    aud_sync(c, c->stream);
     if (rc == ZK_OK) memcpy(out, &res, 96);
     return rc;
 }
@@ -737,7 +778,7 @@ ZK_API(zk_msm_srs, (zk_ctx* c, int basis, const uint64_t* scalars, size_t n, uin
     if ((rc = seam_buffer(c, 0, n * sizeof(Fr), (void**)&d_s))) return rc;
     if (hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     if (rc == ZK_OK) rc = ctx_msm_device(c, d_s, basis == ZK_BASIS_LAGRANGE ? c->g_lagrange : c->g, n, &res);
-    hipStreamSynchronize(c->stream);
+    aud_sync(c, c->stream);
     if (rc == ZK_OK) memcpy(out, &res, 96);
     return rc;
 }
@@ -784,9 +825,9 @@ ZK_API(zk_ntt_bn254_fr, (zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32
     if (!own_tw && log_n > 7) rc = ctx_get_twiddles(c, log_n, &job.tw_last);  // best_fft does not scale: c = 1 in both directions
     if (rc == ZK_OK && hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_EHIP;
     if (rc == ZK_OK) {
-        hipEventRecord(c->ev[ZK_T_NTT][0], c->stream);
+        aud_record(c, c->ev[ZK_T_NTT][0], c->stream);
         hipError_t e = ntt_run(job, c->stream);
-        hipEventRecord(c->ev[ZK_T_NTT][1], c->stream);
+        aud_record(c, c->ev[ZK_T_NTT][1], c->stream);
         c->ev_valid[ZK_T_NTT] = true;
         if (e != hipSuccess) {
             c->last_hip = (int)e;
@@ -796,11 +837,11 @@ ZK_API(zk_ntt_bn254_fr, (zk_ctx* c, uint64_t* a, const uint64_t omega[4], uint32
     // The transform is complete (and known to have succeeded) BEFORE the first byte of the caller's buffer is overwritten: a
     // failed upload or kernel leaves `a` untouched.  (Round 4 staged the result through a zero-filled temporary — 64 MiB of page
     // faults and a second copy per 2^21 call: 19 ms of the call's 19.4; what can still fail below is the copy-out itself.)
-    if (rc == ZK_OK && (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess)) rc = ZK_EHIP;
+    if (rc == ZK_OK && (aud_sync(c, c->stream) != hipSuccess || hipGetLastError() != hipSuccess)) rc = ZK_EHIP;
     if (rc == ZK_OK && (hipMemcpyAsync(a, d_a, n * sizeof(Fr), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                        hipStreamSynchronize(c->stream) != hipSuccess))
+                        aud_sync(c, c->stream) != hipSuccess))
         rc = ZK_EHIP;
-    hipStreamSynchronize(c->stream);
+    aud_sync(c, c->stream);
     hipFree(own_tw);
     return rc;
 }
@@ -822,7 +863,7 @@ int srs_build_tables(zk_ctx* c, uint32_t k) {
     if (e == hipSuccess) e = msm_bases_have_identity(c->g, n, c->stream, (uint32_t*)c->small, (uint32_t*)c->host_small, &c->g_has_identity);
     if (e == hipSuccess)
         e = msm_bases_have_identity(c->g_lagrange, n, c->stream, (uint32_t*)c->small, (uint32_t*)c->host_small, &c->g_lagrange_has_identity);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = aud_sync(c, c->stream);
     if (e != hipSuccess) {
         c->last_hip = (int)e;
         return ZK_EHIP;
@@ -927,7 +968,7 @@ ZK_API(zk_srs_setup, (zk_ctx* c, uint32_t k, const uint8_t seed[32]), (c, k, see
         const Fr cst = fe_mul(fe_sub(sn, Fr::one()), fe_inv(fr_from_u64(n)));
         launch_srs_lagrange_scalars(tw, n, s, cst, d_sc, c->stream);
         launch_srs_fixed_base(d_sc, n, d_table, c->g_lagrange, c->stream);
-        hipError_t e = hipStreamSynchronize(c->stream);
+        hipError_t e = aud_sync(c, c->stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) {
             c->last_hip = (int)e;
@@ -1029,7 +1070,7 @@ ZK_API(zk_poly_free, (zk_ctx* c, zk_poly h), (c, h)) {
     PolyRec* r = find_poly(c, h);
     if (!r) return ZK_EINVAL;
     ctx_bind(c);
-    hipStreamSynchronize(c->stream);  // nothing of this context still uses it
+    aud_sync(c, c->stream);  // nothing of this context still uses it
     const size_t bytes = r->n * sizeof(Fr);
     if (c->poly_spare.size() < zk_ctx::POLY_SPARE_MAX && c->poly_spare_bytes + bytes <= zk_ctx::POLY_SPARE_BYTES) {
         c->poly_spare.push_back(*r);
@@ -1063,7 +1104,7 @@ ZK_API(zk_poly_detach, (zk_ctx* c, zk_poly h, uint64_t* token), (c, h, token)) {
     if (!r) return ZK_EINVAL;
     int rc = ctx_bind(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // whatever this context still does with the vector finishes first
+    HIPCHK(c, aud_sync(c, c->stream));  // whatever this context still does with the vector finishes first
     const Detached d{*r, c->device};
     c->polys.erase(h);
     std::lock_guard<std::mutex> lg(g_detached_mu);
@@ -1126,7 +1167,7 @@ ZK_API(zk_poly_upload, (zk_ctx* c, zk_poly h, const uint64_t* host, size_t n), (
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(r->ptr, host, n * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
     if (n < r->n) HIPCHK(c, hipMemsetAsync(r->ptr + n, 0, (r->n - n) * sizeof(Fr), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -1138,7 +1179,7 @@ ZK_API(zk_poly_download, (zk_ctx* c, zk_poly h, uint64_t* host, size_t n), (c, h
     int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(host, r->ptr, n * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -1153,7 +1194,7 @@ ZK_API(zk_poly_upload_range, (zk_ctx* c, zk_poly h, size_t first, const uint64_t
     if (rc) return rc;
     if (count == 0) return ZK_OK;
     HIPCHK(c, hipMemcpyAsync(r->ptr + first, host, count * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -1168,7 +1209,7 @@ ZK_API(zk_poly_copy_range, (zk_ctx* c, zk_poly dst, size_t dst_first, zk_poly sr
     if (rc) return rc;
     if (count == 0) return ZK_OK;
     HIPCHK(c, hipMemcpyAsync(d->ptr + dst_first, s->ptr + src_first, count * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -1294,9 +1335,18 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
         job.post[1] = coset ? fe_mul(ninv, c->zeta2) : ninv;
         job.post[2] = coset ? fe_mul(ninv, c->zeta) : ninv;
     }
-    hipEventRecord(c->ev[ZK_T_NTT][0], st);
+    if (c->audit.on) {  // reads the sources, writes the destinations, ping-pongs through the context's ONE scratch
+        const void *rd[NTT_MAX_BATCH + 1], *wr[NTT_MAX_BATCH + 1];
+        for (uint32_t b = 0; b < batch; b++) {
+            rd[b] = srcs[b];
+            wr[b] = dsts[b];
+        }
+        rd[batch] = wr[batch] = c->scratch;
+        c->audit.op_v(st, rd, batch + 1, wr, batch + 1, "NTT batch");
+    }
+    aud_record(c, c->ev[ZK_T_NTT][0], st);
     hipError_t e = ntt_run(job, st);
-    hipEventRecord(c->ev[ZK_T_NTT][1], st);
+    aud_record(c, c->ev[ZK_T_NTT][1], st);
     c->ev_valid[ZK_T_NTT] = true;
     if (e != hipSuccess) {
         c->last_hip = (int)e;
@@ -1373,12 +1423,12 @@ ZK_API(zk_eval, (zk_ctx* c, zk_poly h, const uint64_t x[4], uint64_t out[4]), (c
     Fr xx;
     memcpy(&xx, x, 32);
     const uint32_t blocks = eval_blocks((uint32_t)r->n);
-    hipEventRecord(c->ev[ZK_T_EVAL][0], c->stream);
+    aud_record(c, c->ev[ZK_T_EVAL][0], c->stream);
     launch_eval(r->ptr, (uint32_t)r->n, xx, c->small, c->stream);
-    hipEventRecord(c->ev[ZK_T_EVAL][1], c->stream);
+    aud_record(c, c->ev[ZK_T_EVAL][1], c->stream);
     c->ev_valid[ZK_T_EVAL] = true;
     HIPCHK(c, hipMemcpyAsync(c->host_small, c->small + blocks, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     memcpy(out, c->host_small, 32);
     return ZK_OK;
 }
@@ -1401,7 +1451,7 @@ ZK_API(zk_kate_division, (zk_ctx* c, zk_poly hp, const uint64_t z[4], zk_poly hq
     memcpy(&zz, z, 32);
     launch_kate_division(p->ptr, q->ptr, (uint32_t)p->n, zz, c->scratch, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 

@@ -49,6 +49,14 @@
 #ifndef ZK_TAIL_SER
 #define ZK_TAIL_SER false
 #endif
+// ... and except the per-bucket T1 (msm_wbucket_kernel), which is chosen only where the chip is loaded: issue slots count there
+#ifndef ZK_T1B_SER
+#define ZK_T1B_SER true
+#endif
+// slots a bucket may have for the per-bucket T1 to take it (a uniformly random 2^19 column: 17 .. 19)
+#ifndef ZK_T1B_LMAX
+#define ZK_T1B_LMAX 24
+#endif
 #include "ec29.hip.h"
 #include "engine.h"
 
@@ -110,6 +118,7 @@ struct MsmWorkspace {
     bool w_redo_valid;          // the last pass on this workspace ran the wide path's unchecked accumulation over n > 0 scalars: the word
                                 // behind its sums in the host buffer is that pass's redo count (msm_wide_redo_count); any other pass —
                                 // the standard plan on a wide workspace, an empty one — leaves no such word
+    uint32_t w_t1_mode;         // T1 of the wide path: 0 auto (per bucket when the tail runs on the head's stream), 1 per bucket, 2 per part
     bool w_last_wide;           // the last pass on this workspace took the wide path (its tail's timing events were recorded)
     bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
     // per-bucket totals and level-2 cursors exist twice: pass i counts in set i & 1 while its first kernel — 131 K lanes with
@@ -190,6 +199,7 @@ uint32_t msm_num_windows(uint32_t c) { return nwin_for(c); }
 size_t msm_ws_max_n(const MsmWorkspace* ws) { return ws->max_n; }
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws) { return ws->max_batch; }
 uint32_t msm_ws_window(const MsmWorkspace* ws) { return ws->c; }
+void msm_ws_set_t1_mode(MsmWorkspace* ws, uint32_t mode) { ws->w_t1_mode = mode; }
 bool msm_ws_last_pass_wide(const MsmWorkspace* ws) { return ws->w_last_wide; }
 
 // ---------------------------------------------------------------- recode ---
@@ -1573,7 +1583,7 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
                                                         const uint32_t* __restrict__ pstart_all, const uint32_t* __restrict__ pbucket_all,
                                                         uint32_t part_stride, uint32_t nb, const uint32_t* __restrict__ counts,
-                                                        G1X29S* __restrict__ part_all, uint32_t WCAP) {
+                                                        G1X29S* __restrict__ part_all, uint32_t WCAP, uint32_t lmin) {
     const uint32_t col = blockIdx.y;
     const uint32_t nparts = counts[4 * col + 2];
     if (blockIdx.x * 64 >= nparts) return;  // wave-uniform
@@ -1581,10 +1591,20 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
     const uint32_t g = blockIdx.x * 64 + lane;
     const G1X29S* __restrict__ slots = slot_all + (size_t)col * slot_stride;
     uint32_t b = g < nparts ? pbucket_all[(size_t)col * part_stride + g] : 0xffffffffu;  // 0xffffffff: the unused end of a bin's part region
-    const bool active = b != 0xffffffffu;
+    bool active = b != 0xffffffffu;
     uint32_t s = 0, s_end = 0;
     if (active) {
         // the bucket's slots: one per accumulation lane that held some of its entries, at index lane + bucket
+        const uint32_t e0 = bstart_all[(size_t)col * nb + b];
+        const uint32_t s0 = e0 / WL + b;
+        const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
+        if (len <= lmin) {  // the per-bucket kernel (msm_wbucket_kernel) has summed this bucket: its parts take no lane here
+            active = false;
+            b = 0xfffffffeu - lane;  // (distinct: no two such lanes look like parts of one bucket)
+        }
+    }
+    if (!__any(active)) return;  // wave-uniform: under lmin > 0 nearly every wave of a uniformly random column
+    if (active) {
         const uint32_t e0 = bstart_all[(size_t)col * nb + b];
         const uint32_t s0 = e0 / WL + b;
         const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
@@ -1618,6 +1638,44 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
     }
     const uint32_t prev = (uint32_t)__shfl_up((int)b, 1);
     if (active && (lane == 0 || prev != b)) g1x29_store(part_all + (size_t)col * part_stride + g, acc);
+}
+
+// T1, per-bucket form (round 6): ONE lane per bucket sums all of the bucket's slots serially — no parts, no shuffle tree.  A wave
+// of the part form spends 7.9 addition times on 64 parts = ~21 buckets (5 .. 6 serial additions + two tree levels in which most
+// lanes idle: 4.35e7 instructions per 2^19 column, profiles/r5_pmc_ops.txt); here a wave takes 64 buckets in max(len) - 1
+// additions (len = 17 .. 19 slots for a uniformly random column) with every lane busy, and the products take the serial
+// multiply-add form: fewer instructions, a LONGER dependent chain — the form for a loaded chip (the pass's tail on the main
+// stream: three or more proofs in flight), while a lone proof keeps the part form, whose chain is half as long.  Buckets of
+// more than `lmax` slots (witness-like columns put 400 K entries into a few buckets) are left to msm_wparts_kernel (lmin = lmax).
+// The sum goes where T2 looks for it: part[pstart[b]]; a further head of the bucket's part range (a multiple of 64 inside it)
+// becomes the identity.
+__global__ __launch_bounds__(64) void msm_wbucket_kernel(const G1X29S* __restrict__ slot_all, uint32_t slot_stride,
+                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
+                                                         const uint32_t* __restrict__ pstart_all, uint32_t part_stride, uint32_t nb,
+                                                         G1X29S* __restrict__ part_all, uint32_t WCAP, uint32_t lmax) {
+    const uint32_t col = blockIdx.y, b = blockIdx.x * 64 + threadIdx.x;  // nb is a multiple of 64
+    const G1X29S* __restrict__ slots = slot_all + (size_t)col * slot_stride;
+    const uint32_t e0 = bstart_all[(size_t)col * nb + b];
+    const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
+    const bool mine = len != 0 && len <= lmax;
+    uint32_t s = e0 / WL + b;
+    const uint32_t s_end = mine ? s + len : s;
+    G1X29 acc = g1x29_identity();
+#pragma unroll 1
+    while (__any(s < s_end)) {  // wave-uniform
+        const bool have = s < s_end;
+        G1X29 v;
+        if (have) v = g1x29_load(slots + s);
+        s++;
+        if (have) g1x29_add<ZK_T1B_SER>(acc, v);
+    }
+    if (mine) {
+        G1X29S* __restrict__ part = part_all + (size_t)col * part_stride;
+        const uint32_t g = pstart_all[(size_t)col * nb + b], g_end = g + (len + WCAP - 1) / WCAP;
+        g1x29_store(part + g, acc);
+        const uint32_t h = (g | 63u) + 1;
+        if (h < g_end) g1x29_store(part + h, g1x29_identity());
+    }
 }
 
 // T2: one wave per row (blockIdx.x < rows) or column (blockIdx.x - rows) of the column's bucket matrix [rows][256]: lanes walk
@@ -2010,8 +2068,17 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     if (n > 0) {
         // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_wscatter1_kernel)
         const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * g.bins + 64;
+        // T1 per bucket where the tail shares its stream with the head (the engine puts it there while three or more proofs are in
+        // flight on the device: issue slots are what is short), per part — the shorter dependent chain — for a lone proof
+        const bool per_bucket = ws->w_t1_mode == 1 || (ws->w_t1_mode == 0 && ts == st);
+        uint32_t lmin = 0;
+        if (per_bucket) {
+            lmin = ZK_T1B_LMAX;
+            hipLaunchKernelGGL(msm_wbucket_kernel, dim3(nb / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, totals, ws->w_bstart,
+                               ws->w_pstart, ws->w_part_stride, nb, ws->w_part, WCAP, lmin);
+        }
         hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, ts, ws->slot_pt, ws->w_slot_stride, totals,
-                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
+                           ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP, lmin);
     }
     hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, ts, ws->w_part, ws->w_part_stride, totals, ws->w_bstart,
                        ws->w_pstart, nb, ws->w_rc, WCAP);
@@ -2057,7 +2124,7 @@ hipError_t msm_wide_redo(MsmWorkspace* ws, uint32_t batch, size_t n, hipStream_t
     if (e != hipSuccess) return e;
     const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * bins + 64;
     hipLaunchKernelGGL(msm_wparts_kernel, dim3((max_parts + 63) / 64, batch), dim3(64), 0, st, ws->slot_pt, ws->w_slot_stride, totals,
-                       ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP);
+                       ws->w_bstart, ws->w_pstart, ws->w_pbucket, ws->w_part_stride, nb, ws->counts, ws->w_part, WCAP, 0u);
     hipLaunchKernelGGL(msm_wrowcol_kernel, dim3(rows + 256, batch), dim3(64), 0, st, ws->w_part, ws->w_part_stride, totals, ws->w_bstart,
                        ws->w_pstart, nb, ws->w_rc, WCAP);
     G1X* out_dev = nullptr;

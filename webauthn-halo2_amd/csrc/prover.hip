@@ -348,7 +348,7 @@ int pk_ensure_batch(zk_ctx* c, zk_pk_rec* pk, uint32_t batch) {
         pk->members.push_back(m);
     }
     if (pk->bb && pk->bb->cap >= batch) return ZK_OK;
-    hipStreamSynchronize(c->stream);
+    aud_sync(c, c->stream);
     bb_destroy(pk->bb);
     pk->bb = nullptr;
     BatchBufs* bb = new (std::nothrow) BatchBufs();
@@ -432,7 +432,7 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
         return rc;
     }
     auto fail = [&](int code) {
-        hipStreamSynchronize(st);
+        aud_sync(c, st);
         pk_destroy(pk);
         return code;
     };
@@ -494,7 +494,7 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
             pk->sigma_coset.push_back(e);
             hipMemcpyAsync(d_map, &mapping[(size_t)col * n], (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, st);
             hipLaunchKernelGGL(sigma_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_map, tw, d_dpow, v, n);
-            hipStreamSynchronize(st);  // d_map is reused
+            aud_sync(c, st);  // d_map is reused
         }
         hipFree(d_map);
     }
@@ -522,7 +522,7 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
         if (d.rc) return fail(d.rc);
         auto make = [&](Fr* dst) -> int {
             hipMemcpyAsync(scratch_n, tmp.data(), (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st);
-            hipStreamSynchronize(st);
+            aud_sync(c, st);
             int r2 = ctx_ntt(c, scratch_n, n, scratch_n, lay.k, true, false, n);
             if (r2) return r2;
             return ctx_ntt(c, scratch_n, n, dst, lay.ext_k, false, true, N);
@@ -537,7 +537,7 @@ ZK_API(zk_keygen, (zk_ctx* c, const zk_circuit_params* params, const uint64_t* f
     }
     pk->transcript_repr = pk_standin_transcript_repr(pk);
     if ((rc = pk_alloc_workspace(c, pk))) return fail(rc);
-    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
+    if (aud_sync(c, st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(ZK_EHIP);
     const uint64_t h = c->next_handle++;
     c->pks[h] = pk;
     *out = h;
@@ -550,7 +550,7 @@ ZK_API(zk_pk_free, (zk_ctx* c, zk_pk h), (c, h)) {
     auto it = c->pks.find(h);
     if (it == c->pks.end()) return ZK_EINVAL;
     ctx_bind(c);
-    hipStreamSynchronize(c->stream);
+    aud_sync(c, c->stream);
     pk_destroy(it->second);
     c->pks.erase(it);
     return ZK_OK;
@@ -706,7 +706,7 @@ ZK_API(zk_quotient, (zk_ctx* c, zk_pk h, const zk_poly* advice_ext, size_t n_adv
     int rc = ctx_bind(c);
     if (rc) return rc;
     if ((rc = pk_quotient(c, pk, qc, b, g, yy, divide != 0, out))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the argument block is reused by the next call
+    HIPCHK(c, aud_sync(c, c->stream));  // the argument block is reused by the next call
     return ZK_OK;
 }
 
@@ -772,10 +772,22 @@ struct Prover {
     // Blinding rows are staged on the host and written by rows_flush() — one upload and one launch for all
     // the columns of a phase — before the first kernel that reads those columns (commit_begin_batch and
     // transforms() flush; other readers call rows_flush() themselves).
+    // ---- stream audit (audit.h, ZK_OPT_STREAM_AUDIT): every enqueue of this prover names the buffers it reads and writes
+    void A(std::initializer_list<const void*> r, std::initializer_list<const void*> w, const char* site) {
+        if (c->audit.on) c->audit.op(st, r, w, site);
+    }
+    void AV(const std::vector<const void*>& r, const std::vector<const void*>& w, const char* site) {
+        if (c->audit.on) c->audit.op_v(st, r.data(), r.size(), w.data(), w.size(), site);
+    }
+    std::vector<const void*> aud_rows;  // the columns the staged blinding rows go to (audit only)
     void set_rows(Fr* col, uint32_t first, const std::vector<Fr>& vals) {
         if (!ok()) return;
         if (vals.size() > 8) return fail(ZK_ESTATE);
         if (rows->count == ROWS_CAP) rows_flush();
+        if (c->audit.on) {
+            if (rows->count == 0) c->audit.host_write(rows->host + (size_t)rows->block * ROWS_CAP, "blinding rows: the host fills a staging block");
+            aud_rows.push_back(col);
+        }
         RowEntry& e = rows->host[(size_t)rows->block * ROWS_CAP + rows->count++];
         memcpy(e.vals, vals.data(), vals.size() * sizeof(Fr));
         e.dst = col + first;
@@ -786,13 +798,18 @@ struct Prover {
         if (!ok() || rows->count == 0) return;
         RowEntry* h = rows->host + (size_t)rows->block * ROWS_CAP;
         RowEntry* d = rows->dev + (size_t)rows->block * ROWS_CAP;
+        if (c->audit.on) {
+            A({h}, {d}, "blinding rows: upload of the staging block");
+            AV({d}, aud_rows, "blinding rows: scatter into the columns");
+            aud_rows.clear();
+        }
         if (hipMemcpyAsync(d, h, rows->count * sizeof(RowEntry), hipMemcpyHostToDevice, st) != hipSuccess) return fail(ZK_EHIP);
         launch_scatter_rows(d, rows->count, st);
-        hipEventRecord(c->ev_rows, st);  // what the transform stream waits for (transforms())
+        aud_record(c, c->ev_rows, st);  // what the transform stream waits for (transforms())
         rows->count = 0;
         if (++rows->block == ROWS_BLOCKS) {
             // the ring wraps: the oldest block's upload must have been consumed before it is overwritten
-            if (hipStreamSynchronize(st) != hipSuccess) return fail(ZK_EHIP);
+            if (aud_sync(c, st) != hipSuccess) return fail(ZK_EHIP);
             rows->block = 0;
         }
     }
@@ -890,22 +907,28 @@ struct Prover {
     // share the context's ping-pong scratch without an order between them (round 5's first form decided per call: under four
     // pipelines the count dips to one now and then, and 1 proof in ~ 1 500 came out wrong — tools/soak.py)
     bool xside = false;
-    bool xform_side() const { return xside; }
+    // (audit self-test, ZK_OPT_STREAM_AUDIT = 2: round 5's faulty form on purpose — the stream chosen per CALL, alternating, and no
+    // join before a main-stream transform: the ledger must then refuse every proof whose transforms come in more than one call)
+    bool fault_flip = false;
+    bool xform_side() {
+        if (c->audit_fault) return fault_flip = !fault_flip;
+        return xside;
+    }
     void xform_join() {
         if (!c->xform_pending) return;
         c->xform_pending = false;
-        if (hipStreamWaitEvent(st, c->ev_xform, 0) != hipSuccess) fail(ZK_EHIP);
+        if (aud_wait(c, st, c->ev_xform) != hipSuccess) fail(ZK_EHIP);
     }
     void transforms(const std::vector<Forms>& cols) {
         rows_flush();
         if (!ok() || cols.empty()) return;
         const bool side = xform_side();
         const hipStream_t xs = side ? c->xform_stream : st;
-        if (side && hipStreamWaitEvent(xs, c->ev_rows, 0) != hipSuccess) return fail(ZK_EHIP);
-        if (!side) xform_join();  // (the two streams share the NTT's ping-pong scratch)
+        if (side && aud_wait(c, xs, c->ev_rows) != hipSuccess) return fail(ZK_EHIP);
+        if (!side && !c->audit_fault) xform_join();  // (the two streams share the NTT's ping-pong scratch)
         transforms_on(cols, xs);
         if (side) {
-            if (hipEventRecord(c->ev_xform, xs) != hipSuccess) return fail(ZK_EHIP);
+            if (aud_record(c, c->ev_xform, xs) != hipSuccess) return fail(ZK_EHIP);
             c->xform_pending = true;
         }
     }
@@ -939,6 +962,12 @@ struct Prover {
     };
     void lincomb_many(Fr* out, const std::vector<Term>& terms, bool sub0, const Fr& sub0_val, bool accumulate_first = false,
                       const std::vector<Fr>* sub_low = nullptr) {
+        if (c->audit.on) {
+            std::vector<const void*> rd;
+            for (auto& t : terms) rd.push_back(t.poly);
+            if (accumulate_first) rd.push_back(out);
+            AV(rd, {out}, "linear combination");
+        }
         if (terms.size() > MAX_LC && !accumulate_first && n >= 256 && pk->lc_used + terms.size() <= pk->lc_cap) {
             // hundreds of inputs: one launch over an argument list in device memory.  The list's slots are not reused within a
             // proof (the copies are asynchronous; capacity: every opened polynomial twice, pk_alloc_workspace)
@@ -998,6 +1027,12 @@ struct Prover {
         }
         xform_join();  // every coset form is complete
         if (!ok()) return rc;
+        if (c->audit.on) {
+            std::vector<const void*> rd;
+            for (auto* v : {&qc.adv, &qc.z, &qc.lk_a, &qc.lk_s, &qc.lk_z})
+                for (const Fr* q : *v) rd.push_back(q);
+            AV(rd, {pk->h_ext}, "quotient");
+        }
         int r = pk_quotient(c, pk, qc, beta, gamma, y, true, pk->h_ext);
         if (r) return r;
         return ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
@@ -1081,6 +1116,7 @@ struct Prover {
             a.unit[i] = i == 0;
             p = fe_mul(p, xn);
         }
+        A({pk->h_ext}, {pk->h_comb}, "h(X) from its pieces");
         launch_lincomb(a, st);
     }
 
@@ -1091,7 +1127,7 @@ struct Prover {
         // the MSM passes of a lone proof on the context's MSM stream (ctx.h): same rule, same once-per-proof decision; measured
         // (tools/single_ab.py OPTS=9=1 / 9=2, four alternations on one box): 11.40-11.55 -> 11.29-11.38 ms, same bytes
         c->msm_side = !batch_member && (c->opt_msm_stream == 1 || (c->opt_msm_stream == 0 && xside && c->opt_xform_stream == 0));
-        if ((xside || c->msm_side) && (rc = ctx_lone_streams(c))) return rc;
+        if ((xside || c->msm_side || c->audit_fault) && (rc = ctx_lone_streams(c))) return rc;
         if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
         omega = fr_omega(lay.k);
         omega_inv = fe_inv_fast(omega);
@@ -1113,12 +1149,23 @@ struct Prover {
         if (many) {
             CopyPair* h = static_cast<CopyPair*>(pk->h_batch_args);
             for (uint32_t j = 0; j < lay.n_adv; j++) h[j] = CopyPair{advice_dev[j], pk->adv_val[j]};
+            if (c->audit.on) {
+                std::vector<const void*> rd, wr;
+                for (uint32_t j = 0; j < lay.n_adv; j++) {
+                    rd.push_back(advice_dev[j]);
+                    wr.push_back(pk->adv_val[j]);
+                }
+                AV(rd, wr, "advice columns into the workspace");
+            }
             if (hipMemcpyAsync(pk->d_batch_args, h, lay.n_adv * sizeof(CopyPair), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
             launch_copy_columns(static_cast<const CopyPair*>(pk->d_batch_args), lay.n_adv, n, st);
-            if (hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;
+            if (aud_sync(c, st) != hipSuccess) return ZK_EHIP;
         }
         for (uint32_t j = 0; j < lay.n_adv; j++) {
-            if (!many) hipMemcpyAsync(pk->adv_val[j], advice_dev[j], (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
+            if (!many) {
+                A({advice_dev[j]}, {pk->adv_val[j]}, "advice column into the workspace");
+                hipMemcpyAsync(pk->adv_val[j], advice_dev[j], (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st);
+            }
             set_rows(pk->adv_val[j], usable, draw(bf + 1));
         }
         draw(lay.n_adv);  // advice blinds (unused by KZG, still drawn)
@@ -1186,6 +1233,7 @@ struct Prover {
             memset(&lp, 0, sizeof(lp));
             for (uint32_t l = 0; l < lay.n_lookups; l++) {
                 if (lay.single) {
+                    A({pk->adv_val[0]}, {pk->lk_in[l]}, "lookup input = q_lookup x advice");
                     launch_mul(pk->lk_in[l], pk->fixed_val[lay.fx_qlookup], pk->adv_val[0], n, st);
                     lp.inp[l] = pk->lk_in[l];
                 } else {
@@ -1193,6 +1241,15 @@ struct Prover {
                 }
                 lp.ap[l] = pk->lk_ap[l];
                 lp.sp[l] = pk->lk_sp[l];
+            }
+            if (c->audit.on) {
+                std::vector<const void*> rd, wr;
+                for (uint32_t l = 0; l < lay.n_lookups; l++) {
+                    rd.push_back(lp.inp[l]);
+                    wr.push_back(lp.ap[l]);
+                    wr.push_back(lp.sp[l]);
+                }
+                AV(rd, wr, "lookup permutation");
             }
             launch_lookup_permute(lp, lay.n_lookups, usable, T, pk->lks, st);
         }
@@ -1211,7 +1268,7 @@ struct Prover {
             // one check for all lookups (the flag accumulates): an input outside the table is halo2's
             // ConstraintSystemFailure; nothing has been written for the lookups yet
             uint32_t* err = reinterpret_cast<uint32_t*>(c->host_small);
-            if (hipMemcpyAsync(err, pk->lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            if (hipMemcpyAsync(err, pk->lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess || aud_sync(c, st) != hipSuccess)
                 return ZK_EHIP;
             if (*err) {
                 ctx_msm_drain(c);
@@ -1232,6 +1289,7 @@ struct Prover {
             const uint64_t skip = (uint64_t)lay.n_chunks * (bf + 1) + (uint64_t)lay.n_lookups * (bf + 1);
             ChaChaKey key;
             memcpy(key.w, rng.key, 32);
+            A({}, {pk->random_poly}, "random polynomial");
             launch_chacha_fr(key, rng.block + skip, pk->random_poly, n, st);
             commit_begin(0, pk->random_poly, n, ZK_BASIS_MONOMIAL);
         }
@@ -1255,7 +1313,7 @@ struct Prover {
             const Fr delta = fr_delta();
             Fr dcur = Fr::one();
             const bool many_chunks = lay.n_chunks > BATCH_ARGS_MIN;
-            if (many_chunks && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the argument staging may still be in use
+            if (many_chunks && aud_sync(c, st) != hipSuccess) return ZK_EHIP;  // the argument staging may still be in use
             for (uint32_t ci = 0; ci < lay.n_chunks; ci++) {
                 PermArgs a;
                 memset(&a, 0, sizeof(a));
@@ -1273,6 +1331,11 @@ struct Prover {
                 a.gamma = gamma;
                 a.num = pk->gp_num[ci];
                 a.den = pk->gp_den[ci];
+                if (c->audit.on) {
+                    std::vector<const void*> rd;
+                    for (uint32_t q = 0; q < a.ncols; q++) rd.push_back(a.values[q]);
+                    AV(rd, {a.num, a.den}, "permutation numerators / denominators");  // (the batched form launches below, same stream)
+                }
                 if (many_chunks) static_cast<PermArgs*>(pk->h_batch_args)[ci] = a;
                 else launch_perm_numden(a, st);
                 zs.push_back(pk->z_val[ci]);
@@ -1283,10 +1346,11 @@ struct Prover {
                 launch_perm_numden_batch(static_cast<const PermArgs*>(pk->d_batch_args), lay.n_chunks, n, st);
             }
             const bool many_lookups = lay.n_lookups > BATCH_ARGS_MIN;
-            if (many_lookups && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the staging is rewritten below
+            if (many_lookups && aud_sync(c, st) != hipSuccess) return ZK_EHIP;  // the staging is rewritten below
             for (uint32_t l = 0; l < lay.n_lookups; l++) {
                 const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
                 const uint32_t p = lay.n_chunks + l;
+                A({pk->lk_ap[l], pk->lk_sp[l], inp}, {pk->gp_num[p], pk->gp_den[p]}, "lookup numerators / denominators");
                 if (many_lookups)
                     static_cast<LkNumDenArgs*>(pk->h_batch_args)[l] =
                         LkNumDenArgs{pk->lk_ap[l], pk->lk_sp[l], inp, pk->fixed_val[lay.fx_table], pk->gp_num[p], pk->gp_den[p]};
@@ -1316,12 +1380,21 @@ struct Prover {
             Fr* qinv_dev = pk->gp_scal + nprod;
             Fr* k_dev = pk->gp_scal + 2 * (size_t)nprod;
             Fr* init_dev = pk->gp_scal + 3 * (size_t)nprod;
+            if (c->audit.on) {
+                std::vector<const void*> rd, wr;
+                for (uint32_t p = 0; p < nprod; p++) {
+                    rd.push_back(pk->gp_num[p]);
+                    rd.push_back(pk->gp_den[p]);
+                    wr.push_back(zs[p]);
+                }
+                AV(rd, wr, "grand products");  // (scan + apply, or the batch_invert fallback: same buffers, same stream)
+            }
             bool fast = !c->opt_gp_batch_invert;  // zk_ctx_set_option(ZK_OPT_GP_BATCH_INVERT)
             if (fast) {
                 if (hipMemcpyAsync(pk->d_gp_items, items.data(), nprod * sizeof(GpItem), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
                 launch_gp_batch_scan(pk->d_gp_items, nprod, n, q_dev, st);
                 if (hipMemcpyAsync(pk->gp_host, q_dev, nprod * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess)
+                    aud_sync(c, st) != hipSuccess)
                     return ZK_EHIP;
                 // all inverses with one field inversion
                 Fr* q = pk->gp_host;
@@ -1401,13 +1474,20 @@ struct Prover {
                 ha[i].poly = ev[i].poly;
                 ha[i].x = xrot(x, ev[i].rot);
             }
+            if (c->audit.on) {
+                std::vector<const void*> rd;
+                for (size_t i = 0; i < ev.size(); i++) rd.push_back(ev[i].poly);
+                AV(rd, {pk->ev_out}, "evaluations");
+                A({pk->ev_out}, {pk->tail_host}, "evaluations to the host");
+            }
             hipEventRecord(c->ev[ZK_T_EVAL][0], st);
             launch_eval_batch(ha, pk->d_evargs, (uint32_t)ev.size(), n, pk->ev_scratch, pk->ev_out, st);
             hipEventRecord(c->ev[ZK_T_EVAL][1], st);
             c->ev_valid[ZK_T_EVAL] = true;
             if (hipMemcpyAsync(pk->tail_host, pk->ev_out, ev.size() * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
+                aud_sync(c, st) != hipSuccess)
                 return ZK_EHIP;
+            c->audit.host_read(pk->tail_host, "evaluations read by the host");
             for (size_t i = 0; i < ev.size(); i++) ev[i].eval = pk->tail_host[i];
         HT("evals on host");
         }
@@ -1458,6 +1538,10 @@ struct Prover {
             pts[set_idx] = xrot(x, s.first);
             set_idx++;
             if (!ok()) return rc;
+        }
+        if (c->audit.on) {
+            std::vector<const void*> b(wbuf, wbuf + set_idx);
+            AV(b, b, "GWC: division by (X - point)");
         }
         launch_kate_division_batch(wbuf, wbuf, pts, (uint32_t)set_idx, n, pk->kd_scratch, st);
         for (size_t i = 0; i < set_idx; i++) wit.push_back(wbuf[i]);
@@ -1608,6 +1692,10 @@ struct Prover {
                     zs[cnt] = set_pts[si][step];
                     cnt++;
                 }
+            if (c->audit.on) {
+                std::vector<const void*> b(bufs, bufs + cnt);
+                AV(b, b, "SHPLONK: division step");
+            }
             launch_kate_division_batch(bufs, bufs, zs, cnt, n, pk->kd_scratch, st);
         }
         {
@@ -1653,7 +1741,9 @@ struct Prover {
         terms.push_back(Term{S.hx, fe_neg(zt)});
         lincomb_many(pk->t_a, terms, true, sub);
         HT("L launched");
+        A({pk->t_a}, {pk->t_b}, "SHPLONK: final division");
         launch_kate_division(pk->t_a, pk->t_b, n, u, pk->kd_scratch, st);
+        A({pk->t_b}, {pk->t_b}, "SHPLONK: scale");
         launch_scale(pk->t_b, fe_inv_fast(z_diffs[0]), n, st);
         *out = pk->t_b;
         return rc;
@@ -1686,14 +1776,14 @@ struct ProveQuiesce {
     void settle() {
         ctx_msm_drain(c);  // an early error may leave commitments in flight
         if (c->msm_side) {
-            hipStreamSynchronize(c->msm_stream);
+            aud_sync(c, c->msm_stream);
             c->msm_side = false;
         }
         if (c->xform_pending) {  // (an early error before the quotient: transforms still in flight)
-            hipStreamSynchronize(c->xform_stream);
+            aud_sync(c, c->xform_stream);
             c->xform_pending = false;
         }
-        hipStreamSynchronize(c->stream);
+        aud_sync(c, c->stream);
     }
     ~ProveQuiesce() { settle(); }
 };
@@ -1741,12 +1831,14 @@ ZK_API(zk_prove, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_advice, co
     EvmTranscript evm;
     Blake2bTranscript b2;
     Transcript* tr = transcript == ZK_TRANSCRIPT_EVM ? (Transcript*)&evm : (Transcript*)&b2;
+    const uint64_t aud0 = c->audit.violations;
+    c->audit.base_of.clear();  // (allocations may have changed hands since the last proof)
     Prover p(c, pk, rng_seed, tr);
     {
         ProveQuiesce quiesce(c);  // (declared after the prover: it settles the streams while the prover's host buffers are alive)
         rc = p.run(adv.data(), scheme);
     }
-    if (rc) return rc;
+    if ((rc = aud_verdict(c, aud0, rc))) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;
     *proof_len = tr->out.size();
     if (!proof_out || proof_cap < tr->out.size()) return proof_out ? ZK_EINVAL : ZK_OK;
@@ -1816,7 +1908,7 @@ int phase_grand_products(zk_ctx* c, zk_pk_rec* pk, const std::vector<Fr*>& num, 
         HIPCHK(c, hipMemcpyAsync(pk->d_gp_items, items.data(), nprod * sizeof(GpItem), hipMemcpyHostToDevice, st));
         launch_gp_batch_scan(pk->d_gp_items, nprod, n, q_dev, st);
         HIPCHK(c, hipMemcpyAsync(pk->gp_host, q_dev, nprod * sizeof(Fr), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, aud_sync(c, st));
         Fr *q = pk->gp_host, *qi = pk->gp_host + nprod;
         Fr run = Fr::one();
         for (uint32_t p = 0; p < nprod && fast; p++) {
@@ -1842,7 +1934,7 @@ int phase_grand_products(zk_ctx* c, zk_pk_rec* pk, const std::vector<Fr*>& num, 
             launch_prefix_product(pk->t_frac, z[p], n, prev, Fr::one(), pk->t_a, pk->t_small, st);
         }
     }
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, aud_sync(c, st));
     return hipGetLastError() == hipSuccess ? ZK_OK : ZK_EHIP;
 }
 }  // namespace
@@ -1888,7 +1980,7 @@ ZK_API(zk_lookup_permute, (zk_ctx* c, zk_pk h, const zk_poly* advice, size_t n_a
     launch_lookup_permute(lp, lay.n_lookups, lay.usable, 1u << lay.lookup_bits, P.pk->lks, st);
     uint32_t* err = reinterpret_cast<uint32_t*>(c->host_small);
     HIPCHK(c, hipMemcpyAsync(err, P.pk->lks.err, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, aud_sync(c, st));
     return *err ? ZK_EWITNESS : ZK_OK;
 }
 
@@ -2000,7 +2092,7 @@ ZK_API(zk_pk_export_poly, (zk_ctx* c, zk_pk h, int which, size_t index, zk_poly 
     int rc = ctx_bind(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(d, (*v)[index], (size_t)pk->lay.n * sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -2017,7 +2109,7 @@ ZK_API(zk_random_poly, (zk_ctx* c, const uint8_t chacha_key[32], uint64_t first_
     ChaChaKey key;
     memcpy(key.w, chacha_key, 32);
     launch_chacha_fr(key, first_block, it->second.ptr, (uint32_t)it->second.n, c->stream);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -2061,7 +2153,7 @@ ZK_API(zk_poly_lincomb, (zk_ctx* c, zk_poly out, const zk_poly* in, const uint64
         launch_lincomb(a, c->stream);
         first = false;
     } while (done < count);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, aud_sync(c, c->stream));
     return ZK_OK;
 }
 
@@ -2105,12 +2197,14 @@ ZK_API(zk_prove_batch, (zk_ctx* c, zk_pk h, size_t batch, const zk_poly* advice,
         provers.emplace_back(new Prover(c, q == 0 ? pk : pk->members[q - 1], rng_seeds + 32 * (size_t)q, trs.back().get()));
         P.push_back(provers.back().get());
     }
+    const uint64_t aud0 = c->audit.violations;
+    c->audit.base_of.clear();
     {
         BatchRun run(c, pk, P, cap);
         ProveQuiesce quiesce(c);
         rc = run.run(adv.data(), scheme);
     }
-    if (rc) return rc;
+    if ((rc = aud_verdict(c, aud0, rc))) return rc;
     if (hipGetLastError() != hipSuccess) return ZK_EHIP;
     const size_t len = trs[0]->out.size();
     for (uint32_t q = 0; q < B; q++)
@@ -2130,6 +2224,6 @@ ZK_API(zk_poly_upload_canonical, (zk_ctx* c, zk_poly h, const uint64_t* host_can
     if (it == c->polys.end()) return ZK_EINVAL;
     if ((rc = ctx_bind(c))) return rc;
     launch_to_mont(it->second.ptr, (uint32_t)n, c->stream);
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZK_EHIP;
+    if (aud_sync(c, c->stream) != hipSuccess) return ZK_EHIP;
     return ZK_OK;
 }

@@ -155,7 +155,7 @@ struct BatchRun {
             }
             P[q]->draw(lay.n_adv);  // advice blinds (unused by KZG, still drawn)
         }
-        if (many && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the argument staging is reused below
+        if (many && aud_sync(c, st) != hipSuccess) return ZK_EHIP;  // the argument staging is reused below
         // one advice column and one lookup per proof (k = 19): the advice pass of all proofs stays in flight on lane 0
         // while the lookup columns are made and committed; otherwise plain order, as Prover::run
         const bool pipe = lay.n_adv == 1 && lay.n_lookups == 1 && B <= pass_cap;
@@ -256,7 +256,7 @@ struct BatchRun {
             // one check for all lookups of all proofs (the flag accumulates): an input outside the table is halo2's
             // ConstraintSystemFailure; nothing has been written for the lookups yet.  The batch fails as a whole.
             uint32_t* err = reinterpret_cast<uint32_t*>(c->host_small);
-            if (hipMemcpyAsync(err, bb.lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            if (hipMemcpyAsync(err, bb.lks.err, 4, hipMemcpyDeviceToHost, st) != hipSuccess || aud_sync(c, st) != hipSuccess)
                 return ZK_EHIP;
             if (*err) {
                 ctx_msm_drain(c);
@@ -298,7 +298,7 @@ struct BatchRun {
             const uint32_t nblk = gp_blocks(n);
             const Fr delta = fr_delta();
             const bool many_chunks = lay.n_chunks > BATCH_ARGS_MIN, many_lookups = lay.n_lookups > BATCH_ARGS_MIN;
-            if ((many_chunks || many_lookups) && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the argument staging may still be in use
+            if ((many_chunks || many_lookups) && aud_sync(c, st) != hipSuccess) return ZK_EHIP;  // the argument staging may still be in use
             for (uint32_t q = 0; q < B; q++) {
                 zk_pk_rec* pk = P[q]->pk;
                 Fr dcur = Fr::one();
@@ -327,7 +327,7 @@ struct BatchRun {
                     if (hipMemcpyAsync(pk->d_batch_args, pk->h_batch_args, lay.n_chunks * sizeof(PermArgs), hipMemcpyHostToDevice, st) != hipSuccess)
                         return ZK_EHIP;
                     launch_perm_numden_batch(static_cast<const PermArgs*>(pk->d_batch_args), lay.n_chunks, n, st);
-                    if (many_lookups && hipStreamSynchronize(st) != hipSuccess) return ZK_EHIP;  // the staging is rewritten below
+                    if (many_lookups && aud_sync(c, st) != hipSuccess) return ZK_EHIP;  // the staging is rewritten below
                 }
                 for (uint32_t l = 0; l < lay.n_lookups; l++) {
                     const Fr* inp = lay.single ? pk->lk_in[l] : pk->adv_val[lay.n_gate + l];
@@ -368,7 +368,7 @@ struct BatchRun {
                 if (hipMemcpyAsync(bb.d_gp_items, items.data(), np * sizeof(GpItem), hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
                 launch_gp_batch_scan(bb.d_gp_items, np, n, q_dev, st);
                 if (hipMemcpyAsync(bb.gp_host, q_dev, np * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess)
+                    aud_sync(c, st) != hipSuccess)
                     return ZK_EHIP;
                 // all inverses of all proofs with one field inversion
                 Fr* qv = bb.gp_host;
@@ -502,7 +502,7 @@ struct BatchRun {
             hipEventRecord(c->ev[ZK_T_EVAL][1], st);
             c->ev_valid[ZK_T_EVAL] = true;
             if (hipMemcpyAsync(bb.tail_host, bb.ev_out, total * sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
+                aud_sync(c, st) != hipSuccess)
                 return ZK_EHIP;
             size_t pos = 0;
             for (uint32_t q = 0; q < B; q++) {

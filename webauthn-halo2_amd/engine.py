@@ -21,7 +21,7 @@ ZK_T_MSM, ZK_T_NTT, ZK_T_QUOTIENT, ZK_T_EVAL, ZK_T_MSM_ACCUM, ZK_T_MSM_COLUMNS, 
 ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
 ZK_SERDE_PROCESSED, ZK_SERDE_RAW_BYTES, ZK_SERDE_RAW_BYTES_UNCHECKED = 0, 1, 2
 ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT, ZK_OPT_MSM_TAIL_STREAM = 1, 2, 3, 4, 5
-ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS, ZK_OPT_XFORM_STREAM, ZK_OPT_MSM_STREAM = 6, 7, 8, 9
+ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS, ZK_OPT_XFORM_STREAM, ZK_OPT_MSM_STREAM, ZK_OPT_MSM_T1, ZK_OPT_STREAM_AUDIT = 6, 7, 8, 9, 10, 11
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
 
@@ -141,6 +141,7 @@ def load_library():
         "zk_timer_reset": ([vp], ctypes.c_int),
         "zk_timer_stats": ([vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_clock_probe": ([vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+        "zk_audit_report": ([vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, sz], ctypes.c_int),
         "zk_keygen": ([vp, ctypes.POINTER(CircuitParamsC), u64p, sz, ctypes.POINTER(ctypes.c_uint32), sz,
                        ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
         "zk_pk_set_transcript_repr": ([vp, ctypes.c_uint64, u64p], ctypes.c_int),
@@ -486,6 +487,13 @@ class Engine:
         t, n = ctypes.c_double(), ctypes.c_uint64()
         self._chk(self.L.zk_timer_stats(self.ctx, which, ctypes.byref(t), ctypes.byref(n)), "zk_timer_stats")
         return t.value, n.value
+
+    def audit_report(self):
+        """(ordering checks made, violations, description of the first violation) of ZK_OPT_STREAM_AUDIT (zk_audit_report)."""
+        counts = (ctypes.c_uint64 * 2)()
+        msg = ctypes.create_string_buffer(600)
+        self._chk(self.L.zk_audit_report(self.ctx, counts, msg, len(msg)), "zk_audit_report")
+        return int(counts[0]), int(counts[1]), msg.value.decode(errors="replace")
 
     def clock_probe(self, millis=100):
         """(shader-clock ticks, 100 MHz ticks, dependent multiply-adds issued) over ~`millis` ms of one spinning wave (zk_clock_probe)."""
