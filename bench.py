@@ -41,6 +41,9 @@ WORKLOAD = ("batch of independent proofs, k=19 (bench_ecdsa.config row 1: A=1,L=
             "create_proof receives); `value_advice_resident` is the same batch with the columns in HBM before the clock starts")
 
 
+SYNTH_PROCESSES = None  # witness pool size (None: batch.py's default); tools/valu_proofs.py sets 1 — rocprofv3 does not survive the pool's workers
+
+
 def bind_to_gpu_numa_node(device):
     """Bind this rank's host threads (the pipelines' workers, the witness pool) — and therefore the pinned staging buffers they
     allocate — to the NUMA node the GPU hangs off: on an 8-GPU node a rank that proves on GPU 5 from the far socket pays for
@@ -86,7 +89,7 @@ class ProofWorkload:
         self.jobs = [rank + world * j for j in range(max(steps, 1))]
         self.warm = self.jobs[:max(1, min(len(self.jobs), warmup * inflight))]
         t0 = time.time()
-        wit = batch.synthesize_jobs(p, self.jobs)
+        wit = batch.synthesize_jobs(p, self.jobs, processes=SYNTH_PROCESSES)
         self.synth_s = (time.time() - t0) / len(self.jobs)
         fixed, copies = batch.structure(p)
         t0 = time.time()
@@ -237,12 +240,14 @@ def pmc_traffic_bytes(kernel="zk::msm_wacc_fast_kernel"):
 # mads, 4 waves/SIMD).  One XYZZ mixed addition as the kernel computes it (csrc/ec29.hip.h): 6 products (81 a*b + 81 m*p
 # multiply-adds each on the carry-free 9x29-bit form), 2 squarings (45 + 81) and the fused R*(Q - X3) - Y1*PPP (2 x 81 + one
 # reduction of 81) = 1 467 multiply-adds; nothing cheaper exists on this ISA (8x32-bit limbs: 128 + carries per product).
-MAD_CYCLES = 4.84  # profiles/r2_ubench_isa.txt: v_mad_u64_u32 (indep), 4 waves/SIMD
+MAD_CYCLES = 4.72  # profiles/r6_ubench_isa.txt: v_mad_u64_u32 (indep), 4 waves/SIMD, at the nominal 2.4 GHz the file's "cycles" assume (r2: 4.84)
+UBENCH_NOMINAL_GHZ = 2.4  # tools/ubench_isa.hip turns its measured time into "cycles" with hipDeviceProp.clockRate = 2.4 GHz
 SIMDS = 1024
 MADS_PER_ADD = 6 * 162 + 2 * 126 + 243
-# the OTHER vector instructions of a mixed addition as the kernel's text has them (tools/isa_mix.py, the mixed-addition block of
-# msm_wacc_fast_kernel): masks, 64-bit column shifts, the reduction's v_mul_lo, limb-wise additions — priced by class below
-OTHER_CYCLES_PER_ADD = 196 * 2.5 + 151 * 4.74 + 81 * 4.4 + 120 * 2.5
+# the OTHER vector instructions of a mixed addition as the kernel's text has them (tools/isa_mix.py prints the block: 576 = 285 plain
+# VOP2 masks / limb additions, 154 64-bit column shifts and moves, 81 v_mul_lo of the reduction, 56 VOP3 three-operand forms), at
+# the rates of profiles/r6_ubench_isa.txt — a plain instruction between two multiply-adds costs 3.96, not the 2.5 of a run of them
+OTHER_CYCLES_PER_ADD = 285 * 3.96 + 154 * 4.56 + 81 * 4.3 + 56 * 4.3
 
 
 def alu_roofline(eng, k, device=0):
@@ -288,7 +293,9 @@ def alu_roofline(eng, k, device=0):
     ms, cnt = eng.timer_stats(4)
     p.free()
     ms /= max(cnt, 1)
-    clock_ghz = ghz or 2.25  # (fallback: the rocm-smi samples of profiles/r4_clock_samples.txt)
+    # the rates are TIMES per wave-instruction measured under full VALU load, printed as cycles of the nominal clock: the peak is
+    # priced at that same nominal clock (whatever the chip's effective clock was then, it is now); the probe's reading is reported
+    clock_ghz = UBENCH_NOMINAL_GHZ
     peak = SIMDS * clock_ghz / MAD_CYCLES * 64 / MADS_PER_ADD
     peak_all = SIMDS * clock_ghz * 64 / (MADS_PER_ADD * MAD_CYCLES + OTHER_CYCLES_PER_ADD)
     adds = n * windows * (1.0 - 2.0 ** -c)  # a signed digit is zero with probability 2^-c
@@ -297,8 +304,9 @@ def alu_roofline(eng, k, device=0):
             "peak": peak, "unit": "G mixed adds/s", "frac": achieved / peak, "avg_launch_ms": ms,
             "frac_all_instructions": achieved / peak_all, "peak_all_instructions": peak_all,
             "sclk_ghz_under_this_kernel": ghz, "window_bits": c, "adds_per_launch": adds,
-            "peak_model": "%d SIMDs x %.3f GHz (measured beside the launches) / %.2f cycles per wave64 v_mad_u64_u32 x 64 lanes / %d mads per "
-                          "mixed add; all instructions: + %.0f issue cycles of non-mad instructions per addition"
+            "peak_model": "%d SIMDs x %.1f GHz (the nominal clock profiles/r6_ubench_isa.txt prints its measured issue times in) / %.2f cycles "
+                          "per wave64 v_mad_u64_u32 x 64 lanes / %d mads per mixed add; all instructions: + %.0f issue cycles of non-mad "
+                          "instructions per addition"
             % (SIMDS, clock_ghz, MAD_CYCLES, MADS_PER_ADD, OTHER_CYCLES_PER_ADD)}
 
 
@@ -468,9 +476,6 @@ def clock_under_load(wl, device, jobs):
     return res
 
 
-UBENCH_NOMINAL_GHZ = 2.4  # tools/ubench_isa.hip turns its measured time into "cycles" with hipDeviceProp.clockRate = 2.4 GHz
-
-
 def valu_issue_roofline(ms_per_proof, clock):
     """VALU issue as the first-class roofline of this path (round-5 review): none of the kernels is bound by HBM, all of them by
     the issue of their own integer instructions.  Instructions per proof and per kernel = SQ_INSTS_VALU of the committed counter
@@ -485,14 +490,18 @@ def valu_issue_roofline(ms_per_proof, clock):
     pmc, mix = _newest("*_proof_k19_pmc_valu.csv"), _newest("*_isa_mix.csv")
     if not pmc or not mix:
         return None
-    cpi = {_kname(r["kernel"]): float(r["issue_cycles_per_valu_instruction"]) for r in csv.DictReader(open(mix))}
-    rows, instr, cycles, gui, dur = [], 0.0, 0.0, 0.0, 0.0
+    cpi, cpi_mixed = {}, {}
+    for r in csv.DictReader(open(mix)):
+        cpi[_kname(r["kernel"])] = float(r["issue_cycles_per_valu_instruction"])
+        cpi_mixed[_kname(r["kernel"])] = float(r.get("issue_cycles_per_valu_instruction_mixed_stream") or r["issue_cycles_per_valu_instruction"])
+    rows, instr, cycles, cycles_mixed, gui, dur = [], 0.0, 0.0, 0.0, 0.0, 0.0
     for r in csv.DictReader(open(pmc)):
         k = _kname(r["kernel"])
         i = float(r["SQ_INSTS_VALU_per_proof"])
         c = cpi.get(k, 2.5)
         instr += i
         cycles += i * c
+        cycles_mixed += i * cpi_mixed.get(k, 3.96)
         if "msm_wacc_fast" in k:
             gui, dur = float(r.get("GRBM_GUI_ACTIVE_per_proof", 0) or 0), float(r.get("duration_ns_per_proof_under_the_profiler", 0) or 0)
         rows.append({"kernel": k, "launches_per_proof": float(r["launches_per_proof"]), "instr_per_proof": i,
@@ -506,6 +515,10 @@ def valu_issue_roofline(ms_per_proof, clock):
             "mix_weighted_ns_per_instr": cycles / instr / UBENCH_NOMINAL_GHZ, "simds": SIMDS,
             "issue_slots_per_s": SIMDS / (cycles / instr / UBENCH_NOMINAL_GHZ * 1e-9), "floor_ms": floor_ms, "ms_per_proof": ms_per_proof,
             "frac": floor_ms / ms_per_proof,
+            # the same with plain VOP2 instructions at the 3.96 cycles they cost BETWEEN multiply-adds (r6_ubench_isa.txt "4 mad + 4 v_and")
+            # instead of the 2.5 of an uninterrupted run of them: the less optimistic floor
+            "floor_ms_mixed_stream": cycles_mixed / UBENCH_NOMINAL_GHZ / SIMDS * 1e-6,
+            "frac_mixed_stream": cycles_mixed / UBENCH_NOMINAL_GHZ / SIMDS * 1e-6 / ms_per_proof,
             "sclk_mhz_probe_under_load": (clock or {}).get("sclk_mhz"), "sclk_mhz_probe_idle": (clock or {}).get("idle_mhz"),
             "sclk_mhz_grbm_accumulate_under_profiler": (gui / 8.0 / dur * 1e3) if dur else None,
             "by_kernel": sorted(rows, key=lambda r: -r["simd_ns_per_proof"])[:16],

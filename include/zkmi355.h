@@ -112,10 +112,9 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         for a lone proof — with ZK_OPT_XFORM_STREAM's auto rule: main, tail, transform and MSM stream are
                                         the runtime's four hardware queues —, so that the glue kernels of the next phase do not queue
                                         behind an accumulation), 1 always that stream, 2 always the main stream */
-#define ZK_OPT_MSM_T1 10             /* first kernel of the MSM reduction tail (the sum of a bucket's partial sums): 0 auto — one lane per
-                                        bucket (fewest instructions, longer dependent chain) for a pass whose tail runs on its head's stream,
-                                        i.e. while three or more proofs are in flight on the device, parts of <= 8 partial sums + a segmented
-                                        tree (shorter chain) otherwise; 1 always per bucket; 2 always per part.  Same bytes either way */
+#define ZK_OPT_MSM_T1 10             /* first kernel of the MSM reduction tail (the sum of a bucket's partial sums): 0 / 2 parts of <= 8 partial
+                                        sums + a segmented tree (default), 1 one lane per bucket (a quarter fewer instructions, a dependent chain
+                                        twice as long: measured equal under load, slower for a lone proof).  Same bytes either way */
 #define ZK_OPT_STREAM_AUDIT 11       /* debug: 1 switches on the happens-before ledger of the context's streams (csrc/audit.h): every enqueue
                                         names the buffers it reads and writes, and one whose stream is not ordered after the buffer's last
                                         writer (or, for a write, its last readers) makes the entry point return ZK_EINTERNAL instead of ZK_OK —

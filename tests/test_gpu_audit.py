@@ -71,8 +71,15 @@ def test_prover_shapes_under_the_audit(name):
         _regime(eng, regime)
         for kind in ("blake2b", "evm"):
             for j in range(2):
-                assert eng.prove(pk, sets[j], rs[j], KIND[kind]) == prover.create_proof(opk, asgs[j].advice, ChaCha20Rng(rs[j]), kind), (name, regime, kind, j)
-            got = eng.prove_batch(pk, sets, rs, KIND[kind])  # lock-step: members' workspaces, wider passes
+                try:
+                    got1 = eng.prove(pk, sets[j], rs[j], KIND[kind])
+                except zk.ZkError as e:
+                    raise AssertionError("%s under the audit (%s, %s): %s" % (e, name, regime, eng.audit_report())) from e
+                assert got1 == prover.create_proof(opk, asgs[j].advice, ChaCha20Rng(rs[j]), kind), (name, regime, kind, j)
+            try:
+                got = eng.prove_batch(pk, sets, rs, KIND[kind])  # lock-step: members' workspaces, wider passes
+            except zk.ZkError as e:
+                raise AssertionError("%s (batch) under the audit (%s, %s): %s" % (e, name, regime, eng.audit_report())) from e
             assert got == [prover.create_proof(opk, asgs[j].advice, ChaCha20Rng(rs[j]), kind) for j in range(3)], (name, regime, kind)
         assert eng.prove(pk, sets[0], rs[0], E.ZK_TRANSCRIPT_EVM, E.ZK_SCHEME_SHPLONK) == prover.create_proof(opk, asgs[0].advice, ChaCha20Rng(rs[0]), "evm", "shplonk")
         assert eng.prove(pk, sets[0], rs[0], E.ZK_TRANSCRIPT_BLAKE2B, E.ZK_SCHEME_GWC) == prover.create_proof(opk, asgs[0].advice, ChaCha20Rng(rs[0]), "blake2b", "gwc")

@@ -2,8 +2,8 @@
     python tools/isa_mix.py [tag]            -> profiles/<tag>_isa_mix.csv
 Per kernel: vector instructions by issue class and the mix-weighted issue cycles per wave-instruction per SIMD, with the class
 rates MEASURED on MI355X at four waves per SIMD (tools/ubench_isa.hip, profiles/r2_ubench_isa.txt):
-    v_mad_u64_u32 4.84   v_mul_lo/hi_u32 4.42 / 4.27   v_addc/subb (carry chain) 4.45   64-bit shifts / adds / moves 4.74
-    v_fma_f64 4.62       every other VALU instruction 2.5 (v_mov 2.46, v_add_u32 2.58)
+    v_mad_u64_u32 4.72   v_mul_lo/hi_u32 4.3   carry chain 4.39   64-bit shifts / adds / moves 4.56   v_fma_f64 4.62
+    VOP3-encoded 32-bit instructions (v_add3, v_alignbit, v_bfe, v_lshl_add, v_and_or, ...) 4.3   plain VOP1 / VOP2 2.5 (3.96 between multiply-adds)
 bench.py's roofline.valu_issue multiplies the per-kernel instruction counts of the PMC pass (SQ_INSTS_VALU) by these weights to
 price a proof's instruction stream in SIMD issue cycles.  The mix is the whole kernel's static text: the hot loops of these
 kernels are fully unrolled (a mixed addition is 2 000 straight-line instructions), so their text IS what executes; rarely taken
@@ -22,21 +22,29 @@ CSRC = os.path.join(ROOT, "webauthn-halo2_amd", "csrc")
 FILES = ["msm.hip", "ntt.hip", "quotient.hip", "poly.hip", "prover_kernels.hip", "engine.hip", "serde.hip"]
 CXXFILT = "c++filt"  # (binutils; llvm-cxxfilt is not in the image)
 
-CLASS_CYCLES = {"mad64": 4.84, "mul32": 4.4, "carry": 4.45, "wide64": 4.74, "f64": 4.62, "other": 2.5}
+# issue cycles per wave-instruction per SIMD at the nominal 2.4 GHz, four waves per SIMD, every SIMD busy (profiles/r6_ubench_isa.txt;
+# round 2's file has the first nine).  Only runs of plain 32-bit VOP1 / VOP2 instructions reach the double rate; everything
+# encoded as VOP3 (three operands: v_add3, v_alignbit, v_bfe, v_lshl_add, v_and_or, v_mad_u32_u24, 64-bit moves and shifts)
+# issues at the multiplier's rate — and a plain instruction BETWEEN two multiply-adds costs ~ 4.0, not 2.5 ("4 mad + 4 v_and":
+# 4.34 per instruction): `simple` below is therefore the optimistic price, SIMPLE_MIXED the one measured in a mixed stream.
+CLASS_CYCLES = {"mad64": 4.72, "mul32": 4.3, "carry": 4.39, "wide64": 4.56, "f64": 4.62, "vop3": 4.3, "simple": 2.5}
+SIMPLE_MIXED = 3.96
 
 
 def classify(op):
     if op.startswith("v_mad_u64_u32") or op.startswith("v_mad_i64_i32"):
         return "mad64"
-    if op.startswith(("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32")):
+    if op.startswith(("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32", "v_mul_u32_u24", "v_mul_hi_u32_u24")):
         return "mul32"
-    if op.startswith(("v_addc_co", "v_subb_co", "v_subbrev_co")):
+    if op.startswith(("v_addc_co", "v_subb_co", "v_subbrev_co", "v_add_co", "v_sub_co", "v_subrev_co")):
         return "carry"
     if op.startswith(("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64", "v_lshl_add_u64", "v_mov_b64", "v_add_u64", "v_sub_u64")):
         return "wide64"
     if op.endswith("_f64") or "_f64_" in op:
         return "f64"
-    return "other"
+    if op.endswith("_e32") or op in ("v_nop",):
+        return "simple"
+    return "vop3"  # _e64 encodings and the VOP3-only instructions (v_add3_u32, v_alignbit_b32, v_bfe_u32, v_lshl_add_u32, v_perm_b32, ...)
 
 
 def kernels_of(asm_path):
@@ -95,8 +103,9 @@ def main():
             if not total:
                 continue
             cyc = sum(cnt[c] * CLASS_CYCLES[c] for c in cnt)
-            rows.append([dm[mangled], f, total, cnt["mad64"], cnt["mul32"], cnt["carry"], cnt["wide64"], cnt["f64"], cnt["other"], nops,
-                         "%.3f" % (cyc / total)])
+            cyc_mixed = cyc + cnt["simple"] * (SIMPLE_MIXED - CLASS_CYCLES["simple"])
+            rows.append([dm[mangled], f, total, cnt["mad64"], cnt["mul32"], cnt["carry"], cnt["wide64"], cnt["f64"], cnt["vop3"], cnt["simple"], nops,
+                         "%.3f" % (cyc / total), "%.3f" % (cyc_mixed / total)])
             if "msm_wacc_fast_kernel" in mangled:
                 # the mixed addition = the largest basic block
                 blocks, cur = [], []
@@ -119,7 +128,8 @@ def main():
     out = os.path.join(ROOT, "profiles", "%s_isa_mix.csv" % tag)
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["kernel", "file", "valu_static", "mad64", "mul32", "carry", "wide64", "f64", "other", "s_nop", "issue_cycles_per_valu_instruction"])
+        w.writerow(["kernel", "file", "valu_static", "mad64", "mul32", "carry", "wide64", "f64", "vop3", "simple", "s_nop",
+                    "issue_cycles_per_valu_instruction", "issue_cycles_per_valu_instruction_mixed_stream"])
         w.writerows(rows)
     print("wrote", out, "(%d kernels)" % len(rows))
 

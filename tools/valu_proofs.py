@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 n = int(sys.argv[1])
+bench.SYNTH_PROCESSES = 1  # no process pool under rocprofv3 (its signal handler in the pool's workers stalls the run)
 wl = bench.ProofWorkload(0, 0, 1, 1, n, 1)
 wl.run_with_h2d(wl.jobs[:n])
 assert len(wl.proofs) == n and bench.check_against_oracle_digests(wl.proofs) == min(n, 256)

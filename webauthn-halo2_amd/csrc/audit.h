@@ -53,17 +53,21 @@ struct StreamAudit {
     uint64_t violations = 0, checks = 0;
     std::string first;
 
-    // a buffer's identity: the base of the device allocation the pointer lies in (h_ext + i n and h_ext are ONE buffer: the
-    // ledger is conservative about sub-ranges); pointers that are no device allocation — a pinned host buffer, the address of an
-    // MSM workspace record standing for the workspace — are their own identity
+    // a buffer's identity: the base of the DEVICE allocation the pointer lies in (h_ext + i n and h_ext are ONE buffer: the
+    // ledger is conservative about sub-ranges of device vectors); anything else — a block of a pinned staging ring (whose blocks
+    // are reused one by one while uploads of the others are in flight), a pinned result buffer, the address of an MSM workspace
+    // record standing for the workspace — is its own identity
     const void* key(const void* p) {
         auto it = base_of.find(p);
         if (it != base_of.end()) return it->second;
-        hipDeviceptr_t base = nullptr;
-        size_t size = 0;
         const void* k = p;
-        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && base) k = base;
-        else (void)hipGetLastError();
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && base) k = base;
+        }
+        (void)hipGetLastError();  // (a host heap pointer is an error for both calls: not ours to report)
         base_of.emplace(p, k);
         return k;
     }

@@ -89,7 +89,7 @@ struct zk_ctx {
     hipEvent_t ev_msm_in = nullptr;
     bool msm_side = false;          // set by the prover for the duration of a proof
     uint32_t opt_msm_stream = 0;    // ZK_OPT_MSM_STREAM: 0 auto, 1 side stream, 2 main stream
-    uint32_t opt_msm_t1 = 0;        // ZK_OPT_MSM_T1: 0 auto, 1 one lane per bucket, 2 parts + segmented tree (msm.hip msm_wbucket_kernel)
+    uint32_t opt_msm_t1 = 0;        // ZK_OPT_MSM_T1: 1 one lane per bucket, 0 / 2 parts + segmented tree (default) (msm.hip msm_wbucket_kernel)
     hipStream_t xform_stream = nullptr;
     hipEvent_t ev_rows = nullptr, ev_xform = nullptr;
     bool xform_pending = false;

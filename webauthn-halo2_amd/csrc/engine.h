@@ -49,7 +49,7 @@ uint32_t msm_num_windows(uint32_t c);
 size_t msm_ws_max_n(const MsmWorkspace* ws);
 uint32_t msm_ws_max_batch(const MsmWorkspace* ws);
 uint32_t msm_ws_window(const MsmWorkspace* ws);
-void msm_ws_set_t1_mode(MsmWorkspace* ws, uint32_t mode);  // ZK_OPT_MSM_T1: 0 auto, 1 one lane per bucket, 2 parts + segmented tree
+void msm_ws_set_t1_mode(MsmWorkspace* ws, uint32_t mode);  // ZK_OPT_MSM_T1: 1 one lane per bucket, 0 / 2 parts + segmented tree (default)
 bool msm_ws_last_pass_wide(const MsmWorkspace* ws);
 // table[w * n + i] = 2^(c w) * bases[i] (affine), w < msm_num_windows(c)
 // (the wide path's tables — 15 / 16-bit windows, msm_table_is_internal — hold the points in the accumulation's internal form,

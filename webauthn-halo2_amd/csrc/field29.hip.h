@@ -184,6 +184,15 @@ __device__ __forceinline__ void madcol_c(uint64_t& acc, int cnt, const uint32_t 
     for (int i = 0; i < cnt; i++) acc += (uint64_t)x[i] * y[i];
 }
 #endif
+// acc = x * y: the first multiply-add of a product takes the inline constant 0 as its addend instead of a zeroed accumulator
+// (one v_mov_b64 — issued at the multiplier's rate — less per product)
+__device__ __forceinline__ void mad_first(uint64_t& acc, uint32_t x, uint32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(acc) : "v"(x), "v"(y) : "vcc");
+#else
+    acc = (uint64_t)x * y;
+#endif
+}
 // column helpers: sum_{i = lo}^{hi} a_i b_{k - i} and sum_{i = lo}^{hi} m_i p_{k - i}, one statement each in the block form
 template <class PRM, bool SER>
 __device__ __forceinline__ void col_ab(uint64_t& acc, const uint32_t (&a)[9], const uint32_t (&b)[9], int k, int lo, int hi) {
@@ -226,7 +235,8 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        col_ab<PRM, SER>(acc, a.l, b.l, k, 0, k);
+        if (SER && MUL29_BLOCK && k == 0) mad_first(acc, a.l[0], b.l[0]);
+        else col_ab<PRM, SER>(acc, a.l, b.l, k, 0, k);
         if (k) col_mp<PRM, SER>(acc, m, k, 0, k - 1);
         m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
         mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
@@ -254,7 +264,8 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        col_ab<PRM, SER>(acc, a.l, b.l, k, 0, k);
+        if (SER && MUL29_BLOCK && k == 0) mad_first(acc, a.l[0], b.l[0]);
+        else col_ab<PRM, SER>(acc, a.l, b.l, k, 0, k);
         col_ab<PRM, SER>(acc, c.l, d.l, k, 0, k);
         if (k) col_mp<PRM, SER>(acc, m, k, 0, k - 1);
         m[k] = ((uint32_t)acc * Lim29<PRM>::INV) & M29;
@@ -298,7 +309,8 @@ __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
                 y[cnt] = a.l[k / 2];
                 cnt++;
             }
-            madcol_v(acc, cnt, x, y);
+            if (k == 0) mad_first(acc, a.l[0], a.l[0]);
+            else madcol_v(acc, cnt, x, y);
         } else {
 #pragma unroll
             for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) mad29<SER>(acc, a2[i], a.l[k - i]);

@@ -6,31 +6,23 @@
 // Any correct algorithm yields the same group element, so the result is
 // bit-identical to the reference's after affine normalisation.
 //
-// Two modes share one pipeline:
-//   generic   bases are arbitrary (the fine-grained `zk_msm_bn254` seam): W windows of
-//             c bits, W x 2^(c-1) buckets, host does the final W-window Horner;
-//   fixed     bases are the resident SRS (`zk_commit`): a table of window multiples
-//             2^(c w) P_i is precomputed once per basis, so every window's digits fall
-//             into ONE set of 2^(c-1) buckets — no per-window reduction, no Horner.
-//
-// Pipeline (one stream, no host round trip until the window sums):
-//   1. msm_recode        signed c-bit window recoding of every scalar -> digits[W][n]
-//   2. msm_sort<COUNT>   per (scalar chunk, window) workgroup: bucket histogram in LDS,
-//                        one returning atomicAdd per non-empty bucket reserves the
-//                        workgroup's range inside the bucket
-//   3. msm_scan          exclusive scan of bucket totals -> bucket starts
-//   4. msm_sort<SCATTER> same workgroups: LDS cursors = bucket start + reserved base,
-//                        counting-sort scatter of (bucket, +-base index) entries
-//   5. msm_accumulate    bucket ranges are padded to multiples of 16 entries; every lane sums one
-//                        aligned 16-entry segment with XYZZ mixed adds (8M + 2S) -> one partial
-//                        sum ("slot") per lane, all lanes of a launch do the same amount of work
-//   6. msm_gather1/2     two-level sum of each bucket's slots: dense lanes add 4 slots serially, then
-//                        16-lane groups finish each bucket with a shuffle tree (tail stream)
-//   7. msm_bitsum        sum_j j B_j = sum_t 2^t G_t, G_t = sum of buckets with bit t of j set:
-//                        c tree reductions per bucket set; the short Horner is done on the host
-// Load balance does not depend on the scalar distribution: witness columns are
-// dominated by zeros / small values (hot low buckets), and a segment is a fixed number
-// of entries whatever bucket they fall in.
+// Layout of the source (round 6; one translation unit — the parts are textual includes that share the constants and the
+// workspace record defined here):
+//   msm.hip             constants, the workspace, the choice of the window plan, msm_run / msm_run_wide (the launch sequences),
+//                       the host's finish (Horner over the bit sums)
+//   msm_wide.hip.h      THE path of every proof of the reference's configurations (2^16 .. 2^21 points over the resident SRS):
+//                       15 .. 17-bit windows on precomputed window tables, ONE bucket set per column, a dense two-level sort,
+//                       restartable accumulation lanes, the three-kernel reduction tail
+//   msm_legacy.hip.h    the plans around it: lg n - 5 window bits with digit planes and padded segments below 2^16 points, the
+//                       swept sort from 2^22, and arbitrary bases (`zk_msm_bn254`: W windows x 2^(c-1) buckets, host Horner over
+//                       the windows) — kernels msm_recode / msm_sort / msm_scatter* / msm_accumulate / msm_gather* / msm_bitsum
+//   msm_tables.hip.h    the window tables 2^(c w) P_i and the identity test of a basis
+// Two modes:
+//   generic   bases are arbitrary (the fine-grained `zk_msm_bn254` seam): W windows of c bits, W x 2^(c-1) buckets;
+//   fixed     bases are the resident SRS (`zk_commit`): a table of window multiples 2^(c w) P_i is precomputed once per basis,
+//             so every window's digits fall into ONE set of 2^(c-1) buckets — no per-window reduction, no window Horner.
+// Load balance does not depend on the scalar distribution: witness columns are dominated by zeros / small values (hot low
+// buckets), and an accumulation lane is a fixed number of entries whatever buckets they fall in.
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -118,7 +110,7 @@ struct MsmWorkspace {
     bool w_redo_valid;          // the last pass on this workspace ran the wide path's unchecked accumulation over n > 0 scalars: the word
                                 // behind its sums in the host buffer is that pass's redo count (msm_wide_redo_count); any other pass —
                                 // the standard plan on a wide workspace, an empty one — leaves no such word
-    uint32_t w_t1_mode;         // T1 of the wide path: 0 auto (per bucket when the tail runs on the head's stream), 1 per bucket, 2 per part
+    uint32_t w_t1_mode;         // T1 of the wide path (ZK_OPT_MSM_T1): 1 one lane per bucket, otherwise parts + segmented tree
     bool w_last_wide;           // the last pass on this workspace took the wide path (its tail's timing events were recorded)
     bool w_clean;               // the pass counters (totals, cursors, counts) are zero: the previous wide pass left them so
     // per-bucket totals and level-2 cursors exist twice: pass i counts in set i & 1 while its first kernel — 131 K lanes with
@@ -202,1656 +194,10 @@ uint32_t msm_ws_window(const MsmWorkspace* ws) { return ws->c; }
 void msm_ws_set_t1_mode(MsmWorkspace* ws, uint32_t mode) { ws->w_t1_mode = mode; }
 bool msm_ws_last_pass_wide(const MsmWorkspace* ws) { return ws->w_last_wide; }
 
-// ---------------------------------------------------------------- recode ---
-
-__global__ __launch_bounds__(256) void msm_recode_kernel(const Fr* __restrict__ scalars, uint32_t n, uint32_t stride,
-                                                         uint32_t c, uint32_t nwin, int16_t* __restrict__ digits) {
-    __shared__ uint32_t limbs[256][9];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const Fr s = fe_from_mont(fe_load(scalars + i));
-    uint32_t* L = limbs[threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < 8; k++) L[k] = s.v[k];
-    L[8] = 0;
-    const uint32_t half = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < nwin; w++) {
-        const uint32_t bit = w * c, word = bit >> 5, off = bit & 31;
-        uint32_t raw = 0;
-        if (word < 8) {
-            const uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
-            raw = (uint32_t)(two >> off) & mask;
-        }
-        raw += carry;
-        int32_t d;
-        if (raw > half) {
-            d = (int32_t)raw - (int32_t)(1u << c);
-            carry = 1;
-        } else {
-            d = (int32_t)raw;
-            carry = 0;
-        }
-        digits[(size_t)w * stride + i] = (int16_t)d;
-    }
-}
-
-// ------------------------------------------------------- histogram / scatter ---
-// grid.x = nchunks * nwin; blk = w * nchunks + chunk.  slice = fixed ? 0 : w.
-template <bool SCATTER>
-__global__ __launch_bounds__(256) void msm_sort_kernel(const int16_t* __restrict__ digits, uint32_t n, uint32_t stride,
-                                                       uint32_t nchunks, uint32_t nb, uint32_t fixed,
-                                                       uint32_t table_stride, uint32_t* __restrict__ totals,
-                                                       const uint32_t* __restrict__ bucket_start,
-                                                       uint32_t* __restrict__ blockbase, uint32_t* __restrict__ entries) {
-    extern __shared__ uint32_t lds[];  // min(nb, SORT_LDS_BUCKETS) counters / cursors
-    const uint32_t blk = blockIdx.x;
-    const uint32_t w = blk / nchunks, chunk = blk - w * nchunks;
-    const uint32_t slice = fixed ? 0 : w;
-    const uint32_t lo = chunk * CHUNK, hi = min(n, lo + CHUNK);
-    const int16_t* dg = digits + (size_t)w * stride;
-    // bucket sets beyond the LDS budget (c = 15) are handled in several sweeps over the chunk's digits
-    const uint32_t span = min(nb, SORT_LDS_BUCKETS);
-    for (uint32_t b0 = 0; b0 < nb; b0 += span) {
-        if (!SCATTER) {
-            for (uint32_t b = threadIdx.x; b < span; b += 256) lds[b] = 0;
-        } else {
-            for (uint32_t b = threadIdx.x; b < span; b += 256)
-                lds[b] = bucket_start[slice * nb + b0 + b] + blockbase[(size_t)blk * nb + b0 + b];
-        }
-        __syncthreads();
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-            const int32_t d = dg[i];
-            if (d == 0) continue;
-            const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            const uint32_t rel = mag - 1 - b0;
-            if (rel >= span) continue;
-            const uint32_t pos = atomicAdd(&lds[rel], 1u);
-            if (SCATTER) {
-                const uint32_t idx = (fixed ? w * table_stride : 0) + i;
-                entries[pos] = idx | (d < 0 ? SIGN_BIT : 0);
-            }
-        }
-        __syncthreads();
-        if (!SCATTER) {
-            for (uint32_t b = threadIdx.x; b < span; b += 256) {
-                const uint32_t cnt = lds[b];
-                blockbase[(size_t)blk * nb + b0 + b] = cnt ? atomicAdd(&totals[slice * nb + b0 + b], cnt) : 0;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ---- fixed-base mode: every window feeds ONE bucket set, so a workgroup owns a chunk of scalars with
-// ALL their windows: digit extraction and the LDS histogram are one kernel, and the scatter re-reads the
-// digits it wrote (5 launches per MSM head instead of 10).
-#ifndef ZK_FCHUNK
-#define ZK_FCHUNK 1024
-#endif
-static constexpr uint32_t FCHUNK = ZK_FCHUNK;  // scalars per workgroup (x nwin entries)
-
-__device__ __forceinline__ uint32_t msm_digits_of(const uint32_t* L, uint32_t c, uint32_t nwin, uint32_t i, uint32_t stride,
-                                                  int16_t* __restrict__ digits, uint32_t* hist) {
-    const uint32_t half = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < nwin; w++) {
-        const uint32_t bit = w * c, word = bit >> 5, off = bit & 31;
-        uint32_t raw = 0;
-        if (word < 8) {
-            const uint64_t two = (uint64_t)L[word] | ((uint64_t)L[word + 1] << 32);
-            raw = (uint32_t)(two >> off) & mask;
-        }
-        raw += carry;
-        int32_t d;
-        if (raw > half) {
-            d = (int32_t)raw - (int32_t)(1u << c);
-            carry = 1;
-        } else {
-            d = (int32_t)raw;
-            carry = 0;
-        }
-        digits[(size_t)w * stride + i] = (int16_t)d;
-        if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
-    }
-    return carry;
-}
-
-// Batched form: blockIdx.y is the column (one scalar vector each, same bases): every column has its own
-// bucket set [col * nb, (col + 1) * nb) and its own digit planes, so that ONE accumulate launch serves
-// all columns of a batch.
-__global__ __launch_bounds__(256) void msm_recode_hist_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c,
-                                                              uint32_t nwin, uint32_t nb, int16_t* __restrict__ digits_all,
-                                                              uint32_t* __restrict__ totals_all,
-                                                              uint32_t* __restrict__ blockbase_all) {
-    extern __shared__ uint32_t lds[];  // nb counters, then 256 x 9 limbs
-    const uint32_t col = blockIdx.y;
-    const Fr* __restrict__ scalars = batch.s[col];
-    int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
-    uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
-    uint32_t* __restrict__ blockbase = blockbase_all + (size_t)col * gridDim.x * nb;
-    uint32_t* hist = lds;
-    uint32_t* L = lds + nb + threadIdx.x * 9;
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const Fr s = fe_from_mont(fe_load(scalars + i));
-#pragma unroll
-        for (int k = 0; k < 8; k++) L[k] = s.v[k];
-        L[8] = 0;
-        msm_digits_of(L, c, nwin, i, stride, digits, hist);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
-        const uint32_t cnt = hist[b];
-        blockbase[(size_t)blockIdx.x * nb + b] = cnt ? atomicAdd(&totals[b], cnt) : 0;
-    }
-}
-
-// ---- two-level counting sort (ZK_SORT2).  The one-pass scatter below writes every entry to a random place of a 40 MB
-// list: 10.5 M uncoalesced 4-byte stores, 128 us per 2^19 column against 24 us for the same kernel with coalesced stores
-// (tools/scat_exp.sh).  Here the entries are first grouped by coarse bin (bucket / 64) and then, inside a bin, by bucket; in
-// both levels a workgroup sorts 4096 entries in LDS by a 6-bit key and writes them out in runs (~64 entries = 256 B per key),
-// so that consecutive lanes store to consecutive addresses.  The 6-bit fine key rides in bits 24..29 of the entry between
-// the two levels (an entry is sign << 31 | window * n + i, which needs 24 bits up to 20 windows x 2^19).
-#ifndef ZK_SORT2
-#define ZK_SORT2 1
-#endif
-static constexpr uint32_t CBINS_MAX = 256;   // coarse bins: buckets / 64 (64 at 13-bit windows, 128 at 14); buckets / 128 on the wide path (256 at 16)
-#ifndef ZK_SORT_SUB
-#define ZK_SORT_SUB 4096
-#endif
-#ifndef ZK_SORT2_MIN_N
-#define ZK_SORT2_MIN_N (1u << 18)
-#endif
-// The two extra launches and the 4096-entry sub-rounds only pay for long columns: single proofs of the k <= 16 rows of
-// bench_ecdsa.config are 2-6 % slower with it, k = 17 1-2 %, k >= 18 equal, and batches of k = 19 proofs 4 % faster.
-static bool sort2_applies(bool fused, size_t n, uint32_t nb, uint32_t nwin, size_t table_stride) {
-    return ZK_SORT2 && fused && n >= ZK_SORT2_MIN_N && nb >= 64 && (nb >> 6) <= CBINS_MAX &&
-           (uint64_t)nwin * table_stride <= (1u << 24);
-}
-
-static constexpr uint32_t SUB = ZK_SORT_SUB;  // entries sorted in LDS at a time
-static constexpr uint32_t COARSE_WORDS = 5 * (CBINS_MAX + 1);  // per column, CBINS_MAX + 1 words each: bin starts, chunk prefix, append cursors, (unused), wide path: the bins' part regions
-
-// digits + fine histogram: the global bucket totals (the workgroup's counts are added with one atomic per non-empty bucket)
-__global__ __launch_bounds__(256) void msm_recode_hist2_kernel(MsmBatch batch, uint32_t n, uint32_t stride, uint32_t c, uint32_t nwin,
-                                                               uint32_t nb, int16_t* __restrict__ digits_all,
-                                                               uint32_t* __restrict__ totals_all, uint32_t* __restrict__ coarse_all,
-                                                               uint32_t coarse_stride) {
-    extern __shared__ uint32_t lds[];  // nb counters, then 256 x 9 limbs
-    const uint32_t col = blockIdx.y;
-    const Fr* __restrict__ scalars = batch.s[col];
-    int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
-    uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
-    uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    uint32_t* hist = lds;
-    uint32_t* L = lds + nb + threadIdx.x * 9;
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const Fr s = fe_from_mont(fe_load(scalars + i));
-#pragma unroll
-        for (int k = 0; k < 8; k++) L[k] = s.v[k];
-        L[8] = 0;
-        msm_digits_of(L, c, nwin, i, stride, digits, hist);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
-        const uint32_t cnt = hist[b];
-        if (cnt) atomicAdd(&totals[b], cnt);
-    }
-    // the workgroup's range inside every coarse bin of `inter`: one returning atomic per bin on the append cursors
-    const uint32_t bins = nb >> 6;
-    if (threadIdx.x < bins) {
-        uint32_t sum = 0;
-        for (uint32_t q = 0; q < 64; q++) sum += hist[threadIdx.x * 64 + ((q + threadIdx.x) & 63)];  // staggered: no bank conflict
-        chdr[COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX + threadIdx.x] = sum ? atomicAdd(&chdr[2 * (CBINS_MAX + 1) + threadIdx.x], sum) : 0;
-    }
-}
-
-// per column: coarse-bin totals (sums of 64 bucket totals), their exclusive scan (the bins' places in `inter`), the chunk
-// prefix of the second level (ceil(total / SUB) chunks per bin), and the first level's append cursors (zero)
-__global__ __launch_bounds__(CBINS_MAX) void msm_scan_coarse_kernel(const uint32_t* __restrict__ totals_all, uint32_t nb,
-                                                                    uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t bins,
-                                                                    uint32_t fb) {
-    __shared__ uint32_t tot[CBINS_MAX];
-    const uint32_t* totals = totals_all + (size_t)blockIdx.x * nb;
-    uint32_t* c = coarse_all + (size_t)blockIdx.x * coarse_stride;
-    if (threadIdx.x < bins) {
-        uint32_t sum = 0;
-        for (uint32_t q = 0; q < (1u << fb); q++) sum += totals[(threadIdx.x << fb) + q];
-        tot[threadIdx.x] = sum;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0, chunks = 0;
-        for (uint32_t b = 0; b < bins; b++) {
-            c[b] = run;
-            c[(CBINS_MAX + 1) + b] = chunks;
-            run += tot[b];
-            chunks += (tot[b] + SUB - 1) / SUB;
-        }
-        c[bins] = run;
-        c[(CBINS_MAX + 1) + bins] = chunks;
-    }
-}
-
-// one LDS counting sort of up to SUB entries by a 6-bit (7-bit) key held in `key[]`, then the coalesced write-out:
-// slot q of the sorted run goes to dst[gbase[key] + q - lstart[key]]
-struct SortLds {
-    uint32_t cnt[CBINS_MAX], lstart[CBINS_MAX + 1], gbase[CBINS_MAX];
-    uint32_t sorted[SUB];
-    uint8_t kid[SUB];
-};
-
-__device__ __forceinline__ void sort_scan(SortLds& S, uint32_t bins) {
-    // exclusive scan of S.cnt over `bins` <= 256 keys by the first wave (four consecutive keys per lane);
-    // S.lstart[CBINS_MAX] = the total
-    if (threadIdx.x < 64) {
-        const uint32_t k0 = threadIdx.x * 4;
-        const uint32_t a0 = k0 < bins ? S.cnt[k0] : 0, a1 = k0 + 1 < bins ? S.cnt[k0 + 1] : 0;
-        const uint32_t a2 = k0 + 2 < bins ? S.cnt[k0 + 2] : 0, a3 = k0 + 3 < bins ? S.cnt[k0 + 3] : 0;
-        const uint32_t s = a0 + a1 + a2 + a3;
-        uint32_t x = s;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t y = __shfl_up(x, off);
-            if ((int)threadIdx.x >= off) x += y;
-        }
-        const uint32_t base = x - s;
-        S.lstart[k0] = base;
-        S.lstart[k0 + 1] = base + a0;
-        S.lstart[k0 + 2] = base + a0 + a1;
-        S.lstart[k0 + 3] = base + a0 + a1 + a2;
-        if (threadIdx.x == 63) S.lstart[CBINS_MAX] = x;
-    }
-}
-
-// level 1: a workgroup's FCHUNK scalars x nwin windows, SUB entry slots (SUB / FCHUNK windows) at a time: sorted in LDS by
-// coarse bin and appended to the workgroup's range of every bin of `inter` (reserved by msm_recode_hist2_kernel)
-__global__ __launch_bounds__(256) void msm_scatter1_kernel(const int16_t* __restrict__ digits_all, uint32_t n, uint32_t stride, uint32_t nwin,
-                                                           uint32_t nb, uint32_t table_stride, const uint32_t* __restrict__ coarse_all,
-                                                           uint32_t coarse_stride, uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                           uint32_t fb) {
-    __shared__ SortLds S;
-    const uint32_t col = blockIdx.y;
-    const int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
-    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    const uint32_t* __restrict__ cbase = chdr + COARSE_WORDS + (size_t)blockIdx.x * CBINS_MAX;
-    uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
-    const uint32_t bins = nb >> fb, fmask = (1u << fb) - 1;
-    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    if (threadIdx.x < bins) S.gbase[threadIdx.x] = chdr[threadIdx.x] + cbase[threadIdx.x];
-    constexpr uint32_t WPS = SUB / FCHUNK;      // windows per sub-round
-    constexpr uint32_t PER = SUB / 256;         // entry slots per lane and sub-round
-    for (uint32_t w0 = 0; w0 < nwin; w0 += WPS) {
-        if (threadIdx.x < CBINS_MAX) S.cnt[threadIdx.x] = 0;
-        __syncthreads();
-        uint32_t ent[PER], meta[PER];  // meta = key << 16 | rank, 0xffffffff = no entry
-#pragma unroll
-        for (uint32_t q = 0; q < PER; q++) {
-            const uint32_t e = threadIdx.x + q * 256;  // slot: window w0 + e / FCHUNK, scalar lo + e % FCHUNK
-            const uint32_t w = w0 + e / FCHUNK, i = lo + (e % FCHUNK);
-            meta[q] = 0xffffffffu;
-            if (w < nwin && i < hi) {
-                const int32_t d = digits[(size_t)w * stride + i];
-                if (d != 0) {
-                    const uint32_t bkt = (uint32_t)(d < 0 ? -d : d) - 1;
-                    const uint32_t key = bkt >> fb;
-                    ent[q] = (w * table_stride + i) | ((bkt & fmask) << 24) | (d < 0 ? SIGN_BIT : 0);
-                    meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        sort_scan(S, bins);
-        __syncthreads();
-#pragma unroll
-        for (uint32_t q = 0; q < PER; q++)
-            if (meta[q] != 0xffffffffu) {
-                const uint32_t key = meta[q] >> 16, pos = S.lstart[key] + (meta[q] & 0xffffu);
-                S.sorted[pos] = ent[q];
-                S.kid[pos] = (uint8_t)key;
-            }
-        __syncthreads();
-        const uint32_t total = S.lstart[CBINS_MAX];
-        for (uint32_t q = threadIdx.x; q < total; q += 256) {
-            const uint32_t key = S.kid[q];
-            inter[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
-        }
-        __syncthreads();
-        if (threadIdx.x < bins) S.gbase[threadIdx.x] += S.cnt[threadIdx.x];
-    }
-}
-
-// level 2: one chunk (<= SUB entries) of one coarse bin into its 64 buckets; also the bucket padding (skip markers)
-__global__ __launch_bounds__(256) void msm_scatter2_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                           const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, uint32_t nb,
-                                                           const uint32_t* __restrict__ totals_all,
-                                                           const uint32_t* __restrict__ bucket_start_all, uint32_t* __restrict__ cursor_all,
-                                                           uint32_t* __restrict__ entries_all, uint32_t fb, uint32_t pad,
-                                                           size_t ent_stride, const uint8_t* __restrict__ delta_all) {
-    // 13 / 14-bit plan: the bucket starts of all columns index one dense entry list (ent_stride = 0), ranges padded to
-    // PAD entries (skip markers); wide path (delta_all != nullptr): column-local starts, one entry region per column, no
-    // padding (pad = 1) — the first entry of every bucket carries WIDE_FLAG and the bucket's distance from the previous
-    // non-empty one (msm_binscan_kernel) in its spare bits
-    __shared__ SortLds S;
-    __shared__ uint32_t s_bin, s_chunk;
-    __shared__ uint32_t s_mark[CBINS_MAX];  // wide path: flag bits of a key's first entry when this chunk holds the bucket's first
-    const uint32_t col = blockIdx.y;
-    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
-    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
-    const uint32_t* __restrict__ bucket_start = bucket_start_all + (size_t)col * nb;
-    uint32_t* __restrict__ cursor = cursor_all + (size_t)col * nb;
-    uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
-    const uint32_t bins = nb >> fb, keys = 1u << fb;
-    // this workgroup's share of the bucket padding (skip markers up to the next multiple of `pad`)
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
-        const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b] + ((totals[b] + pad - 1) & ~(pad - 1));
-        for (uint32_t q = beg; q < end; q++) entries[q] = SKIP_ENTRY;
-    }
-    const uint32_t* cpre = chdr + (CBINS_MAX + 1);
-    if (blockIdx.x >= cpre[bins]) return;  // the grid is sized for the worst case
-    if (threadIdx.x == 0) {
-        uint32_t lo = 0, hi = bins;  // the bin whose chunk range holds blockIdx.x
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (cpre[mid] <= blockIdx.x) lo = mid;
-            else hi = mid;
-        }
-        s_bin = lo;
-        s_chunk = blockIdx.x - cpre[lo];
-    }
-    if (threadIdx.x < keys) S.cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t bin = s_bin;
-    const uint32_t beg = chdr[bin] + s_chunk * SUB;
-    const uint32_t end = min(chdr[bin + 1], beg + SUB);
-    constexpr uint32_t PER = SUB / 256;
-    uint32_t ent[PER], meta[PER];
-#pragma unroll
-    for (uint32_t q = 0; q < PER; q++) {
-        const uint32_t p = beg + threadIdx.x + q * 256;
-        meta[q] = 0xffffffffu;
-        if (p < end) {
-            const uint32_t e = inter[p];
-            const uint32_t key = (e >> 24) & (keys - 1);
-            ent[q] = e & ~((keys - 1) << 24);
-            meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
-        }
-    }
-    __syncthreads();
-    sort_scan(S, keys);
-    if (threadIdx.x < keys) {
-        const uint32_t cnt = S.cnt[threadIdx.x], b = bin * keys + threadIdx.x;
-        const uint32_t before = cnt ? atomicAdd(&cursor[b], cnt) : 0;
-        S.gbase[threadIdx.x] = bucket_start[b] + before;
-        s_mark[threadIdx.x] = (delta_all && cnt && before == 0) ? (WIDE_FLAG | ((uint32_t)delta_all[(size_t)col * nb + b] << 24)) : 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t q = 0; q < PER; q++)
-        if (meta[q] != 0xffffffffu) {
-            const uint32_t key = meta[q] >> 16, pos = S.lstart[key] + (meta[q] & 0xffffu);
-            S.sorted[pos] = ent[q];
-            S.kid[pos] = (uint8_t)key;
-        }
-    __syncthreads();
-    const uint32_t total = end - beg;
-    for (uint32_t q = threadIdx.x; q < total; q += 256) {
-        const uint32_t key = S.kid[q];
-        entries[S.gbase[key] + q - S.lstart[key]] = S.sorted[q] | (q == S.lstart[key] ? s_mark[key] : 0u);
-    }
-}
-
-#ifndef ZK_SCAT_T
-#define ZK_SCAT_T 256
-#endif
-static constexpr uint32_t SCAT_T = ZK_SCAT_T;  // lanes of a scatter workgroup (FCHUNK / SCAT_T scalars per lane)
-__global__ __launch_bounds__(SCAT_T) void msm_scatter_fixed_kernel(const int16_t* __restrict__ digits_all, uint32_t n, uint32_t stride,
-                                                                uint32_t nwin, uint32_t nb, uint32_t table_stride,
-                                                                const uint32_t* __restrict__ totals_all,
-                                                                const uint32_t* __restrict__ bucket_start_all,
-                                                                const uint32_t* __restrict__ blockbase_all,
-                                                                uint32_t* __restrict__ entries) {
-    extern __shared__ uint32_t lds[];  // nb cursors
-    // column blockIdx.y of the launch: its digit planes, bucket totals / starts ([nb] is the next column's first
-    // start, or the grand total) and reserved ranges
-    const uint32_t col = blockIdx.y;
-    const int16_t* __restrict__ digits = digits_all + (size_t)col * nwin * stride;
-    const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
-    const uint32_t* __restrict__ bucket_start = bucket_start_all + (size_t)col * nb;
-    const uint32_t* __restrict__ blockbase = blockbase_all + (size_t)col * gridDim.x * nb;
-    for (uint32_t b = threadIdx.x; b < nb; b += SCAT_T) lds[b] = bucket_start[b] + blockbase[(size_t)blockIdx.x * nb + b];
-    // this workgroup's share of the bucket padding (skip markers up to the next multiple of PAD)
-    for (uint32_t b = blockIdx.x * SCAT_T + threadIdx.x; b < nb; b += gridDim.x * SCAT_T) {
-        const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
-        for (uint32_t q = beg; q < end; q++) entries[q] = SKIP_ENTRY;
-    }
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    constexpr uint32_t PER = FCHUNK / SCAT_T;  // scalars per thread
-    // the digits of window w + 1 are loaded while those of window w are scattered (the loop is otherwise a
-    // chain of load -> LDS atomic -> store latencies at two waves per SIMD)
-    int32_t cur[PER], nxt[PER];
-#pragma unroll
-    for (uint32_t q = 0; q < PER; q++) {
-        const uint32_t i = lo + threadIdx.x + q * SCAT_T;
-        cur[q] = i < hi ? digits[i] : 0;
-    }
-    for (uint32_t w = 0; w < nwin; w++) {
-        if (w + 1 < nwin) {
-            const int16_t* dg = digits + (size_t)(w + 1) * stride;
-#pragma unroll
-            for (uint32_t q = 0; q < PER; q++) {
-                const uint32_t i = lo + threadIdx.x + q * SCAT_T;
-                nxt[q] = i < hi ? dg[i] : 0;
-            }
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < PER; q++) {
-            const int32_t d = cur[q];
-            if (d == 0) continue;
-            const uint32_t i = lo + threadIdx.x + q * SCAT_T;
-            const uint32_t pos = atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
-            entries[pos] = (w * table_stride + i) | (d < 0 ? SIGN_BIT : 0);
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < PER; q++) cur[q] = nxt[q];
-    }
-}
-
-// exclusive scan of the bucket sizes, each rounded up to a multiple of PAD (so that neither an
-// accumulate lane nor a first-level gather lane straddles two buckets): out[0..m], out[m] = padded total = counts[0]
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                        uint32_t m, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t part[1024];
-    const uint32_t chunk = (m + 1023) / 1024;
-    const uint32_t lo = min(m, threadIdx.x * chunk);
-    const uint32_t hi = min(m, lo + chunk);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += (in[i] + PAD - 1) & ~(PAD - 1);
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (threadIdx.x >= d) ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t h = (in[i] + PAD - 1) & ~(PAD - 1);
-        out[i] = run;
-        run += h;
-    }
-    if (threadIdx.x == 1023) {
-        out[m] = part[1023];
-        counts[0] = part[1023];
-    }
-}
-
-// fill the padding at the end of every bucket with skip markers
-__global__ void msm_pad_kernel(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ bucket_start, uint32_t m,
-                               uint32_t* __restrict__ entries) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= m) return;
-    const uint32_t beg = bucket_start[b] + totals[b], end = bucket_start[b + 1];
-    for (uint32_t p = beg; p < end; p++) entries[p] = SKIP_ENTRY;
-}
-
-// ------------------------------------------------------------ accumulate ---
-
-// Every lane sums one aligned segment of SEG0 entries; bucket ranges are padded to multiples
-// of SEG0, so a segment lies inside ONE bucket and yields one partial sum ("slot").
-// four waves per SIMD (128 registers; the few values that do not fit live in scratch words of the rare paths): needed by the
-// serial multiply-add columns of the addition (field29.hip.h mul29s), neutral otherwise
-#ifndef ZK_ACC_WAVES
-#define ZK_ACC_WAVES 4
-#endif
-// One segment.  SAFE: every addition tests for the identity as an operand and for the exceptional cases (same x as the running
-// sum: a doubling or a cancellation), which are redone on the general formulas — exact for any input.  Otherwise no test at
-// all (4 % faster: it is the branches around the fallback more than the instructions): the caller vouches that no base is the
-// identity and checks the segment's ZZ afterwards.
-template <bool SAFE>
-__device__ __forceinline__ G1X29 accumulate_segment(const uint32_t* __restrict__ e, const G1Affine* __restrict__ bases) {
-    G1X29 acc;
-    acc.inf = true;
-    for (uint32_t k = 0; k < SEG0; k++) {
-        const uint32_t y = e[k];
-        if (y == SKIP_ENTRY) continue;  // padding at the end of a bucket
-        G1Affine p = affine_load(bases + (y & ~SIGN_BIT));
-        if (SAFE && affine_is_identity(p)) continue;
-        if (y & SIGN_BIT) p.y = fe_neg(p.y);
-        if (!g1x29_add_affine<SAFE>(acc, p.x, p.y)) {
-            // same x as the running sum (doubling or cancellation): the general formulas, rarely
-            G1X s = g1x29_to_std(acc);
-            g1x_add_affine(s, p.x, p.y);
-            acc = g1x29_from_std(s);
-        }
-    }
-    return acc;
-}
-
-// Checked kernel: exact for any bases (arbitrary bases of the fine-grained seam; an SRS that holds the identity).
-#if ZK_ACC_WAVES
-__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
-#endif
-__global__ __launch_bounds__(64) void msm_accumulate_kernel(const uint32_t* __restrict__ entries,
-                                                            const G1Affine* __restrict__ bases,
-                                                            const uint32_t* __restrict__ counts,
-                                                            G1X29S* __restrict__ slot_pt) {
-    const uint32_t total = counts[0];  // multiple of SEG0
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t * SEG0 >= total) return;
-    // the running sum lives on the carry-free 29-bit-limb field (ec29.hip.h); bases are read in
-    // their standard memory form, the slot is written in the internal one (the reduction tails stay on that field)
-    g1x29_store(slot_pt + t, accumulate_segment<true>(entries + (size_t)t * SEG0, bases));
-}
-
-// Unchecked kernel for a basis without the identity (the resident SRS): no test at all in the loop, and none of the
-// fallback code in the kernel.  An exceptional step leaves ZZ = 0 (ZZ is the product of the squared x-differences and p is
-// prime): such segments are listed (counts[1], redo[]) and msm_accumulate_redo_kernel, which always follows, redoes them with
-// the checked loop — with distinct bases a handful of segments per MSM, if any.
-#if ZK_ACC_WAVES
-__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
-#endif
-__global__ __launch_bounds__(64) void msm_accumulate_fast_kernel(const uint32_t* __restrict__ entries,
-                                                                 const G1Affine* __restrict__ bases,
-                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ redo,
-                                                                 G1X29S* __restrict__ slot_pt) {
-    const uint32_t total = counts[0];  // multiple of SEG0
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t * SEG0 >= total) return;
-    const G1X29 acc = accumulate_segment<false>(entries + (size_t)t * SEG0, bases);
-    if (!acc.inf && is_zero29(acc.zz)) redo[atomicAdd(&counts[1], 1u)] = t;  // at most one entry per segment: redo[] has one word each
-    g1x29_store(slot_pt + t, acc);
-}
-__global__ __launch_bounds__(64) void msm_accumulate_redo_kernel(const uint32_t* __restrict__ entries,
-                                                                 const G1Affine* __restrict__ bases,
-                                                                 const uint32_t* __restrict__ counts, const uint32_t* __restrict__ redo,
-                                                                 G1X29S* __restrict__ slot_pt) {
-    const uint32_t m = counts[1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const uint32_t t = redo[i];
-        g1x29_store(slot_pt + t, accumulate_segment<true>(entries + (size_t)t * SEG0, bases));
-    }
-}
-
-// start-of-MSM reset in one launch: bucket parts = identity, bucket totals = 0, counts = 0
-__global__ void msm_clear_kernel(G1X29S* __restrict__ p, uint32_t m, uint32_t* __restrict__ totals, uint32_t nt,
-                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, uint32_t ncur,
-                                 uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) g1x29_store(p + i, g1x29_identity());
-    if (i < nt) totals[i] = 0;
-    if (i < 4 * (ncols + 1)) counts[i] = 0;
-    if (i < ncur) cursor[i] = 0;  // second-level write cursors (two-level sort)
-    if (i < ncols * CBINS_MAX) coarse[(size_t)(i / CBINS_MAX) * coarse_stride + 2 * (CBINS_MAX + 1) + (i % CBINS_MAX)] = 0;  // first-level append cursors
-}
-
-#ifdef ZK_TAIL_TRACE  // tools/ubench_tail.hip: where a bit-sum workgroup spends its time (100 MHz wall clock stamps)
-__device__ unsigned long long zk_tail_trace[16];
-__device__ unsigned long long zk_wg_trace[3][8192];  // per-workgroup begin / middle / end of the last traced kernel
-#define ZK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) zk_tail_trace[i] = wall_clock64(); } while (0)
-#define ZK_WG_STAMP(i) do { if (blockIdx.x < 8192 && threadIdx.x == 0) zk_wg_trace[i][blockIdx.x] = wall_clock64(); } while (0)
-#else
-#define ZK_STAMP(i) do { } while (0)
-#define ZK_WG_STAMP(i) do { } while (0)
-#endif
-
-// ---- reduction tails.  The partial sums stay on the carry-free 29-bit-limb field (ec29.hip.h: 3 300 instructions per
-// general XYZZ addition with the products inlined, against 4 600 through out-of-line 8 x 32-bit products, and no dependent
-// carry chains — these kernels run at one or two waves per SIMD, where a chained product is latency-bound).  Every kernel
-// is shaped so that it has ONE inlined addition (a loop that fetches its operand from memory, from a shuffle or from LDS
-// and then adds): three copies of the addition would not fit the instruction cache.
-
-// First-level gather: every lane sums GA consecutive slots serially (same bucket by alignment):
-// dense lanes, no idle tree steps — this is where most of the slot additions happen.
-__global__ __launch_bounds__(64) void msm_gather1_kernel(const G1X29S* __restrict__ slot_pt, const uint32_t* __restrict__ counts,
-                                                         G1X29S* __restrict__ partial) {
-    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if ((size_t)t * PAD >= counts[0]) return;
-    const G1X29S* src = slot_pt + (size_t)t * GA;
-    G1X29 acc = g1x29_load(src);
-#pragma unroll 1
-    for (uint32_t k = 1; k < GA; k++) {
-        const G1X29 v = g1x29_load(src + k);
-        g1x29_add<ZK_TAIL_SER>(acc, v);
-    }
-    g1x29_store(partial + t, acc);
-}
-
-// Parts of bucket b that the second-level gather writes and the bit sums read — ONE definition for both kernels: the
-// parts are not reset between MSMs (msm_run), so a disagreement would make the bit sums read a previous MSM's sums.
-// -DZK_MSM_POISON fills the parts with a non-point before every MSM to catch exactly that.
-__device__ __forceinline__ uint32_t msm_used_parts(const uint32_t* __restrict__ bucket_start, uint32_t b, uint32_t parts) {
-    const uint32_t len = bucket_start[b + 1] / PAD - bucket_start[b] / PAD;
-    return min(parts, (len + GSHARE - 1) / GSHARE);
-}
-
-// Second level: one LANES-lane group per (bucket b, part p) sums the p-th share of the bucket's
-// first-level partials ([start_b / PAD, start_{b+1} / PAD) — contiguous, all of bucket b): lanes
-// stride over the share, then a shuffle tree.  A bucket uses ceil(partials / (4 * LANES)) parts
-// (at most `parts`); the others stay identity.
-template <uint32_t LANES>
-__global__ __launch_bounds__(256) void msm_gather_kernel(const uint32_t* __restrict__ bucket_start,
-                                                         const G1X29S* __restrict__ partial, uint32_t parts, uint32_t ngroups,
-                                                         G1X29S* __restrict__ part) {
-    const uint32_t gid = (blockIdx.x * 256 + threadIdx.x) / LANES;
-    const uint32_t lane = threadIdx.x & (LANES - 1);
-    G1X29 acc = g1x29_identity();
-    bool active = false;
-    uint32_t b = 0, p = 0, s = 0, a1 = 0;
-    if (gid < ngroups) {
-        // part-major: the groups of part 0 (the only one most buckets use) are adjacent, so their waves are
-        // full and the waves of the unused parts exit at once
-        const uint32_t nbk = ngroups / parts;
-        p = gid / nbk;
-        b = gid - p * nbk;
-        const uint32_t s0 = bucket_start[b] / PAD, s1 = bucket_start[b + 1] / PAD;
-        const uint32_t len = s1 - s0;
-        const uint32_t used = msm_used_parts(bucket_start, b, parts);
-        if (p < used) {
-            active = true;
-            const uint32_t share = (len + used - 1) / used;
-            const uint32_t a0 = s0 + p * share;
-            a1 = min(s1, a0 + share);
-            s = a0 + lane;
-        }
-    }
-    if (!__any(active)) return;  // wave-uniform: no group of this wave has work
-    // the serial part (lanes stride over the share) and the shuffle tree feed the same addition
-    int off = LANES >> 1;
-    ZK_STAMP(8);
-    ZK_WG_STAMP(0);
-#pragma unroll 1
-    for (;;) {
-        G1X29 v;
-        bool have;
-        if (__any(active && s < a1)) {  // wave-uniform
-            have = active && s < a1;
-            if (have) v = g1x29_load(partial + s);
-            s += LANES;
-        } else {
-            if (off == 0) break;
-            if (off == (int)(LANES >> 1)) {
-                ZK_STAMP(9);
-                ZK_WG_STAMP(1);
-            }
-            v = g1x29_shfl_down(acc, off);  // every lane of the wave takes part in the shuffles
-            have = (int)lane < off;
-            off >>= 1;
-        }
-        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
-    }
-    ZK_STAMP(10);
-    ZK_WG_STAMP(2);
-    if (active && lane == 0) g1x29_store(part + (size_t)b * parts + p, acc);
-}
-
-// ---------------------------------------------------------------- reduce ---
-// sum_j j * B_j = sum_t 2^t * G_t with G_t = sum of the buckets whose multiplier j has
-// bit t set: c tree reductions per bucket set instead of 2^(c-1) scalar multiplications.
-// grid = slices * c * split workgroups of THREADS lanes, one multiplier per lane: the shape follows the
-// bucket count (2^(c-1) / 2 multipliers per bit: 4 x 512 lanes at c = 13, 1 x 128 at c = 9), so that the
-// tree is no deeper than the data and small bucket sets do not launch idle waves.  The host adds the
-// `split` partials of a bit and runs the c-term Horner (on the standard form: the one lane that writes a
-// bit sum converts it).
-static constexpr uint32_t BITSUM_MAX_SPLIT = 4;
-// One wave per workgroup.  Measured on the 4 x 2048 multipliers of a 13-bit window (tools/ubench_bitsum.hip): workgroups of
-// 512 lanes (one multiplier per lane, a cross-wave step through LDS) 205 us, 256 lanes 140, 128 lanes 113, 64 lanes 107 —
-// the hardware packs the waves of a workgroup two or three to a SIMD even on an idle chip, each tree step then costs two or
-// three additions, and the others wait at the barrier; a lone wave per workgroup gets a SIMD to itself.
-static uint32_t bitsum_threads(uint32_t nb) {
-    (void)nb;
-    return 64;
-}
-static uint32_t bitsum_split(uint32_t nb) {
-    uint32_t s = (nb >> 1) / 512;
-    if (s < 1) s = 1;
-    if (s > BITSUM_MAX_SPLIT) s = BITSUM_MAX_SPLIT;
-    return s;
-}
-template <uint32_t THREADS>
-__global__ __launch_bounds__(THREADS) void msm_bitsum_kernel(const G1X29S* __restrict__ part, uint32_t parts, uint32_t nb,
-                                                             uint32_t c, uint32_t split, const uint32_t* __restrict__ bucket_start,
-                                                             G1X* __restrict__ out) {
-    __shared__ G1X29S sh[THREADS / 64];
-    const uint32_t q = blockIdx.x % split;
-    const uint32_t st = blockIdx.x / split;
-    const uint32_t slice = st / c, t = st - slice * c;
-    const uint32_t wave = threadIdx.x >> 6;
-    G1X29 acc = g1x29_identity();
-    // the multipliers j in [1, nb] with bit t set, enumerated densely (no lane idles on a clear bit):
-    // t < c-1: j = i with a 1 inserted at bit t, i < nb/2;  t = c-1: j = nb only
-    const uint32_t items = t + 1 < c ? nb >> 1 : 1;
-    uint32_t i = q * THREADS + threadIdx.x, k = 0;
-    // parts of a bucket the gather kernel wrote (the others are identity and not worth a round trip to memory)
-    const auto used_parts = [&](uint32_t b) { return msm_used_parts(bucket_start, b, parts); };
-    const auto multiplier = [&](uint32_t ii) { return t + 1 < c ? (((ii >> t) << (t + 1)) | (1u << t) | (ii & ((1u << t) - 1))) : nb; };
-    uint32_t used = 0;
-    ZK_STAMP(0);
-    while (i < items && (used = used_parts(slice * nb + multiplier(i) - 1)) == 0) i += THREADS * split;
-    ZK_STAMP(1);
-    // stage 0: the lane's multipliers (serial), then a shuffle tree over the wave; stage 1 (wave 0 only): the
-    // per-wave sums from LDS and a shuffle tree over them.  One loop, one addition.
-    int off = 32;
-    uint32_t lanes = 64;
-#pragma unroll 1
-    for (uint32_t stage = 0;; stage++) {
-#pragma unroll 1
-        for (;;) {
-            G1X29 v;
-            bool have;
-            if (stage == 0 && __any(i < items)) {  // wave-uniform
-                have = i < items;
-                if (have) {
-                    v = g1x29_load(part + ((size_t)slice * nb + (multiplier(i) - 1)) * parts + k);
-                    if (++k == used) {
-                        k = 0;
-                        i += THREADS * split;
-                        while (i < items && (used = used_parts(slice * nb + multiplier(i) - 1)) == 0) i += THREADS * split;
-                    }
-                }
-            } else {
-                if (off == 0) break;
-                if (stage == 0 && off == 32) ZK_STAMP(2);
-                v = g1x29_shfl_down(acc, off);
-                have = (threadIdx.x & (lanes - 1)) < (uint32_t)off;
-                off >>= 1;
-            }
-            if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
-        }
-        ZK_STAMP(3 + 2 * stage);
-        if (THREADS == 64 || stage == 1) break;
-        if ((threadIdx.x & 63) == 0) g1x29_store(sh + wave, acc);
-        __syncthreads();
-        ZK_STAMP(4);
-        if (wave != 0) return;
-        acc = (threadIdx.x < THREADS / 64) ? g1x29_load(sh + threadIdx.x) : g1x29_identity();
-        lanes = THREADS / 64;
-        off = (int)(THREADS / 128);
-    }
-    if (threadIdx.x == 0) {
-        G1X r = G1X::identity();
-        if (!acc.inf) {
-            r.x = internal_to_std_call(acc.x);
-            r.y = internal_to_std_call(acc.y);
-            r.zz = internal_to_std_call(acc.zz);
-            r.zzz = internal_to_std_call(acc.zzz);
-        }
-        g1x_store(out + blockIdx.x, r);
-        ZK_STAMP(6);
-    }
-}
-
-// ================================================================== wide path ==
-// Windows of 15 / 16 bits (fixed-base mode): 17 / 16 bucket additions per scalar instead of 20 at 13 bits, paid for with
-// 16384 / 32768 buckets per column.  What changes against the 13-bit plan above:
-//   * the two-level sort splits a bucket index into an 8-bit coarse bin and a 7-bit fine key (128 buckets per bin); the
-//     digits kernel counts coarse bins only, the per-bucket totals are counted from the binned intermediate list
-//     (32768 LDS counters per workgroup would cost 6.7 M global atomics per 2^19 column);
-//   * every column owns a region of the entry / slot / part lists, and all scans are local to a coarse bin;
-//   * NO PADDING: the entry list is dense.  A lane of the accumulation sums WL consecutive entries whatever buckets they
-//     fall in: the first entry of every bucket carries a flag, at which the lane stores its running sum (one "slot" per
-//     (lane, bucket) pair: slot index = lane + bucket, unique and ordered along the staircase of the pairs) and restarts.
-//     A restart costs a few moves because the window tables of this path hold the points in the accumulation's internal
-//     form (x * 2^261: g1x29_add_affine<.., INTERNAL>).  Against 16-entry segments padded per bucket: no padding lanes
-//     (3 %), no skip markers to write, and the run length WL is free to choose (measured below);
-//   * the reduction tail is shaped for many small buckets: (T1) one lane per "part" of at most WCAP slots sums it
-//     serially, lanes of the same bucket inside a wave are joined by a segmented shuffle tree; (T2) the bucket matrix
-//     [rows = nb / 256][256] is summed along its rows and along its columns, one wave each —
-//     sum_b (b + 1) B_b = 256 sum_h h R_h + sum_l (l + 1) C_l — and (T3) the short weighted sums over h and l + 1 are
-//     taken bit by bit (log2(rows) + 9 tree reductions per column); the host runs the 16-step Horner.
-// slots per part (T1's serial run), a per-pass parameter.  8 everywhere: lane-serial additions are the cheap ones (every lane
-// busy); shorter runs for a lone column — whose tail is exposed latency — were measured (tools/single_ab.py, k = 19 single
-// proof): 8: 12.37-12.41 ms, 4: 12.41-12.49, 2: 12.55-12.60 (more waves and more tree levels cost what the shorter chain saves)
-#ifndef ZK_WCAP_BATCH
-#define ZK_WCAP_BATCH 8
-#endif
-static constexpr uint32_t WCAP_MIN = 2, WCAP_BATCH = ZK_WCAP_BATCH;  // WCAP_MIN sizes the part lists
-#ifndef ZK_WCAP_ONE
-#define ZK_WCAP_ONE 8
-#endif
-static inline uint32_t wcap_for(uint32_t batch) { return batch == 1 ? (uint32_t)ZK_WCAP_ONE : WCAP_BATCH; }
-static constexpr uint32_t WIDE_SUMS = 20; // bit sums per column handed to the host: 9 column bits, then up to 8 row bits (65 536 buckets)
-#ifndef ZK_WL
-#define ZK_WL 16
-#endif
-// entries per accumulation lane.  Measured with whole proofs, two pipelines in flight (tools/bench_ab.sh, proofs/s | single
-// proof ms): 8: 90.0 | 12.9, 11: 91.4 | 12.9, 12: 92.8 | 12.5, 16: 95.0 | 12.2, 32: 91.4 | 12.8, 48: 85.8 | 13.7, 64: 84.4 | 13.9
-// — short runs mean more slots for the reduction tail to add up, long runs fewer, longer waves that share the chip badly
-// with the other kernels in flight (a 2^19 column is 8192 waves of 16 additions)
-static constexpr uint32_t WL = ZK_WL;
-// slots of a bucket whose cnt > 0 entries start at position s of the column's entry list: one per lane that holds some of them
-__device__ __forceinline__ uint32_t wide_slot_count(uint32_t s, uint32_t cnt) { return cnt ? (s + cnt - 1) / WL - s / WL + 1 : 0; }
-
-// ---- the wide path's head (round 4): digits in registers, windows of 15 / 16 / 17 bits, table indexes of 24 .. 26 bits ----
-// What changed against the round-3 head (digit planes in int16, a kernel per scan):
-//   * signed digits without a carry chain: with K = sum_w 2^(c - 1 + w c) the unsigned windows u_w of s + K give
-//     d_w = u_w - 2^(c-1) in [-2^(c-1), 2^(c-1)) with sum_w d_w 2^(w c) = s — the same digits as the carry recoding (the
-//     expansion with all digits in that range is unique), but window w needs nothing from window w - 1.  So the digits are
-//     recomputed from the scalar wherever they are needed and the int16 digit planes (and their 16-bit limit) are gone;
-//   * 17-bit windows: 15 bucket additions per scalar instead of 16 (65 536 buckets per column, 512 coarse bins);
-//   * an entry's table index takes ib = 24 .. 26 bits (16 windows x 2^21 points need 25), the fine key / distance fields
-//     the rest: fb = 31 - ib fine bits (128 / 64 / 32 buckets per coarse bin), 30 - ib distance bits;
-//   * the coarse scan is the prologue of the first scatter (every workgroup scans the <= 512 bin totals itself, workgroup
-//     0 publishes the header), the reset of the counters is the epilogue of the last tail kernel.
-static constexpr uint32_t WCB = 512;                  // coarse bins at most (65 536 buckets / 128, or 32 768 / 64)
-// per column: bin starts, chunk prefix, (unused), (unused), part regions — WCB + 1 words each — then the append cursors, ONE
-// PER 128-BYTE LINE: every workgroup of H1 ends with a returning atomic per bin on them (131 K atomics on 256 words per 2^19
-// column); side by side they would all land on 8 cache lines
-#ifndef ZK_WCUR_STRIDE
-#define ZK_WCUR_STRIDE 32
-#endif
-static constexpr uint32_t WCUR = ZK_WCUR_STRIDE;      // words between two append cursors
-static constexpr uint32_t WCUR0 = 5 * (WCB + 1);      // first cursor
-static constexpr uint32_t WHDR = WCUR0 + WCB * WCUR;  // words of the header; the workgroups' reserved bases [blocks][WCB] follow
-static constexpr uint32_t WSUB = 256 * 17;            // entries of a scatter sub-round: 256 scalars x all their windows (<= 17)
-
-struct WideGeo {
-    uint32_t c, nwin, nb;   // window bits, windows, buckets per column
-    uint32_t ib, fb, bins;  // table index bits, fine key bits, coarse bins = nb >> fb
-    uint32_t K[8];          // the recoding bias sum_w 2^(c - 1 + w c)
-};
-
-// u = (s + K) as 9 words (canonical s: the Montgomery image is taken off here)
-__device__ __forceinline__ void wide_biased(const Fr& mont, const WideGeo& g, uint32_t (&u)[9]) {
-    const Fr s = fe_from_mont(mont);
-    uint64_t cy = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        cy += (uint64_t)s.v[k] + g.K[k];
-        u[k] = (uint32_t)cy;
-        cy >>= 32;
-    }
-    u[8] = (uint32_t)cy;  // 0: s + K < 2^256 (see msm_wide_geo)
-}
-// digit w of the biased scalar: C, w compile-time -> static register indexing
-template <uint32_t C>
-__device__ __forceinline__ int32_t wide_digit(const uint32_t (&u)[9], uint32_t w) {
-    const uint32_t bit = w * C, word = bit >> 5, off = bit & 31;
-    const uint64_t two = (uint64_t)u[word] | ((uint64_t)u[word + 1] << 32);
-    return (int32_t)((uint32_t)(two >> off) & ((1u << C) - 1)) - (int32_t)(1u << (C - 1));
-}
-
-// exclusive scan of f(in[k]), k < bins <= 512, by ONE wave (eight consecutive bins per lane): out[k], out[bins] = total
-template <class F>
-__device__ __forceinline__ void wide_wave_scan(const uint32_t* in, uint32_t bins, uint32_t* out, F f) {
-    const uint32_t lane = threadIdx.x & 63, k0 = lane * 8;
-    uint32_t v[8], s = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        v[j] = k0 + j < bins ? f(in[k0 + j]) : 0;
-        s += v[j];
-    }
-    uint32_t x = s;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off);
-        if ((int)lane >= off) x += y;
-    }
-    uint32_t run = x - s;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (k0 + j < bins) out[k0 + j] = run;
-        run += v[j];
-    }
-    if (lane == 63) out[bins] = x;
-}
-
-// H1: coarse histogram of a workgroup's FCHUNK scalars (all windows) and the reservation of its range inside every coarse
-// bin of `inter`: one returning atomic per non-empty bin on the append cursors, which end up holding the bins' totals
-template <uint32_t C>
-__global__ __launch_bounds__(256) void msm_whist_kernel(MsmBatch batch, uint32_t n, WideGeo g, uint32_t* __restrict__ coarse_all,
-                                                        uint32_t coarse_stride, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t hist[WCB];
-    constexpr uint32_t NWIN = 254 / C + 1;
-    const uint32_t col = blockIdx.y;
-    const Fr* __restrict__ scalars = batch.s[col];
-    uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    if (col == 0 && blockIdx.x == 0 && threadIdx.x == 0) counts[1] = 0;  // this pass's redo count
-    for (uint32_t b = threadIdx.x; b < g.bins; b += 256) hist[b] = 0;
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    constexpr uint32_t PERL = FCHUNK / 256;
-    Fr sv[PERL];  // the lane's scalars, all loads in flight together
-#pragma unroll
-    for (uint32_t q = 0; q < PERL; q++) {
-        const uint32_t i = lo + threadIdx.x + q * 256;
-        sv[q] = i < hi ? fe_load(scalars + i) : Fr::zero();
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < PERL; q++) {
-        if (lo + threadIdx.x + q * 256 >= hi) break;
-        uint32_t u[9];
-        wide_biased(sv[q], g, u);
-#pragma unroll
-        for (uint32_t w = 0; w < NWIN; w++) {
-            const int32_t d = wide_digit<C>(u, w);
-            if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1) >> g.fb], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < g.bins; b += 256) {
-        const uint32_t sum = hist[b];
-        chdr[WHDR + (size_t)blockIdx.x * WCB + b] = sum ? atomicAdd(&chdr[WCUR0 + b * WCUR], sum) : 0;
-    }
-}
-
-struct WSortLds {
-    uint32_t cnt[WCB], lstart[WCB + 1], gbase[WCB];
-    uint32_t sorted[WSUB];
-    uint16_t kid[WSUB];
-};
-
-// H2: level 1 of the sort.  Prologue: the bins' places in `inter` from the totals H1 left in the append cursors (every
-// workgroup scans them itself; workgroup 0 of a column also publishes the header the later kernels read: bin starts, the
-// chunk prefix of level 2, the bins' part regions — sized for the worst case, every bucket of a bin one slot and one part
-// more than its share — and counts[4 col] = entries, counts[4 col + 2] = the end of the last part region).  Then, 256
-// scalars at a time: digits in registers, entries sorted in LDS by coarse bin, runs appended to the workgroup's ranges.
-template <uint32_t C>
-__global__ __launch_bounds__(256) void msm_wscatter1_kernel(MsmBatch batch, uint32_t n, WideGeo g, uint32_t table_stride,
-                                                            uint32_t* __restrict__ coarse_all, uint32_t coarse_stride,
-                                                            uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                            uint32_t* __restrict__ counts, uint32_t WCAP) {
-    __shared__ WSortLds S;
-    constexpr uint32_t NWIN = 254 / C + 1;
-    constexpr uint32_t CB = WCB + 1;
-    const uint32_t col = blockIdx.y;
-    const Fr* __restrict__ scalars = batch.s[col];
-    uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    const uint32_t* __restrict__ cbase = chdr + WHDR + (size_t)blockIdx.x * WCB;
-    uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
-    const uint32_t bins = g.bins, keys = 1u << g.fb;
-    for (uint32_t b = threadIdx.x; b < bins; b += 256) S.cnt[b] = chdr[WCUR0 + b * WCUR];  // the bins' totals (H1's cursors)
-    __syncthreads();
-    const uint32_t* tot = S.cnt;
-    if (threadIdx.x < 64) {
-        wide_wave_scan(tot, bins, S.lstart, [](uint32_t t) { return t; });
-        if (blockIdx.x == 0) {
-            wide_wave_scan(tot, bins, chdr, [](uint32_t t) { return t; });
-            wide_wave_scan(tot, bins, chdr + CB, [](uint32_t t) { return (t + SUB - 1) / SUB; });
-            wide_wave_scan(tot, bins, chdr + 4 * CB, [=](uint32_t t) { return t ? (t / WL + 2 * keys + WCAP - 1) / WCAP + keys : 0u; });
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bins; b += 256) S.gbase[b] = S.lstart[b] + cbase[b];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        counts[4 * col] = S.lstart[bins];
-        counts[4 * col + 2] = chdr[4 * CB + bins];  // written by this wave above (same lane 63 -> memory; read back after the barrier)
-    }
-    const uint32_t lo = blockIdx.x * FCHUNK, hi = min(n, lo + FCHUNK);
-    Fr next = lo + threadIdx.x < hi ? fe_load(scalars + lo + threadIdx.x) : Fr::zero();
-    for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
-        __syncthreads();  // gbase / the previous round's lstart, kid, sorted are free
-        for (uint32_t b = threadIdx.x; b < bins; b += 256) S.cnt[b] = 0;
-        __syncthreads();
-        const uint32_t i = i0 + threadIdx.x;
-        const Fr cur = next;  // the next round's scalar is loaded under this round's sort
-        if (i + 256 < hi) next = fe_load(scalars + i + 256);
-        uint32_t ent[NWIN], meta[NWIN];  // meta = key << 16 | rank, 0xffffffff = no entry
-#pragma unroll
-        for (uint32_t w = 0; w < NWIN; w++) meta[w] = 0xffffffffu;
-        if (i < hi) {
-            uint32_t u[9];
-            wide_biased(cur, g, u);
-#pragma unroll
-            for (uint32_t w = 0; w < NWIN; w++) {
-                const int32_t d = wide_digit<C>(u, w);
-                if (d != 0) {
-                    const uint32_t bkt = (uint32_t)(d < 0 ? -d : d) - 1;
-                    const uint32_t key = bkt >> g.fb;
-                    ent[w] = (w * table_stride + i) | ((bkt & (keys - 1)) << g.ib) | (d < 0 ? SIGN_BIT : 0);
-                    meta[w] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) wide_wave_scan(S.cnt, bins, S.lstart, [](uint32_t t) { return t; });
-        __syncthreads();
-#pragma unroll
-        for (uint32_t w = 0; w < NWIN; w++)
-            if (meta[w] != 0xffffffffu) {
-                const uint32_t key = meta[w] >> 16, pos = S.lstart[key] + (meta[w] & 0xffffu);
-                S.sorted[pos] = ent[w];
-                S.kid[pos] = (uint16_t)key;
-            }
-        __syncthreads();
-        const uint32_t total = S.lstart[bins];
-        for (uint32_t q = threadIdx.x; q < total; q += 256) {
-            const uint32_t key = S.kid[q];
-            inter[S.gbase[key] + q - S.lstart[key]] = S.sorted[q];
-        }
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < bins; b += 256) S.gbase[b] += S.cnt[b];
-    }
-}
-
-// per-bucket totals from the sorted intermediate list: one workgroup per chunk (<= SUB entries) of a coarse bin — the
-// decomposition of the second sort level — counts its entries per fine key in LDS and adds the counts to totals[]
-// (zero at the start of a pass).  Chunks, not whole bins: witness-like columns put most of their entries into a few bins
-// (a permuted lookup column at k = 19: 400 K entries in bin 0 — one workgroup needed 200 us for them).
-__global__ __launch_bounds__(256) void msm_wfinehist_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                            const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
-                                                            uint32_t* __restrict__ totals_all, uint32_t* __restrict__ next_totals,
-                                                            uint32_t* __restrict__ next_cursor, uint32_t next_cols) {
-    __shared__ uint32_t hist[128];
-    __shared__ uint32_t s_bin, s_chunk;
-    const uint32_t col = blockIdx.y, keys = 1u << g.fb;
-    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
-    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    const uint32_t* cpre = chdr + (WCB + 1);
-    {
-        // the NEXT pass's per-bucket counters — the other set: nothing of this pass touches it — shared among this kernel's
-        // (worst-case many) workgroups (next_cols: the columns the last pass on that set used: it may have been a wider batch than
-        // this one).  In H1, whose lanes all have a scalar to wait for, the same stores cost 13 us
-        const uint32_t step = gridDim.x * 256;
-        for (uint32_t cc = col; cc < next_cols; cc += gridDim.y)
-            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < g.nb; i += step) {
-                next_totals[(size_t)cc * g.nb + i] = 0;
-                next_cursor[(size_t)cc * g.nb + i] = 0;
-            }
-    }
-    if (blockIdx.x == gridDim.x - 1) {
-        // (one block more than the worst case of chunks is launched for this)  The append cursors of the coarse bins have been
-        // read by the first scatter: back to zero for the next pass's H1
-        uint32_t* cur = const_cast<uint32_t*>(chdr) + WCUR0;
-        for (uint32_t b = threadIdx.x; b < WCB; b += 256) cur[b * WCUR] = 0;
-    }
-    if (blockIdx.x >= cpre[g.bins]) return;  // the grid is sized for the worst case
-    if (threadIdx.x == 0) {
-        uint32_t lo = 0, hi = g.bins;  // the bin whose chunk range holds blockIdx.x
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (cpre[mid] <= blockIdx.x) lo = mid;
-            else hi = mid;
-        }
-        s_bin = lo;
-        s_chunk = blockIdx.x - cpre[lo];
-    }
-    if (threadIdx.x < keys) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t bin = s_bin;
-    const uint32_t beg = chdr[bin] + s_chunk * SUB;
-    const uint32_t end = min(chdr[bin + 1], beg + SUB);
-    for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&hist[(inter[p] >> g.ib) & (keys - 1)], 1u);
-    __syncthreads();
-    if (threadIdx.x < keys) {
-        const uint32_t cnt = hist[threadIdx.x];
-        if (cnt) atomicAdd(&totals_all[(size_t)col * g.nb + bin * keys + threadIdx.x], cnt);
-    }
-}
-
-// The bin-local scans of the per-bucket totals (the first `keys` lanes of the workgroup, a lane per bucket of the bin; every lane
-// of the workgroup must call): the bucket's place in the column's dense entry list (returned) and its distance from the previous
-// non-empty bucket of the bin minus one (`esc` for a bin's first one or a longer gap: what the bucket's first entry tells the
-// accumulation lane that runs into it).  `publish`: also write what the LATER kernels read — bstart[b], lane_b[] (the bucket an
-// accumulation lane starts in), pstart[b] / pbucket[] (the bucket's parts of at most WCAP slots, T1) and the no-part markers at
-// the end of the bin's part region.  (Round 3 ran this as a kernel of its own between the fine histogram and the second scatter;
-// now every chunk of a bin redoes the two 128-element scans — a few microseconds — and the bin's first chunk publishes.)
-struct WideBinScan {
-    uint32_t wsum[4];
-    int wlast[2];
-};
-__device__ __forceinline__ uint32_t wide_binscan(WideBinScan& B, const uint32_t* __restrict__ chdr, const WideGeo& g, uint32_t col,
-                                                 uint32_t bin, const uint32_t* __restrict__ totals_all, bool publish,
-                                                 uint32_t* __restrict__ bstart_all, uint32_t* __restrict__ lane_b,
-                                                 uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket, uint32_t WCAP,
-                                                 uint32_t* delta_out) {
-    constexpr uint32_t CB = WCB + 1;
-    const uint32_t nb = g.nb, keys = 1u << g.fb;
-    const uint32_t esc = (1u << (30 - g.ib)) - 1;
-    const bool mine = threadIdx.x < keys;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t top = min(63u, keys - 1);  // the last lane of a wave that holds buckets
-    const uint32_t b = bin * keys + threadIdx.x;
-    const uint32_t cnt = mine ? totals_all[(size_t)col * nb + b] : 0;
-    if (threadIdx.x < 4) B.wsum[threadIdx.x] = 0;
-    if (threadIdx.x < 2) B.wlast[threadIdx.x] = -1;
-    __syncthreads();
-    // exclusive scan of the counts -> place in the entry list
-    uint32_t xe = cnt;
-    int last = cnt ? (int)threadIdx.x : -1;  // inclusive running maximum: the last non-empty bucket up to this one
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t ye = __shfl_up(xe, off);
-        const int yl = __shfl_up(last, off);
-        if ((int)lane >= off) {
-            xe += ye;
-            last = max(last, yl);
-        }
-    }
-    if (mine && lane == top) {
-        B.wsum[2 * wave] = xe;
-        B.wlast[wave] = last;
-    }
-    __syncthreads();
-    const uint32_t s = chdr[bin] + xe - cnt + (wave == 1 ? B.wsum[0] : 0);
-    // the last non-empty bucket strictly before this one
-    int prev = __shfl_up(last, 1);
-    if (lane == 0) prev = -1;
-    if (wave == 1) prev = max(prev, B.wlast[0]);
-    const uint32_t gap = prev < 0 ? esc : (uint32_t)((int)threadIdx.x - prev - 1);
-    *delta_out = gap < esc ? gap : esc;
-    if (!publish) return s;  // (workgroup-uniform)
-    const uint32_t slots = wide_slot_count(s, cnt);
-    const uint32_t np = mine ? (slots + WCAP - 1) / WCAP : 0;
-    // exclusive scan of the part counts -> place in the bin's part region
-    uint32_t xp = np;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t yp = __shfl_up(xp, off);
-        if ((int)lane >= off) xp += yp;
-    }
-    if (mine && lane == top) B.wsum[2 * wave + 1] = xp;
-    __syncthreads();
-    const uint32_t pbase = chdr[4 * CB + bin], pend = chdr[4 * CB + bin + 1];
-    const uint32_t p_used = B.wsum[1] + B.wsum[3];
-    const uint32_t p0 = pbase + xp - np + (wave == 1 ? B.wsum[1] : 0);
-    if (mine) {
-        bstart_all[(size_t)col * nb + b] = s;
-        pstart_all[(size_t)col * nb + b] = p0;
-        if (cnt)  // lanes whose first entry lies in this bucket
-            for (uint32_t t = (s + WL - 1) / WL; t * WL < s + cnt; t++) lane_b[t] = b;
-        for (uint32_t q = 0; q < np; q++) pbucket[p0 + q] = b;
-    }
-    for (uint32_t q = pbase + p_used + threadIdx.x; q < pend; q += 256) pbucket[q] = 0xffffffffu;
-    return s;
-}
-
-// level 2 of the sort: one chunk (<= SUB entries) of one coarse bin into its buckets, dense (no padding): the first entry of
-// every bucket carries WIDE_FLAG and the bucket's distance from the previous non-empty one in its spare bits.  The bin-local
-// scans are the kernel's prologue (wide_binscan); the first chunk of a bin publishes them, one block beyond the worst case of
-// chunks covers the bins without entries.
-__global__ __launch_bounds__(256) void msm_wscatter2_kernel(const uint32_t* __restrict__ inter_all, size_t inter_stride,
-                                                            const uint32_t* __restrict__ coarse_all, uint32_t coarse_stride, WideGeo g,
-                                                            const uint32_t* __restrict__ totals_all, uint32_t* __restrict__ bstart_all,
-                                                            uint32_t* __restrict__ cursor_all, uint32_t* __restrict__ entries_all,
-                                                            size_t ent_stride, uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
-                                                            uint32_t* __restrict__ pstart_all, uint32_t* __restrict__ pbucket_all,
-                                                            uint32_t part_stride, uint32_t WCAP) {
-    __shared__ SortLds S;
-    __shared__ WideBinScan B;
-    __shared__ uint32_t s_bin, s_chunk;
-    __shared__ uint32_t s_mark[128];  // flag bits of a key's first entry when this chunk holds the bucket's first
-    __shared__ uint32_t s_start[128], s_delta[128];
-    constexpr uint32_t CB = WCB + 1;
-    const uint32_t col = blockIdx.y, nb = g.nb, keys = 1u << g.fb;
-    const uint32_t* __restrict__ inter = inter_all + (size_t)col * inter_stride;
-    const uint32_t* __restrict__ chdr = coarse_all + (size_t)col * coarse_stride;
-    uint32_t* __restrict__ cursor = cursor_all + (size_t)col * nb;
-    uint32_t* __restrict__ entries = entries_all + (size_t)col * ent_stride;
-    const uint32_t* cpre = chdr + CB;
-    if (blockIdx.x == gridDim.x - 1) {
-        // the spare block: bins without entries have no chunk, but their buckets' starts are read all the same (an empty bucket
-        // shares its start with the next non-empty one: wide_bucket_at) and their part ranges must be empty
-        for (uint32_t bin = 0; bin < g.bins; bin++) {
-            if (chdr[bin + 1] != chdr[bin]) continue;
-            if (threadIdx.x < keys) {
-                bstart_all[(size_t)col * nb + bin * keys + threadIdx.x] = chdr[bin];
-                pstart_all[(size_t)col * nb + bin * keys + threadIdx.x] = chdr[4 * CB + bin];
-            }
-        }
-        return;
-    }
-    if (blockIdx.x >= cpre[g.bins]) return;  // the grid is sized for the worst case
-    if (threadIdx.x == 0) {
-        uint32_t lo = 0, hi = g.bins;  // the bin whose chunk range holds blockIdx.x
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (cpre[mid] <= blockIdx.x) lo = mid;
-            else hi = mid;
-        }
-        s_bin = lo;
-        s_chunk = blockIdx.x - cpre[lo];
-    }
-    if (threadIdx.x < keys) S.cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t bin = s_bin;
-    {
-        uint32_t dl;
-        const uint32_t st = wide_binscan(B, chdr, g, col, bin, totals_all, s_chunk == 0, bstart_all, lane_b_all + (size_t)col * lane_stride,
-                                         pstart_all, pbucket_all + (size_t)col * part_stride, WCAP, &dl);
-        if (threadIdx.x < keys) {
-            s_start[threadIdx.x] = st;
-            s_delta[threadIdx.x] = dl;
-        }
-    }
-    const uint32_t beg = chdr[bin] + s_chunk * SUB;
-    const uint32_t end = min(chdr[bin + 1], beg + SUB);
-    constexpr uint32_t PER = SUB / 256;
-    uint32_t ent[PER], meta[PER];
-#pragma unroll
-    for (uint32_t q = 0; q < PER; q++) {
-        const uint32_t p = beg + threadIdx.x + q * 256;
-        meta[q] = 0xffffffffu;
-        if (p < end) {
-            const uint32_t e = inter[p];
-            const uint32_t key = (e >> g.ib) & (keys - 1);
-            ent[q] = e & ~((keys - 1) << g.ib);
-            meta[q] = (key << 16) | atomicAdd(&S.cnt[key], 1u);
-        }
-    }
-    __syncthreads();
-    sort_scan(S, keys);
-    if (threadIdx.x < keys) {
-        const uint32_t cnt = S.cnt[threadIdx.x], b = bin * keys + threadIdx.x;
-        const uint32_t before = cnt ? atomicAdd(&cursor[b], cnt) : 0;
-        S.gbase[threadIdx.x] = s_start[threadIdx.x] + before;
-        s_mark[threadIdx.x] = (cnt && before == 0) ? (WIDE_FLAG | (s_delta[threadIdx.x] << g.ib)) : 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t q = 0; q < PER; q++)
-        if (meta[q] != 0xffffffffu) {
-            const uint32_t key = meta[q] >> 16, pos = S.lstart[key] + (meta[q] & 0xffffu);
-            S.sorted[pos] = ent[q];
-            S.kid[pos] = (uint8_t)key;
-        }
-    __syncthreads();
-    const uint32_t total = end - beg;
-    for (uint32_t q = threadIdx.x; q < total; q += 256) {
-        const uint32_t key = S.kid[q];
-        entries[S.gbase[key] + q - S.lstart[key]] = S.sorted[q] | (q == S.lstart[key] ? s_mark[key] : 0u);
-    }
-}
-
-// the counters a pass of the wide path expects to be zero: per-bucket totals and level-2 cursors, the append cursors of the
-// coarse bins, counts[].  Launched only when the workspace is not known to be clean (first pass, after an error or after the
-// 13-bit plan used the workspace): every pass leaves them clean (H1 zeroes the other set of per-bucket counters and the redo
-// count, the fine histogram's spare block the append cursors)
-__global__ void msm_wclear_kernel(uint32_t* __restrict__ totals, uint32_t* __restrict__ cursor, uint32_t* __restrict__ totals2,
-                                  uint32_t* __restrict__ cursor2, uint32_t nbt, uint32_t* __restrict__ counts,
-                                  uint32_t* __restrict__ coarse, uint32_t coarse_stride, uint32_t ncols) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nbt) {
-        totals[i] = 0;
-        cursor[i] = 0;
-        totals2[i] = 0;
-        cursor2[i] = 0;
-    }
-    if (i < 4 * (MSM_MAX_BATCH + 1)) counts[i] = 0;
-    if (i < ncols * WCB) coarse[(size_t)(i / WCB) * coarse_stride + WCUR0 + (i % WCB) * WCUR] = 0;
-}
-
-// the bucket of the entry at position `pos` of a column (the escape of a first-of-bucket entry whose distance field is
-// saturated): the last bucket whose start is <= pos — empty buckets share their start with the next non-empty one
-__device__ __noinline__ uint32_t wide_bucket_at(const uint32_t* __restrict__ bstart, uint32_t nb, uint32_t pos) {
-    uint32_t lo = 0, hi = nb;  // bstart[lo] <= pos (bstart[0] = 0), hi: first index with bstart > pos (or nb)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (bstart[mid] <= pos) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// ---- the accumulation of the wide path: lane t of a column sums entries [t WL, (t + 1) WL) of the dense list, storing its
-// running sum and restarting at every first-of-bucket entry (slot index = t + bucket).  SAFE as in accumulate_segment:
-// the unchecked loop vouches that the table holds no identity and reports a lane whose sums show an exceptional step
-// (ZZ = 0) to the redo list; the checked loop is exact for any table.
-template <bool SAFE>
-__device__ __forceinline__ bool wide_accumulate_lane(const uint32_t* __restrict__ e, uint32_t count, uint32_t pos0, uint32_t t, uint32_t b,
-                                                     const uint32_t* __restrict__ bstart, uint32_t nb,
-                                                     const G1Affine* __restrict__ table, G1X29S* __restrict__ slots, uint32_t ib) {
-    G1X29 acc;
-    acc.inf = true;
-    bool suspicious = false;
-    const uint32_t idx_mask = (1u << ib) - 1, esc = (1u << (30 - ib)) - 1;
-    for (uint32_t k = 0; k < count; k++) {
-        const uint32_t y = e[k];
-        if ((y & WIDE_FLAG) && k) {  // a new bucket begins inside the lane's run
-            if (!SAFE && !acc.inf && is_zero29(acc.zz)) suspicious = true;
-            g1x29_store(slots + t + b, acc);
-            acc.inf = true;
-            const uint32_t d = (y >> ib) & esc;
-            b = d < esc ? b + 1 + d : wide_bucket_at(bstart, nb, pos0 + k);
-        }
-        G1Affine p = affine_load(table + (y & idx_mask));
-        if (SAFE && affine_is_identity(p)) continue;
-        if (y & SIGN_BIT) p.y = fe_neg(p.y);
-        if (!g1x29_add_affine<SAFE, true>(acc, p.x, p.y)) {
-            // same x as the running sum (doubling or cancellation): the general formulas, rarely.  The table is in the
-            // internal form: back to the standard one for the general addition (divide by 32: one product each)
-            G1X s = g1x29_to_std(acc);
-            Fq px = internal_to_std(to29(p.x)), py = internal_to_std(to29(p.y));
-            g1x_add_affine(s, px, py);
-            acc = g1x29_from_std(s);
-        }
-    }
-    if (!SAFE && !acc.inf && is_zero29(acc.zz)) suspicious = true;
-    g1x29_store(slots + t + b, acc);
-    return suspicious;
-}
-
-#if ZK_ACC_WAVES
-__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
-#endif
-__global__ __launch_bounds__(64) void msm_wacc_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
-                                                      const G1Affine* __restrict__ table, const uint32_t* __restrict__ counts,
-                                                      const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
-                                                      const uint32_t* __restrict__ bstart_all, uint32_t nb,
-                                                      G1X29S* __restrict__ slot_all, uint32_t slot_stride, uint32_t ib) {
-    const uint32_t col = blockIdx.y, total = counts[4 * col];
-    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t * WL >= total) return;
-    wide_accumulate_lane<true>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
-                               lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
-                               slot_all + (size_t)col * slot_stride, ib);
-}
-#if ZK_ACC_WAVES
-__attribute__((amdgpu_waves_per_eu(ZK_ACC_WAVES, ZK_ACC_WAVES)))
-#endif
-__global__ __launch_bounds__(64) void msm_wacc_fast_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
-                                                           const G1Affine* __restrict__ table, uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
-                                                           const uint32_t* __restrict__ bstart_all, uint32_t nb,
-                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, uint32_t* __restrict__ redo,
-                                                           uint32_t ib) {
-    const uint32_t col = blockIdx.y, total = counts[4 * col];
-    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t * WL >= total) return;
-    if (wide_accumulate_lane<false>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
-                                    lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
-                                    slot_all + (size_t)col * slot_stride, ib))
-        redo[atomicAdd(&counts[1], 1u)] = col * lane_stride + t;  // at most one entry per lane: redo[] has one word each
-}
-__global__ __launch_bounds__(64) void msm_wacc_redo_kernel(const uint32_t* __restrict__ entries_all, size_t ent_stride,
-                                                           const G1Affine* __restrict__ table, const uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ lane_b_all, uint32_t lane_stride,
-                                                           const uint32_t* __restrict__ bstart_all, uint32_t nb,
-                                                           G1X29S* __restrict__ slot_all, uint32_t slot_stride, const uint32_t* __restrict__ redo,
-                                                           uint32_t ib) {
-    const uint32_t m = counts[1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const uint32_t col = redo[i] / lane_stride, t = redo[i] - col * lane_stride, total = counts[4 * col];
-        wide_accumulate_lane<true>(entries_all + (size_t)col * ent_stride + (size_t)t * WL, min(WL, total - t * WL), t * WL, t,
-                                   lane_b_all[(size_t)col * lane_stride + t], bstart_all + (size_t)col * nb, nb, table,
-                                   slot_all + (size_t)col * slot_stride, ib);
-    }
-}
-
-// T1: part g of a column = up to WCAP consecutive slots of one bucket, summed serially by one lane; then the lanes of a wave
-// that hold parts of the same bucket (a bucket's parts are consecutive) are joined by a segmented shuffle tree — the first
-// lane of every run stores.  part[g] is therefore valid at the "heads": g = pstart[b] and the multiples of 64 inside
-// (pstart[b], pstart[b + 1]).
-__global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict__ slot_all, uint32_t slot_stride,
-                                                        const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
-                                                        const uint32_t* __restrict__ pstart_all, const uint32_t* __restrict__ pbucket_all,
-                                                        uint32_t part_stride, uint32_t nb, const uint32_t* __restrict__ counts,
-                                                        G1X29S* __restrict__ part_all, uint32_t WCAP, uint32_t lmin) {
-    const uint32_t col = blockIdx.y;
-    const uint32_t nparts = counts[4 * col + 2];
-    if (blockIdx.x * 64 >= nparts) return;  // wave-uniform
-    const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x * 64 + lane;
-    const G1X29S* __restrict__ slots = slot_all + (size_t)col * slot_stride;
-    uint32_t b = g < nparts ? pbucket_all[(size_t)col * part_stride + g] : 0xffffffffu;  // 0xffffffff: the unused end of a bin's part region
-    bool active = b != 0xffffffffu;
-    uint32_t s = 0, s_end = 0;
-    if (active) {
-        // the bucket's slots: one per accumulation lane that held some of its entries, at index lane + bucket
-        const uint32_t e0 = bstart_all[(size_t)col * nb + b];
-        const uint32_t s0 = e0 / WL + b;
-        const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
-        if (len <= lmin) {  // the per-bucket kernel (msm_wbucket_kernel) has summed this bucket: its parts take no lane here
-            active = false;
-            b = 0xfffffffeu - lane;  // (distinct: no two such lanes look like parts of one bucket)
-        }
-    }
-    if (!__any(active)) return;  // wave-uniform: under lmin > 0 nearly every wave of a uniformly random column
-    if (active) {
-        const uint32_t e0 = bstart_all[(size_t)col * nb + b];
-        const uint32_t s0 = e0 / WL + b;
-        const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
-        const uint32_t np = (len + WCAP - 1) / WCAP;
-        const uint32_t p = g - pstart_all[(size_t)col * nb + b];
-        // balanced shares: part p of np takes slots [s0 + p len / np, s0 + (p + 1) len / np)
-        s = s0 + (uint32_t)(((uint64_t)p * len) / np);
-        s_end = s0 + (uint32_t)(((uint64_t)(p + 1) * len) / np);
-    }
-    G1X29 acc = g1x29_identity();
-    int off = 1;
-#pragma unroll 1
-    for (;;) {
-        G1X29 v;
-        bool have;
-        if (__any(s < s_end)) {  // wave-uniform: the serial runs
-            have = s < s_end;
-            if (have) v = g1x29_load(slots + s);
-            s++;
-        } else {
-            // segmented tree: lane i takes lane i + off's sum when both hold parts of the same bucket (a bucket's parts are
-            // consecutive lanes: a level without any such pair ends the tree)
-            if (off >= 64) break;
-            const uint32_t kb = (uint32_t)__shfl_down((int)b, off);
-            have = active && lane + off < 64 && kb == b;
-            if (!__any(have)) break;
-            v = g1x29_shfl_down(acc, off);
-            off <<= 1;
-        }
-        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
-    }
-    const uint32_t prev = (uint32_t)__shfl_up((int)b, 1);
-    if (active && (lane == 0 || prev != b)) g1x29_store(part_all + (size_t)col * part_stride + g, acc);
-}
-
-// T1, per-bucket form (round 6): ONE lane per bucket sums all of the bucket's slots serially — no parts, no shuffle tree.  A wave
-// of the part form spends 7.9 addition times on 64 parts = ~21 buckets (5 .. 6 serial additions + two tree levels in which most
-// lanes idle: 4.35e7 instructions per 2^19 column, profiles/r5_pmc_ops.txt); here a wave takes 64 buckets in max(len) - 1
-// additions (len = 17 .. 19 slots for a uniformly random column) with every lane busy, and the products take the serial
-// multiply-add form: fewer instructions, a LONGER dependent chain — the form for a loaded chip (the pass's tail on the main
-// stream: three or more proofs in flight), while a lone proof keeps the part form, whose chain is half as long.  Buckets of
-// more than `lmax` slots (witness-like columns put 400 K entries into a few buckets) are left to msm_wparts_kernel (lmin = lmax).
-// The sum goes where T2 looks for it: part[pstart[b]]; a further head of the bucket's part range (a multiple of 64 inside it)
-// becomes the identity.
-__global__ __launch_bounds__(64) void msm_wbucket_kernel(const G1X29S* __restrict__ slot_all, uint32_t slot_stride,
-                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
-                                                         const uint32_t* __restrict__ pstart_all, uint32_t part_stride, uint32_t nb,
-                                                         G1X29S* __restrict__ part_all, uint32_t WCAP, uint32_t lmax) {
-    const uint32_t col = blockIdx.y, b = blockIdx.x * 64 + threadIdx.x;  // nb is a multiple of 64
-    const G1X29S* __restrict__ slots = slot_all + (size_t)col * slot_stride;
-    const uint32_t e0 = bstart_all[(size_t)col * nb + b];
-    const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
-    const bool mine = len != 0 && len <= lmax;
-    uint32_t s = e0 / WL + b;
-    const uint32_t s_end = mine ? s + len : s;
-    G1X29 acc = g1x29_identity();
-#pragma unroll 1
-    while (__any(s < s_end)) {  // wave-uniform
-        const bool have = s < s_end;
-        G1X29 v;
-        if (have) v = g1x29_load(slots + s);
-        s++;
-        if (have) g1x29_add<ZK_T1B_SER>(acc, v);
-    }
-    if (mine) {
-        G1X29S* __restrict__ part = part_all + (size_t)col * part_stride;
-        const uint32_t g = pstart_all[(size_t)col * nb + b], g_end = g + (len + WCAP - 1) / WCAP;
-        g1x29_store(part + g, acc);
-        const uint32_t h = (g | 63u) + 1;
-        if (h < g_end) g1x29_store(part + h, g1x29_identity());
-    }
-}
-
-// T2: one wave per row (blockIdx.x < rows) or column (blockIdx.x - rows) of the column's bucket matrix [rows][256]: lanes walk
-// their buckets' heads serially, then a shuffle tree.  rc[col][rows + 256]
-__global__ __launch_bounds__(64) void msm_wrowcol_kernel(const G1X29S* __restrict__ part_all, uint32_t part_stride,
-                                                         const uint32_t* __restrict__ totals_all, const uint32_t* __restrict__ bstart_all,
-                                                         const uint32_t* __restrict__ pstart_all, uint32_t nb,
-                                                         G1X29S* __restrict__ rc_all, uint32_t WCAP) {
-    const uint32_t col = blockIdx.y, rows = nb >> 8, r = blockIdx.x, lane = threadIdx.x;
-    const uint32_t* __restrict__ pstart = pstart_all + (size_t)col * nb;
-    const uint32_t* __restrict__ totals = totals_all + (size_t)col * nb;
-    const uint32_t* __restrict__ bstart = bstart_all + (size_t)col * nb;
-    const G1X29S* __restrict__ part = part_all + (size_t)col * part_stride;
-    const bool is_row = r < rows;
-    // lane's j-th bucket: rows: 256 r + lane + 64 j (j < 4); columns: 256 (lane + 64 j) + (r - rows) (j < rows / 64)
-    const uint32_t nj = is_row ? 4u : rows / 64;
-    uint32_t j = 0, g = 0, g_end = 0;
-    const auto bucket_of = [&](uint32_t jj) { return is_row ? 256 * r + lane + 64 * jj : 256 * (lane + 64 * jj) + (r - rows); };
-    const auto open_bucket = [&]() {
-        while (j < nj) {
-            const uint32_t b = bucket_of(j);
-            g = pstart[b];
-            g_end = g + (wide_slot_count(bstart[b], totals[b]) + WCAP - 1) / WCAP;
-            if (g < g_end) return;
-            j++;
-        }
-    };
-    open_bucket();
-    G1X29 acc = g1x29_identity();
-    int off = 32;
-#pragma unroll 1
-    for (;;) {
-        G1X29 v;
-        bool have;
-        if (__any(j < nj)) {  // wave-uniform
-            have = j < nj;
-            if (have) {
-                v = g1x29_load(part + g);
-                g = (g | 63u) + 1;  // the next head of this bucket, if any
-                if (g >= g_end) {
-                    j++;
-                    open_bucket();
-                }
-            }
-        } else {
-            if (off == 0) break;
-            v = g1x29_shfl_down(acc, off);
-            have = (int)lane < off;
-            off >>= 1;
-        }
-        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
-    }
-    if (lane == 0) g1x29_store(rc_all + (size_t)col * (rows + 256) + r, acc);
-}
-
-// T3: blockIdx.x = t < 9: sum of the column sums C_l with bit t of (l + 1) set; t >= 9: sum of the row sums R_h with bit
-// t - 9 of h set.  One wave each; lane 0 hands the sum over in the standard form.  out[col][WIDE_SUMS]
-__global__ __launch_bounds__(64) void msm_wbits_kernel(const G1X29S* __restrict__ rc_all, uint32_t nb, G1X* __restrict__ out,
-                                                       const uint32_t* __restrict__ counts) {
-    const uint32_t col = blockIdx.y, rows = nb >> 8, t = blockIdx.x, lane = threadIdx.x;
-    // the word after the last column's sums tells the host how many lanes of the unchecked accumulation saw an exceptional
-    // step (same x: possible only over a degenerate basis): it then re-runs those lanes and this tail (msm_wide_redo) — the
-    // common case pays no redo launch
-    if (col == 0 && t == 0 && lane == 0) *reinterpret_cast<uint32_t*>(out + (size_t)gridDim.y * WIDE_SUMS) = counts[1];
-    const G1X29S* __restrict__ rc = rc_all + (size_t)col * (rows + 256);
-    const bool cols = t < 9;
-    const uint32_t items = cols ? 256u : rows;
-    uint32_t i = lane;
-    const auto wanted = [&](uint32_t ii) { return cols ? (((ii + 1) >> t) & 1u) != 0 : ((ii >> (t - 9)) & 1u) != 0; };
-    while (i < items && !wanted(i)) i += 64;
-    G1X29 acc = g1x29_identity();
-    int off = 32;
-#pragma unroll 1
-    for (;;) {
-        G1X29 v;
-        bool have;
-        if (__any(i < items)) {  // wave-uniform
-            have = i < items;
-            if (have) {
-                v = g1x29_load(rc + (cols ? rows + i : i));
-                i += 64;
-                while (i < items && !wanted(i)) i += 64;
-            }
-        } else {
-            if (off == 0) break;
-            v = g1x29_shfl_down(acc, off);
-            have = (int)lane < off;
-            off >>= 1;
-        }
-        if (have) g1x29_add<ZK_TAIL_SER>(acc, v);
-    }
-    if (lane == 0) {
-        G1X r = G1X::identity();
-        if (!acc.inf) {
-            r.x = internal_to_std_call(acc.x);
-            r.y = internal_to_std_call(acc.y);
-            r.zz = internal_to_std_call(acc.zz);
-            r.zzz = internal_to_std_call(acc.zzz);
-        }
-        g1x_store(out + (size_t)col * WIDE_SUMS + t, r);
-    }
-}
-
-// ------------------------------------------------------ fixed-base tables ---
-// table[w][i] = 2^(c w) * P_i (affine).  One launch per window: c doublings + one inversion.
-__global__ __launch_bounds__(64) void msm_table_step_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next,
-                                                            uint32_t n, uint32_t c) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const G1Affine p = affine_load(prev + i);
-    G1Affine r;
-    if (affine_is_identity(p)) {
-        r.x = Fq::zero();
-        r.y = Fq::zero();
-    } else {
-        G1X acc = g1x_dbl_affine(p.x, p.y);
-        for (uint32_t k = 1; k < c; k++) acc = g1x_dbl(acc);
-        if (acc.is_identity()) {  // cannot happen on a prime-order curve; kept for completeness
-            r.x = Fq::zero();
-            r.y = Fq::zero();
-        } else {
-            const Fq t = fe_inv(acc.zzz);
-            const Fq u = fe_mul(acc.zz, t);
-            r.x = fe_mul(acc.x, fe_sqr(u));
-            r.y = fe_mul(acc.y, t);
-        }
-    }
-    fe_store(&next[i].x, r.x);
-    fe_store(&next[i].y, r.y);
-}
-
-// does any of the n points equal the identity (0, 0)?  Decides which accumulation loop a basis gets (msm_accumulate_kernel).
-__global__ void msm_identity_flag_kernel(const G1Affine* __restrict__ b, uint32_t n, uint32_t* __restrict__ flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && affine_is_identity(affine_load(b + i))) atomicOr(flag, 1u);
-}
-hipError_t msm_bases_have_identity(const G1Affine* bases, uint32_t n, hipStream_t st, uint32_t* d_word, uint32_t* h_word, bool* out) {
-    hipError_t e = hipMemsetAsync(d_word, 0, 4, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(msm_identity_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bases, n, d_word);
-    if ((e = hipMemcpyAsync(h_word, d_word, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    *out = *h_word != 0;
-    return hipSuccess;
-}
-
-// x * 2^256 (standard memory form) -> x * 2^261 (the accumulation's internal form, canonical words): times 32
-__global__ void msm_table_internal_kernel(G1Affine* __restrict__ t, size_t count) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    G1Affine p = affine_load(t + i);
-    for (int k = 0; k < 5; k++) {
-        p.x = fe_add(p.x, p.x);
-        p.y = fe_add(p.y, p.y);
-    }
-    fe_store(&t[i].x, p.x);
-    fe_store(&t[i].y, p.y);
-}
-
-// the same rule msm_run applies (wide workspace && table stride == workspace length; workspaces are >= 1024 long)
-bool msm_table_is_internal(uint32_t c, size_t n) { return msm_wide_applies(c, n) && n >= 1024; }
-
-hipError_t msm_build_table(const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table, hipStream_t st) {
-    const uint32_t nwin = nwin_for(c);
-    hipError_t e = hipMemcpyAsync(table, bases, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return e;
-    for (uint32_t w = 1; w < nwin; w++)
-        hipLaunchKernelGGL(msm_table_step_kernel, dim3((n + 63) / 64), dim3(64), 0, st, table + (size_t)(w - 1) * n,
-                           table + (size_t)w * n, n, c);
-    if (msm_table_is_internal(c, n)) {
-        // the wide path reads its window tables in the accumulation's internal form (the identity stays (0, 0))
-        const size_t count = (size_t)nwin * n;
-        hipLaunchKernelGGL(msm_table_internal_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, table, count);
-    }
-    return hipGetLastError();
-}
+// the kernels, by plan (one translation unit: the parts share the constants and the workspace record above)
+#include "msm_legacy.hip.h"  // 13-bit fused plan (n < 2^16), 15-bit swept sort (n >= 2^22), arbitrary bases
+#include "msm_wide.hip.h"    // 15 .. 17-bit windows, one bucket set per column: every proof of the reference's configurations
+#include "msm_tables.hip.h"  // window tables
 
 // ------------------------------------------------------------------ host ---
 
@@ -2068,9 +414,8 @@ static hipError_t msm_run_wide(MsmWorkspace* ws, const Fr* const* scalars_list, 
     if (n > 0) {
         // parts of one column at most: every bin's region is its slots / WCAP + a part per bucket + slack (msm_wscatter1_kernel)
         const uint32_t max_parts = (lanes + 2 * nb) / WCAP + nb + 2 * g.bins + 64;
-        // T1 per bucket where the tail shares its stream with the head (the engine puts it there while three or more proofs are in
-        // flight on the device: issue slots are what is short), per part — the shorter dependent chain — for a lone proof
-        const bool per_bucket = ws->w_t1_mode == 1 || (ws->w_t1_mode == 0 && ts == st);
+        // T1 per part (default) or per bucket (ZK_OPT_MSM_T1 = 1: fewer instructions, a longer chain — measured: no gain, msm_wide.hip.h)
+        const bool per_bucket = ws->w_t1_mode == 1;
         uint32_t lmin = 0;
         if (per_bucket) {
             lmin = ZK_T1B_LMAX;
