@@ -82,3 +82,23 @@ def test_synthesize_jobs_matches_lone_synthesis():
         assert all((a == asg.to_limbs(c)).all() for a, c in zip(got[j], asg.advice))
     fixed, copies = batch.structure(p)
     assert fixed.shape == (circuit.Layout(p).n_fix, 128, 4) and copies == circuit.synthesize(p, 99).copies
+
+
+def test_stream_audit_ledger_logic(tmp_path):
+    """csrc/audit.h (ZK_OPT_STREAM_AUDIT) on scripted enqueue sequences, host only: read-after-write / write-after-read across
+    streams with and without the event pair, transitivity through a third stream, an event recorded before the producer, round 5's
+    shared-scratch bug, host reads before and after the wait."""
+    import os
+    import shutil
+    import subprocess
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("hipcc") is None:
+        import pytest
+
+        pytest.skip("hipcc not on PATH")
+    exe = str(tmp_path / "audit_logic_check")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-x", "hip", "-I", os.path.join(ROOT, "webauthn-halo2_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "audit_logic_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "audit logic: 0 failures" in out.stdout, out.stdout + out.stderr

@@ -2,7 +2,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/busy_k19; mkdir -p $O
-( cd $R && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/raw -- python bench.py --no-cpu-baseline --steps 120 --inflight $1 > $O/run.log 2>&1 )
+( cd $R && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/raw -- python bench.py --no-cpu-baseline --k17-steps 0 --steps 120 --inflight $1 > $O/run.log 2>&1 )
 f=$(find $O/raw -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$tag
 mkdir -p $O
-BENCH="python $R/bench.py --no-cpu-baseline --steps 20"
+BENCH="python $R/bench.py --no-cpu-baseline --k17-steps 0 --steps 20"
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BENCH > $O/bench_stats.log 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- $BENCH > $O/bench_fetch.log 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bench_write -- $BENCH > $O/bench_write.log 2>&1
