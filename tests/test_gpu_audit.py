@@ -147,3 +147,36 @@ def test_audit_self_test_refuses_the_unordered_path(name):
     assert eng.prove(pk, sets[0], seed, E.ZK_TRANSCRIPT_BLAKE2B) == want
     assert eng.audit_report()[1] == 0
     eng.close()
+
+
+def test_lone_k19_proof_on_four_streams_under_the_audit():
+    """BASELINE's size under the AUTO rules: a lone k = 19 proof is the one case that really runs on four streams (main + tail +
+    transform + MSM stream: the rules need k >= 18 and a quiet device) — two proofs of the batch workload's jobs under the audit,
+    their digests the oracle's, no violation; then the same with the transforms back on the main stream."""
+    import hashlib
+    import json
+    import os
+
+    from webauthn_halo2_amd import batch, circuit
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = json.load(open(os.path.join(root, "tests", "golden", "batch_k19_sha256.json")))["sha256"]
+    p = circuit.K19
+    wit = batch.synthesize_jobs(p, [0, 1])
+    pl = batch.Pipeline(0, p, deterministic_seeds=True)
+    try:
+        pl.eng.set_option(E.ZK_OPT_STREAM_AUDIT, 1)
+        for j in (0, 1):
+            pl.load(j, wit[j])
+        for regime in ("auto", "main", "auto"):
+            _regime(pl.eng, regime)
+            for j in (0, 1):
+                try:
+                    pf = pl.prove(j, E.ZK_TRANSCRIPT_BLAKE2B, keep=True)
+                except zk.ZkError as e:
+                    raise AssertionError("%s under the audit (k = 19, %s): %s" % (e, regime, pl.eng.audit_report())) from e
+                assert hashlib.sha256(pf).hexdigest() == want[str(j)], (regime, j)
+        checks, violations, msg = pl.eng.audit_report()
+        assert violations == 0 and checks > 500, (checks, violations, msg)
+    finally:
+        pl.close()

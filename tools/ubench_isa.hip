@@ -94,6 +94,16 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters) {
             REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_and_b32 %4, 0x1fffffff, %4\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_and_b32 %5, 0x1fffffff, %5\n"
                               "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_and_b32 %6, 0x1fffffff, %6\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_and_b32 %7, 0x1fffffff, %7\n"
                               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b) : "vcc");)
+        } else if (OP == 26) {  // 4 v_mad_u64_u32, then a RUN of 4 v_and_b32 (do plain instructions pair up when they are adjacent?)
+            REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                              "v_and_b32 %4, 0x1fffffff, %4\n v_and_b32 %5, 0x1fffffff, %5\n v_and_b32 %6, 0x1fffffff, %6\n v_and_b32 %7, 0x1fffffff, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b) : "vcc");)
+        } else if (OP == 27) {  // 8 mads, then a run of 8 v_and_b32
+            REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                              "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                              "v_and_b32 %4, 0x1fffffff, %4\n v_and_b32 %5, 0x1fffffff, %5\n v_and_b32 %6, 0x1fffffff, %6\n v_and_b32 %7, 0x1fffffff, %7\n"
+                              "v_and_b32 %4, 0x1ffffffe, %4\n v_and_b32 %5, 0x1ffffffe, %5\n v_and_b32 %6, 0x1ffffffe, %6\n v_and_b32 %7, 0x1ffffffe, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b) : "vcc");)
         } else if (OP == 25) {  // 4 v_mad_u64_u32 + 4 v_lshrrev_b64 interleaved
             REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_lshrrev_b64 %4, 29, %4\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_lshrrev_b64 %5, 29, %5\n"
                               "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_lshrrev_b64 %6, 29, %6\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_lshrrev_b64 %7, 29, %7\n"
@@ -148,6 +158,8 @@ int main() {
         run<23>("v_cndmask_b32", out, w);
         run<24>("4 mad + 4 v_and (per 8 instr)", out, w);
         run<25>("4 mad + 4 v_lshrrev_b64", out, w);
+        run<26>("4 mad, then 4 v_and (per 8 instr)", out, w);
+        run<27>("8 mad, then 8 v_and (per 16 instr)", out, w);
     }
     return 0;
 }

@@ -193,6 +193,21 @@ __device__ __forceinline__ void mad_first(uint64_t& acc, uint32_t x, uint32_t y)
     acc = (uint64_t)x * y;
 #endif
 }
+// the result limbs' masks as ONE run of plain VOP2 instructions (ZK_MUL29_MASKRUN, experiment: a plain instruction between two
+// multiply-adds costs 3.96 cycles, in a run 2.5 — profiles/r6_ubench_isa.txt): r[i] = raw[i] & (2^29 - 1), i < 8
+#ifndef ZK_MUL29_MASKRUN
+#define ZK_MUL29_MASKRUN 0
+#endif
+__device__ __forceinline__ void mask_run8(uint32_t (&r)[9], const uint32_t (&raw)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_and_b32 %0, 0x1fffffff, %8\n\tv_and_b32 %1, 0x1fffffff, %9\n\tv_and_b32 %2, 0x1fffffff, %10\n\tv_and_b32 %3, 0x1fffffff, %11\n\t"
+        "v_and_b32 %4, 0x1fffffff, %12\n\tv_and_b32 %5, 0x1fffffff, %13\n\tv_and_b32 %6, 0x1fffffff, %14\n\tv_and_b32 %7, 0x1fffffff, %15"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(raw[0]), "v"(raw[1]), "v"(raw[2]), "v"(raw[3]), "v"(raw[4]), "v"(raw[5]), "v"(raw[6]), "v"(raw[7]));
+#else
+    for (int i = 0; i < 8; i++) r[i] = raw[i] & M29;
+#endif
+}
 // column helpers: sum_{i = lo}^{hi} a_i b_{k - i} and sum_{i = lo}^{hi} m_i p_{k - i}, one statement each in the block form
 template <class PRM, bool SER>
 __device__ __forceinline__ void col_ab(uint64_t& acc, const uint32_t (&a)[9], const uint32_t (&b)[9], int k, int lo, int hi) {
@@ -233,6 +248,7 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
     uint32_t m[9];
     Fe29<PRM> r;
     uint64_t acc = 0;
+    uint32_t raw[8];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         if (SER && MUL29_BLOCK && k == 0) mad_first(acc, a.l[0], b.l[0]);
@@ -246,9 +262,11 @@ __device__ __forceinline__ Fe29<PRM> mul29(const Fe29<PRM>& a, const Fe29<PRM>& 
     for (int k = 9; k < 17; k++) {
         col_ab<PRM, SER>(acc, a.l, b.l, k, k - 8, 8);
         col_mp<PRM, SER>(acc, m, k, k - 8, 8);
-        r.l[k - 9] = (uint32_t)acc & M29;
+        if (ZK_MUL29_MASKRUN && SER && MUL29_BLOCK) raw[k - 9] = (uint32_t)acc;
+        else r.l[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
+    if (ZK_MUL29_MASKRUN && SER && MUL29_BLOCK) mask_run8(r.l, raw);
     r.l[8] = (uint32_t)acc;
     return r;
 }
@@ -262,6 +280,7 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
     uint32_t m[9];
     Fe29<PRM> r;
     uint64_t acc = 0;
+    uint32_t raw[8];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         if (SER && MUL29_BLOCK && k == 0) mad_first(acc, a.l[0], b.l[0]);
@@ -277,9 +296,11 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
         col_ab<PRM, SER>(acc, a.l, b.l, k, k - 8, 8);
         col_ab<PRM, SER>(acc, c.l, d.l, k, k - 8, 8);
         col_mp<PRM, SER>(acc, m, k, k - 8, 8);
-        r.l[k - 9] = (uint32_t)acc & M29;
+        if (ZK_MUL29_MASKRUN && SER && MUL29_BLOCK) raw[k - 9] = (uint32_t)acc;
+        else r.l[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
+    if (ZK_MUL29_MASKRUN && SER && MUL29_BLOCK) mask_run8(r.l, raw);
     r.l[8] = (uint32_t)acc;
     return r;
 }
@@ -287,7 +308,7 @@ __device__ __forceinline__ Fe29<PRM> mul2add29(const Fe29<PRM>& a, const Fe29<PR
 // a * a * 2^-261 mod p: the 36 cross products are taken once against the doubled operand (45 instead of 81 products of a * a)
 template <class PRM, bool SER = MUL29_SER>
 __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
-    uint32_t m[9], a2[9];
+    uint32_t m[9], a2[9], raw[8];
 #pragma unroll
     for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
     Fe29<PRM> r;
@@ -322,10 +343,12 @@ __device__ __forceinline__ Fe29<PRM> sqr29(const Fe29<PRM>& a) {
             mad29c<SER>(acc, m[k], Lim29<PRM>::P[0]);
         } else {
             col_mp<PRM, SER>(acc, m, k, k - 8, 8);
-            r.l[k - 9] = (uint32_t)acc & M29;
+            if (ZK_MUL29_MASKRUN && SER && MUL29_BLOCK) raw[k - 9] = (uint32_t)acc;
+            else r.l[k - 9] = (uint32_t)acc & M29;
         }
         acc >>= 29;
     }
+    if (ZK_MUL29_MASKRUN && SER && MUL29_BLOCK) mask_run8(r.l, raw);
     r.l[8] = (uint32_t)acc;
     return r;
 }
