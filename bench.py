@@ -75,11 +75,20 @@ class ProofWorkload:
     def __init__(self, device, rank, world, inflight, steps, warmup, options=(), lockstep=1, params=None, transcript=None):
         from webauthn_halo2_amd import batch, circuit, engine as E
 
-        def factory(dev):  # tuning experiments only (--opt id=value -> zk_ctx_set_option before the SRS is loaded)
-            e = E.Engine(dev)
+        made = []
+
+        def configure(e):  # tuning experiments only (--opt id=value -> zk_ctx_set_option right after zk_ctx_create)
             for oid, val in options:
+                if isinstance(val, (list, tuple)):  # one value per pipeline, in the order the pipelines are made
+                    val = val[len(made) % len(val)]
                 e.set_option(oid, val)
+            made.append(e)
             return e
+
+        def factory(dev):
+            return configure(E.Engine(dev))
+
+        factory.configure = configure
 
         self.batch, self.E = batch, E
         self.lockstep = max(1, lockstep)
@@ -644,7 +653,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE",
                     help="tuning experiments: zk_ctx_set_option(ID, VALUE) on every pipeline (include/zkmi355.h ZK_OPT_*)")
     args = ap.parse_args()
-    options = [tuple(int(x) for x in o.split("=")) for o in args.opt]
+    options = []
+    for o in args.opt:  # ID=VALUE, or ID=V0,V1,.. (one value per pipeline)
+        oid, val = o.split("=")
+        vals = [int(x) for x in val.split(",")]
+        options.append((int(oid), vals[0] if len(vals) == 1 else vals))
 
     if args.k17_worker:
         return k17_worker(args)

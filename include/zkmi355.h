@@ -123,6 +123,10 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         audit's self-test: on, AND zk_prove takes a knowingly unordered path (its column transforms alternate
                                         between two streams per call without ordering their shared scratch — round 5's first form): every
                                         proof whose transforms come in more than one call must then return ZK_EINTERNAL */
+#define ZK_OPT_STREAM_PRIORITY 12    /* experiment: dispatch priority of the context's MAIN stream — 0 normal (default), 1 high, 2 low
+                                        (hipStreamCreateWithPriority).  Set it right after zk_ctx_create, before any other call: the stream
+                                        is made again.  Pipelines of one device at DIFFERENT priorities do not share the chip evenly, so
+                                        their chip-filling kernels stop ending together (docs/experiments.md) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

@@ -137,3 +137,23 @@ def test_transform_stream_placement_does_not_change_proofs(mode):
         assert not bad, bad
         for e in engs[::-1]:
             e.close()
+
+
+def test_stream_priority_option_leaves_results_unchanged():
+    """ZK_OPT_STREAM_PRIORITY (experiment, profiles/r6_ab_pipeline_priority.txt) re-makes a context's main stream at another
+    dispatch priority: same commitments, bad values refused, and a context that shares the first one's SRS takes it too."""
+    k = 12
+    n = 1 << k
+    base = zk.Engine(0)
+    base.srs_setup(k)
+    col = _column(n, 99)
+    want = base.commit(base.poly(n, col), E.ZK_BASIS_LAGRANGE).copy()
+    for value in (1, 2, 0):
+        e = zk.Engine(0, share_with=base)
+        e.set_option(E.ZK_OPT_STREAM_PRIORITY, value)
+        assert np.array_equal(e.commit(e.poly(n, col), E.ZK_BASIS_LAGRANGE), want)
+        e.close()
+    with pytest.raises(zk.ZkError):
+        base.set_option(E.ZK_OPT_STREAM_PRIORITY, 3)
+    base.set_option(E.ZK_OPT_STREAM_PRIORITY, 1)  # on a context that has already worked: drained, then replaced
+    assert np.array_equal(base.commit(base.poly(n, col), E.ZK_BASIS_LAGRANGE), want)

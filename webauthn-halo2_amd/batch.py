@@ -95,6 +95,9 @@ class Pipeline:
         self.deterministic_seeds = deterministic_seeds
         if share_srs_with is not None:
             self.eng = Engine(device, share_with=share_srs_with.eng)
+            configure = getattr(engine_factory, "configure", None)  # a factory's per-engine settings also reach the sharing pipelines
+            if configure is not None:
+                configure(self.eng)
         else:
             self.eng = engine_factory(device)
             self.eng.srs_setup(params.degree)

@@ -725,6 +725,28 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_GP_BATCH_INVERT:
             c->opt_gp_batch_invert = value ? 1 : 0;
             return ZK_OK;
+        case ZK_OPT_STREAM_PRIORITY: {
+            // experiment (docs/experiments.md "pipelines at different priorities"): the context's MAIN stream is made again at
+            // another dispatch priority.  Only meaningful before any work was enqueued (the audit ledger and the lone-proof side
+            // streams refer to the main stream by value); the old stream is drained first
+            if (value > 2) return ZK_EINVAL;
+            for (int i = 0; i < zk_ctx::MSM_LANES; i++)
+                if (c->lanes[i].busy) return ZK_EINVAL;  // an MSM pass in flight holds the stream by value
+            int rc = ctx_bind(c);
+            if (rc) return rc;
+            int lo = 0, hi = 0;  // numerically lower = higher priority
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return ZK_EHIP;
+            const int pr = value == 1 ? hi : value == 2 ? lo : (lo + hi) / 2;
+            hipStream_t ns = nullptr;
+            if (hipStreamCreateWithPriority(&ns, hipStreamDefault, pr) != hipSuccess) return ZK_EHIP;
+            hipStreamSynchronize(c->stream);
+            for (int i = 0; i < zk_ctx::MSM_LANES; i++)
+                if (c->lanes[i].tail == c->stream) c->lanes[i].tail = ns;
+            hipStreamDestroy(c->stream);
+            c->stream = ns;
+            c->audit.streams[0] = ns;
+            return ZK_OK;
+        }
         default: return ZK_EINVAL;
     }
 }

@@ -608,7 +608,6 @@ __global__ __launch_bounds__(64) void msm_wparts_kernel(const G1X29S* __restrict
     if (active) {
         // the bucket's slots: one per accumulation lane that held some of its entries, at index lane + bucket
         const uint32_t e0 = bstart_all[(size_t)col * nb + b];
-        const uint32_t s0 = e0 / WL + b;
         const uint32_t len = wide_slot_count(e0, totals_all[(size_t)col * nb + b]);
         if (len <= lmin) {  // the per-bucket kernel (msm_wbucket_kernel) has summed this bucket: its parts take no lane here
             active = false;
