@@ -127,6 +127,14 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         (hipStreamCreateWithPriority).  Set it right after zk_ctx_create, before any other call: the stream
                                         is made again.  Pipelines of one device at DIFFERENT priorities do not share the chip evenly, so
                                         their chip-filling kernels stop ending together (docs/experiments.md) */
+#define ZK_OPT_QUOTIENT_DOMAIN 13    /* zk_prove, circuits whose quotient has THREE pieces (two or more advice columns: deg h < 3n): h can be
+                                        taken over three of the four cosets of halo2's extended domain — three n-point transforms per column
+                                        instead of one 4n-point one, 3n quotient rows, a 3 x 3 solve per coefficient: the same pieces, the same
+                                        proof bytes, a quarter of that work less.  0 (default) = auto: that route for columns of 2^16 rows or
+                                        more (the proving server's k = 17 among them; the many-column rows below lose by it), 1 = always the
+                                        whole extended domain (round 5's route), 2 = three cosets wherever h has three pieces.
+                                        zk_prove_batch follows the same rule; the phase-level entry points (zk_coeff_to_extended, zk_quotient,
+                                        zk_extended_to_coeff) always work on the whole domain in halo2's order */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

@@ -35,6 +35,9 @@ def main():
     eng = zk.Engine(0)
     if os.environ.get("MSM_WINDOW"):  # tuning runs: force the fixed-base MSM window for every row
         eng.set_option(E.ZK_OPT_MSM_WINDOW, int(os.environ["MSM_WINDOW"]))
+    for o in os.environ.get("OPTS", "").split(","):  # OPTS=13=1: zk_ctx_set_option
+        if o:
+            eng.set_option(*(int(x) for x in o.split("=")))
     only = [int(x) for x in os.environ["ROWS"].split(",")] if os.environ.get("ROWS") else None
     print("degree,num_advice,num_lookup,num_fixed,lookup_bits,proof_ms,proof_size,published_cpu_s,speedup")
     for k, A, L, F, lb, idle, pub_s, pub_b in ROWS:

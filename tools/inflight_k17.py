@@ -16,18 +16,24 @@ fixed, copies = batch.structure(p)
 OPTS = [tuple(int(x) for x in o.split("=")) for o in os.environ.get("OPTS", "").split(",") if o]  # OPTS=5=1,2=4: zk_ctx_set_option
 
 
-def factory(dev):
-    e = E.Engine(dev)
+def configure(e):
     for o, v in OPTS:
         e.set_option(o, v)
     return e
+
+
+def factory(dev):
+    return configure(E.Engine(dev))
+
+
+factory.configure = configure  # (batch.Pipeline: the options also reach the pipelines that share the first one's SRS)
 
 
 for spec in (sys.argv[1:] or ["1", "2", "3", "4"]):
     npipe, ls = (int(x) for x in (spec.split("x") + ["1"])[:2])
     pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True)]
     for _ in range(npipe - 1):
-        pipes.append(batch.Pipeline(0, p, fixed, copies, deterministic_seeds=True, share_srs_with=pipes[0]))
+        pipes.append(batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True, share_srs_with=pipes[0]))
     for pl in pipes:
         for j in jobs:
             pl.load(j, wit[j])

@@ -48,6 +48,9 @@ struct zk_ctx {
     std::map<uint32_t, Fr*> twiddles_ntt;  // the same powers in the NTT's internal form (x 2^261, ntt.hip)
     std::map<uint32_t, Fr> ninv;           // 1 / 2^log_n (host constant of the inverse transforms)
     std::map<uint32_t, Fr*> twiddles_ninv; // w^i / 2^log_n (standard form): the last pass of an inverse transform (ntt.hip NTT_FOLD)
+    std::map<uint32_t, Fr*> coset3_pre;    // k -> [2][2^k]: the twists (zeta w_4n^j)^m, j = 1, 2, of the three-coset transforms (poly.hip)
+    std::map<uint32_t, Coset3Consts> coset3_consts;  // k -> the constants of the 3 x 3 solve
+    uint32_t opt_quotient_domain = 0;      // ZK_OPT_QUOTIENT_DOMAIN: 0 auto (three cosets from k = 16), 1 always the whole extended domain, 2 three cosets wherever h has three pieces
     // SRS (the pointers below alias the members of `srs`, the owner)
     std::shared_ptr<SrsBlock> srs;
     int srs_k = -1;
@@ -221,6 +224,10 @@ void ctx_msm_drain(zk_ctx* c);  // error paths: wait for every MSM in flight and
 // NTT between device buffers: inverse => x 1/N; coset => zeta scaling (coeff_to_extended / extended_to_coeff)
 int ctx_ntt(zk_ctx* c, const Fr* src, size_t src_n, Fr* dst, uint32_t log_n, bool inverse, bool coset, size_t n_out);
 // the same transform over `batch` vectors in one launch per pass (batch <= ctx_ntt_max_batch(log_n))
+// the three-coset route (poly.hip "three cosets"): coefficient vectors (n = 2^k) -> [3][n] coset-major values, `cols` columns per
+// call (3 cols <= ctx_ntt_max_batch(k)); and the quotient's way back, in place: [3][n] values of h -> its 3n coefficients
+int ctx_ntt_cosets3(zk_ctx* c, const Fr* const* polys, Fr* const* dsts, uint32_t cols, uint32_t k, hipStream_t on = nullptr);
+int ctx_intt_cosets3(zk_ctx* c, Fr* h, uint32_t k);
 int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dsts, uint32_t batch, uint32_t log_n, bool inverse,
                   bool coset, size_t n_out, hipStream_t on = nullptr /* the context's main stream */);
 uint32_t ctx_ntt_max_batch(uint32_t log_n);

@@ -30,6 +30,9 @@ struct NttJob {
     uint32_t n_in, n_out;
     uint32_t has_pre, has_post;
     Fr pre[3], post[3]; // period-3 scale factors by index (coset zeta powers, 1/N)
+    // batch mode, optional per vector: element i of srcs[b] is multiplied by pre_tabs[b][i] (times 2^266 as plain words, like
+    // `pre`) on the way in instead of pre[i % 3]: the twist of a transform over the coset (zeta w_4n^j) H (engine.hip, coset3)
+    const Fr* pre_tabs[NTT_MAX_BATCH];
     uint32_t max_log_r; // 0 = default
 };
 hipError_t ntt_run(const NttJob& job, hipStream_t st);
@@ -37,6 +40,15 @@ void launch_twiddles(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);          
 void launch_twiddles_scaled(Fr* tw, const Fr& w, const Fr& scale, uint32_t n, hipStream_t st);  // scale * w^i, standard form
 void launch_twiddles_internal(Fr* tw, const Fr& w, uint32_t n, hipStream_t st);  // w^i * 2^261 (plain words): ntt.hip's own form
 int ntt_plan(uint32_t log_n, uint32_t max_log_r, uint32_t bits[8]);
+
+// ---- the three-coset route of a quotient with three pieces (poly.hip "three cosets") ----
+struct Coset3Consts {  // constants of the 3 x 3 solve, standard form
+    Fr inv2, inv_2z, zi, inv_2z2;  // 1/2, 1/(2 z), z i, 1/(2 z^2) with z = zeta^n, i = w_4n^n
+    Fr zinv[3];                    // zeta^-(m mod 3)
+};
+void launch_coset3_pre(const Fr* tw_ext, uint32_t n, uint32_t j, const Fr zp1024[3], Fr* tab, hipStream_t st);
+void launch_coset3_relayout(const Fr* const* src, Fr* const* dst, uint32_t count, uint32_t n, hipStream_t st);
+void launch_coset3_combine(Fr* h, const Fr* tw_ext, uint32_t n, const Coset3Consts& k, hipStream_t st);
 
 // ---- MSM (msm.hip) ---------------------------------------------------------
 struct MsmWorkspace;  // opaque, sized for a maximum n and a maximum number of columns per launch

@@ -541,6 +541,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (auto& kv : c->twiddles_ntt) hipFree(kv.second);
     for (auto& kv : c->twiddles_ninv) hipFree(kv.second);
     for (auto& kv : c->coset_points) hipFree(kv.second);
+    for (auto& kv : c->coset3_pre) hipFree(kv.second);
     pk_destroy_all(c);
     for (auto& kv : c->polys) hipFree(kv.second.ptr);
     for (auto& r : c->poly_spare) hipFree(r.ptr);
@@ -724,6 +725,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
             return ZK_OK;
         case ZK_OPT_GP_BATCH_INVERT:
             c->opt_gp_batch_invert = value ? 1 : 0;
+            return ZK_OK;
+        case ZK_OPT_QUOTIENT_DOMAIN:
+            if (value > 2) return ZK_EINVAL;
+            c->opt_quotient_domain = (uint32_t)value;
             return ZK_OK;
         case ZK_OPT_STREAM_PRIORITY: {
             // experiment (docs/experiments.md "pipelines at different priorities"): the context's MAIN stream is made again at
@@ -1374,6 +1379,103 @@ int ctx_ntt_batch(zk_ctx* c, const Fr* const* srcs, size_t src_n, Fr* const* dst
         c->last_hip = (int)e;
         return ZK_EHIP;
     }
+    return ZK_OK;
+}
+
+// ---- the three-coset route (poly.hip "three cosets") ---------------------------------------------------------------
+static int ctx_get_coset3_pre(zk_ctx* c, uint32_t k, const Fr** out) {
+    auto it = c->coset3_pre.find(k);
+    if (it != c->coset3_pre.end()) {
+        *out = it->second;
+        return ZK_OK;
+    }
+    const Fr* tw_ext = nullptr;
+    int rc = ctx_get_twiddles(c, k + 2, &tw_ext);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << k;
+    Fr* tab = nullptr;
+    if (hipMalloc(&tab, 2 * n * sizeof(Fr)) != hipSuccess) return ZK_ENOMEM;
+    const Fr k1024 = fr_from_u64(1024);
+    const Fr zp[3] = {k1024, fe_mul(c->zeta, k1024), fe_mul(c->zeta2, k1024)};
+    for (uint32_t j = 1; j <= 2; j++) launch_coset3_pre(tw_ext, (uint32_t)n, j, zp, tab + (size_t)(j - 1) * n, c->stream);
+    aud_sync(c, c->stream);  // made once per context and size; read from any of the context's streams afterwards
+    c->coset3_pre[k] = tab;
+    *out = tab;
+    return ZK_OK;
+}
+
+int ctx_ntt_cosets3(zk_ctx* c, const Fr* const* polys, Fr* const* dsts, uint32_t cols, uint32_t k, hipStream_t on) {
+    const hipStream_t st = on ? on : c->stream;
+    const size_t n = (size_t)1 << k;
+    const uint32_t batch = 3 * cols;
+    if (cols == 0 || batch > ctx_ntt_max_batch(k)) return ZK_EINVAL;
+    int rc = ctx_ensure_scratch(c, n * batch);
+    if (rc) return rc;
+    const Fr *tw = nullptr, *pre = nullptr;
+    if ((rc = ctx_get_twiddles_ntt(c, k, &tw)) != ZK_OK || (rc = ctx_get_coset3_pre(c, k, &pre)) != ZK_OK) return rc;
+    NttJob job;
+    memset(&job, 0, sizeof(job));
+    job.batch = batch;
+    for (uint32_t q = 0; q < cols; q++)
+        for (uint32_t j = 0; j < 3; j++) {
+            job.srcs[3 * q + j] = polys[q];
+            job.dsts[3 * q + j] = dsts[q] + (size_t)j * n;
+            job.pre_tabs[3 * q + j] = j ? pre + (size_t)(j - 1) * n : nullptr;  // coset 0: zeta^m alone (`pre`)
+        }
+    job.tmp = c->scratch;
+    job.tw = tw;
+    job.log_n = k;
+    job.n_in = job.n_out = (uint32_t)n;
+    job.max_log_r = c->opt_ntt_max_r;
+    if (k > 7 && (rc = ctx_get_twiddles(c, k, &job.tw_last)) != ZK_OK) return rc;
+    job.has_pre = 1;
+    job.pre[0] = Fr::one();
+    job.pre[1] = c->zeta;
+    job.pre[2] = c->zeta2;
+    if (c->audit.on) {
+        const void *rd[NTT_MAX_BATCH + 1], *wr[NTT_MAX_BATCH + 1];
+        for (uint32_t q = 0; q < cols; q++) {
+            rd[q] = polys[q];
+            wr[q] = dsts[q];
+        }
+        rd[cols] = wr[cols] = c->scratch;
+        c->audit.op_v(st, rd, cols + 1, wr, cols + 1, "NTT batch (three cosets)");
+    }
+    aud_record(c, c->ev[ZK_T_NTT][0], st);
+    hipError_t e = ntt_run(job, st);
+    aud_record(c, c->ev[ZK_T_NTT][1], st);
+    c->ev_valid[ZK_T_NTT] = true;
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        return ZK_EHIP;
+    }
+    return ZK_OK;
+}
+
+int ctx_intt_cosets3(zk_ctx* c, Fr* h, uint32_t k) {
+    const size_t n = (size_t)1 << k;
+    const Fr* srcs[3] = {h, h + n, h + 2 * n};
+    Fr* dsts[3] = {h, h + n, h + 2 * n};
+    int rc = ctx_ntt_batch(c, srcs, n, dsts, 3, k, true, false, n);  // plain inverse transforms (1/n included), in place
+    if (rc) return rc;
+    const Fr* tw_ext = nullptr;
+    if ((rc = ctx_get_twiddles(c, k + 2, &tw_ext)) != ZK_OK) return rc;
+    auto it = c->coset3_consts.find(k);
+    if (it == c->coset3_consts.end()) {
+        const Fr z = fe_pow_u64(c->zeta, n), i4 = fe_pow_u64(fr_omega(k + 2), n);
+        const Fr two = fr_from_u64(2);
+        Coset3Consts q;
+        q.inv2 = fe_inv_fast(two);
+        q.inv_2z = fe_inv_fast(fe_mul(two, z));
+        q.zi = fe_mul(z, i4);
+        q.inv_2z2 = fe_inv_fast(fe_mul(two, fe_sqr(z)));
+        q.zinv[0] = Fr::one();
+        q.zinv[1] = c->zeta2;  // zeta^-1 = zeta^2 (a cube root of unity)
+        q.zinv[2] = c->zeta;
+        it = c->coset3_consts.emplace(k, q).first;
+    }
+    if (c->audit.on) c->audit.op(c->stream, {h}, {h}, "three cosets -> h pieces");
+    launch_coset3_combine(h, tw_ext, (uint32_t)n, it->second, c->stream);
     return ZK_OK;
 }
 

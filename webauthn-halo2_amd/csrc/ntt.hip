@@ -65,6 +65,8 @@ struct NttPassArgs {
     uint32_t has_pre;    // multiply in[i] by pre[i % 3] on load (first pass)
     uint32_t has_post;   // multiply out[i] by post[i % 3] on store (last pass)
     Fr pre[3];           // pre-scale factors * 2^266 (plain words): product with a standard-form input is internal
+    const Fr* pre_tab[NTT_MAX_BATCH];  // first pass, per vector (nullptr: none): in[i] is multiplied by pre_tab[i] (times 2^266, plain
+                                       // words) instead of pre[i % 3] — the per-element twist of a coset transform (engine.hip coset3)
     Fr post[3];          // post-scale factors in standard Montgomery form: product with an internal value is standard
 };
 
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
         return a.inverse ? ((N - ex) & nmask) : ex;  // 0 <=> trivial twiddle
     };
     const Fr* __restrict__ twl = MODE == NTT_FOLD ? a.tw_last : a.tw;  // inter-pass twiddles of this pass
+    const Fr* __restrict__ ptab = (MODE == NTT_GENERAL && a.log_ns == 0) ? a.pre_tab[blockIdx.y] : nullptr;  // per-element pre-scale
     auto place = [&](uint32_t t, uint32_t r, uint32_t idx, const Fr& v, const Fr& w, uint32_t ti) {
         Fr29 x;
         if (idx < a.n_in) {
@@ -237,8 +240,12 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             } else if (a.log_ns == 0) {
                 // first pass: standard form in.  32 v is a valid internal form (bound 32 p); the coset factor's
                 // constant carries 2^266 so that the product lands in internal form
-                const uint32_t m = a.has_pre ? idx % 3 : 0;
-                x = m ? mul29(to29(v), to29(a.pre[m])) : to29_x32(v);
+                if (ptab) {
+                    x = mul29(to29(v), to29(w));  // w = pre_tab[idx]
+                } else {
+                    const uint32_t m = a.has_pre ? idx % 3 : 0;
+                    x = m ? mul29(to29(v), to29(a.pre[m])) : to29_x32(v);
+                }
             } else {
                 x = to29(v);  // internal value < 2^256
                 if (ti) x = mul29(x, to29(w));
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             ii[k] = src_index(threadIdx.x + k * NTT_THREADS, tt[k], rr[k]);
             ti[k] = a.log_ns ? tw_index(tt[k], rr[k]) : 0;
             v[k] = ii[k] < a.n_in ? fe_load(vin + ii[k]) : Fr::zero();
-            w[k] = (ti[k] || MODE == NTT_FOLD) ? fe_load(twl + ti[k]) : Fr::zero();
+            if (ptab) w[k] = ii[k] < a.n_in ? fe_load(ptab + ii[k]) : Fr::zero();
+            else w[k] = (ti[k] || MODE == NTT_FOLD) ? fe_load(twl + ti[k]) : Fr::zero();
         }
 #pragma unroll
         for (uint32_t k = 0; k < EPT; k++) place(tt[k], rr[k], ii[k], v[k], w[k], ti[k]);
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(cons
             const uint32_t idx = src_index(e, t, r);
             const uint32_t ti = a.log_ns ? tw_index(t, r) : 0;
             const Fr v = idx < a.n_in ? fe_load(vin + idx) : Fr::zero();
-            const Fr w = (ti || MODE == NTT_FOLD) ? fe_load(twl + ti) : Fr::zero();
+            const Fr w = ptab ? (idx < a.n_in ? fe_load(ptab + idx) : Fr::zero()) : (ti || MODE == NTT_FOLD) ? fe_load(twl + ti) : Fr::zero();
             place(t, r, idx, v, w, ti);
         }
     }
@@ -526,6 +534,7 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         for (uint32_t b = 0; b < batch; b++) {
             a.in[b] = cur_in[b];
             a.out[b] = which ? job.tmp + (size_t)b * N : dsts[b];
+            a.pre_tab[b] = (p == 0 && job.batch) ? job.pre_tabs[b] : nullptr;
         }
         a.tw = job.tw;
         a.tw_last = job.tw_last;

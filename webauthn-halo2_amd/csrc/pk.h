@@ -109,6 +109,8 @@ struct zk_pk_rec {
     std::vector<Fr*> dev;  // every device allocation (freed together)
     std::vector<Fr*> fixed_val, fixed_poly, fixed_coset, sigma_val, sigma_poly, sigma_coset;
     Fr *l0_coset = nullptr, *l_last_coset = nullptr, *l_active_coset = nullptr;
+    std::vector<Fr*> fixed_c3, sigma_c3;  // pk_ensure_cosets3 (empty until the first proof on the three-coset route)
+    Fr *l0_c3 = nullptr, *l_last_c3 = nullptr, *l_active_c3 = nullptr;
     std::vector<G1Affine> fixed_commit, perm_commit;
     Fr transcript_repr;
     // prover workspace
@@ -184,7 +186,11 @@ struct Dev {
 // extended cosets the quotient reads beside the key's own: advice columns, permutation products, per lookup a', s', zL
 struct QuotientCosets {
     std::vector<const Fr*> adv, z, lk_a, lk_s, lk_z;
+    bool cosets3 = false;  // the operands are [3][n] coset-major vectors (poly.hip "three cosets"); the key's own are taken from its c3 copies
 };
+// the key's extended cosets (fixed, sigma, l_0, l_last, l_active) once more in the [3][n] coset-major order of the three-coset
+// route: made on the first proof that takes it (keygen and zk_pk_read both end up here), kept with the key
+int pk_ensure_cosets3(zk_ctx* c, zk_pk_rec* pk);
 int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& beta, const Fr& gamma, const Fr& y, bool divide, Fr* out);
 void pk_destroy(zk_pk_rec* pk);
 // the per-proof workspace (advice / z / lookup forms, quotient buffer, scan and evaluation scratch): everything a key

@@ -169,6 +169,80 @@ void launch_eval_batch(EvalItem* h_items, EvalItem* d_items, uint32_t count, uin
     hipLaunchKernelGGL(poly_sum_batch_kernel, dim3(count), dim3(256), 0, st, d_items, scratch, blocks, out);
 }
 
+// ------------------------------------------------- three cosets (round 6) ----
+// A circuit whose quotient has THREE pieces (degree 4: every bench_ecdsa.config row with two or more advice columns, the proving
+// server's k = 17 among them) has deg h < 3n, so h is determined by its values on three of the four cosets
+// g_j H, g_j = zeta w_4n^j, that make up halo2's extended domain (EvaluationDomain::extended_k = k + 2: a power of two, one coset
+// more than the degree needs).  The prover's private path (prover.hip, Prover::transforms / quotient) therefore works on
+// [3][n] "coset-major" vectors — v[j n + i] = f(g_j w_n^i), j < 3 — made by three n-point transforms of the coefficients twisted by
+// g_j^m, evaluates the quotient numerator on those 3n rows, and recovers the pieces from three n-point inverse transforms:
+// with c_j = g_j^n = z i^j (z = zeta^n, i = w_4n^n) the interpolant of coset j is r_j = h0 + c_j h1 + c_j^2 h2 coefficient by
+// coefficient (X^n = c_j on the coset), a 3 x 3 system with constant coefficients.  The coefficients of h are unique, so the
+// pieces — and every proof byte — equal those of the 4n-point route; a quarter of the transform and quotient work is gone.
+// (The public zk_coeff_to_extended / zk_quotient / zk_extended_to_coeff and the key's file image keep halo2's 4n layout.)
+
+// tab[m] = zeta^(m mod 3) * w_4n^(j m) * 2^10 (Montgomery image: as plain words the factor carries 2^266, ntt.hip `pre`)
+__global__ __launch_bounds__(256) void coset3_pre_kernel(const Fr* __restrict__ tw_ext, uint32_t n, uint32_t j, Fr z0, Fr z1, Fr z2,
+                                                         Fr* __restrict__ tab) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n) return;
+    const uint32_t r = m % 3;
+    fe_store(tab + m, fe_mul(fe_load(tw_ext + (size_t)j * m), r == 0 ? z0 : r == 1 ? z1 : z2));  // j m < 4n
+}
+void launch_coset3_pre(const Fr* tw_ext, uint32_t n, uint32_t j, const Fr zp1024[3], Fr* tab, hipStream_t st) {
+    hipLaunchKernelGGL(coset3_pre_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tw_ext, n, j, zp1024[0], zp1024[1], zp1024[2], tab);
+}
+
+// dst[j n + i] = src[4 i + j], j < 3: the key's extended cosets (halo2's order) in coset-major order; blockIdx.y = vector
+struct Coset3Vecs {
+    const Fr* src[32];
+    Fr* dst[32];
+};
+__global__ __launch_bounds__(256) void coset3_relayout_kernel(Coset3Vecs v, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Fr* __restrict__ s = v.src[blockIdx.y];
+    Fr* __restrict__ d = v.dst[blockIdx.y];
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) fe_store(d + (size_t)j * n + i, fe_load(s + 4 * (size_t)i + j));
+}
+void launch_coset3_relayout(const Fr* const* src, Fr* const* dst, uint32_t count, uint32_t n, hipStream_t st) {
+    for (uint32_t c0 = 0; c0 < count; c0 += 32) {
+        Coset3Vecs v;
+        const uint32_t cnt = count - c0 < 32 ? count - c0 : 32;
+        for (uint32_t q = 0; q < cnt; q++) {
+            v.src[q] = src[c0 + q];
+            v.dst[q] = dst[c0 + q];
+        }
+        hipLaunchKernelGGL(coset3_relayout_kernel, dim3((n + 255) / 256, cnt), dim3(256), 0, st, v, n);
+    }
+}
+
+// h[j n + m] = a_j[m] = g_j^m r_j[m] (the three inverse transforms' outputs)  ->  h[k n + m] = h_k[m], k < 3, in place:
+//   v_j = a_j[m] w_4n^(-j m) = zeta^m r_j[m];   h1 = (v0 - v2) / (2 z);   A = (v0 + v2) / 2;   B = v1 - z i h1;
+//   h0 = (A + B) / 2;   h2 = (A - B) / (2 z^2);   each times zeta^(-m)
+__global__ __launch_bounds__(256) void coset3_combine_kernel(Fr* __restrict__ h, const Fr* __restrict__ tw_ext, uint32_t n, Coset3Consts k) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n) return;
+    const uint32_t N4 = 4 * n;
+    const Fr v0 = fe_load(h + m);
+    const Fr v1 = fe_mul(fe_load(h + (size_t)n + m), fe_load(tw_ext + ((N4 - m) & (N4 - 1))));
+    const Fr v2 = fe_mul(fe_load(h + 2 * (size_t)n + m), fe_load(tw_ext + ((N4 - 2 * m) & (N4 - 1))));
+    const Fr h1 = fe_mul(fe_sub(v0, v2), k.inv_2z);
+    const Fr A = fe_mul(fe_add(v0, v2), k.inv2);
+    const Fr B = fe_sub(v1, fe_mul(h1, k.zi));
+    const Fr h0 = fe_mul(fe_add(A, B), k.inv2);
+    const Fr h2 = fe_mul(fe_sub(A, B), k.inv_2z2);
+    const uint32_t r = m % 3;
+    const Fr s = r == 0 ? k.zinv[0] : r == 1 ? k.zinv[1] : k.zinv[2];
+    fe_store(h + m, fe_mul(h0, s));
+    fe_store(h + (size_t)n + m, fe_mul(h1, s));
+    fe_store(h + 2 * (size_t)n + m, fe_mul(h2, s));
+}
+void launch_coset3_combine(Fr* h, const Fr* tw_ext, uint32_t n, const Coset3Consts& k, hipStream_t st) {
+    hipLaunchKernelGGL(coset3_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h, tw_ext, n, k);
+}
+
 // ------------------------------------------------------------------ SRS ----
 
 // out[i] = L_i(s) = w^i * c / (s - w^i),  c = (s^n - 1)/n   (ParamsKZG::setup, g_lagrange scalars)

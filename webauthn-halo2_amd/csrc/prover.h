@@ -155,7 +155,7 @@ uint32_t kate_division_scratch(uint32_t n);  // elements of scratch per division
 void launch_kate_division(const Fr* p, Fr* q, uint32_t n, const Fr& z, Fr* scratch, hipStream_t st);
 void launch_kate_division_batch(const Fr* const* p, Fr* const* q, const Fr* z, uint32_t count, uint32_t n, Fr* scratch,
                                 hipStream_t st);
-void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, uint32_t log_slices, hipStream_t st);
+void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, uint32_t log_slices, hipStream_t st, bool cosets3 = false);
 uint32_t quotient_log_slices(uint32_t log_ext, uint32_t n_gate);
 
 // poly.hip

@@ -573,6 +573,51 @@ ZK_API(zk_vk_export, (zk_ctx* c, zk_pk h, uint64_t* fixed_commitments, uint64_t*
     return ZK_OK;
 }
 
+int pk_ensure_cosets3(zk_ctx* c, zk_pk_rec* pk) {
+    const Layout& lay = pk->lay;
+    if (lay.n_h != 3) return ZK_EINVAL;
+    auto to_members = [&]() {  // by-value copies of the record (pk_make_member): the key half is written through
+        for (zk_pk_rec* m : pk->members) {
+            m->fixed_c3 = pk->fixed_c3;
+            m->sigma_c3 = pk->sigma_c3;
+            m->l0_c3 = pk->l0_c3;
+            m->l_last_c3 = pk->l_last_c3;
+            m->l_active_c3 = pk->l_active_c3;
+        }
+    };
+    if (pk->fixed_c3.size() == lay.n_fix && pk->l_active_c3) {
+        to_members();
+        return ZK_OK;
+    }
+    const size_t n = lay.n;
+    Dev d{c, pk};
+    std::vector<const Fr*> src;
+    std::vector<Fr*> dst;
+    auto add = [&](const Fr* s) {
+        Fr* t = d.alloc(3 * n);
+        src.push_back(s);
+        dst.push_back(t);
+        return t;
+    };
+    std::vector<Fr*> fx, sg;
+    for (uint32_t f = 0; f < lay.n_fix; f++) fx.push_back(add(pk->fixed_coset[f]));
+    for (size_t p = 0; p < lay.perm_cols.size(); p++) sg.push_back(add(pk->sigma_coset[p]));
+    Fr *a0 = add(pk->l0_coset), *a1 = add(pk->l_last_coset), *a2 = add(pk->l_active_coset);
+    if (d.rc) return d.rc;  // (what was allocated stays on the key's list and is freed with it)
+    launch_coset3_relayout(src.data(), dst.data(), (uint32_t)src.size(), (uint32_t)n, c->stream);
+    if (c->audit.on) {
+        std::vector<const void*> rd(src.begin(), src.end()), wr(dst.begin(), dst.end());
+        c->audit.op_v(c->stream, rd.data(), rd.size(), wr.data(), wr.size(), "key cosets -> coset-major");
+    }
+    pk->fixed_c3 = fx;
+    pk->sigma_c3 = sg;
+    pk->l0_c3 = a0;
+    pk->l_last_c3 = a1;
+    pk->l_active_c3 = a2;
+    to_members();
+    return ZK_OK;
+}
+
 // Evaluator::evaluate_h (+ divide_by_vanishing_poly when `divide`) over resident extended cosets: the key's fixed /
 // sigma / l_* cosets and the caller's advice, permutation-product and lookup cosets.  Enqueued on the context stream.
 int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& beta, const Fr& gamma, const Fr& y, bool divide, Fr* out) {
@@ -597,12 +642,14 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
     q.fx_table = lay.fx_table;
     q.fx_qlookup = lay.fx_qlookup;
     for (uint32_t j = 0; j < lay.n_adv; j++) q.adv[j] = qc.adv[j];
-    for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = pk->fixed_coset[f];
+    const bool c3 = qc.cosets3;
+    if (c3 && (lay.n_h != 3 || pk->fixed_c3.size() != lay.n_fix)) return ZK_EINVAL;  // (pk_ensure_cosets3 first)
+    for (uint32_t f = 0; f < lay.n_fix; f++) q.fix[f] = c3 ? pk->fixed_c3[f] : pk->fixed_coset[f];
     for (uint32_t j = 0; j < lay.n_gate; j++) q.fx_sel[j] = lay.gate_sel[j];
     for (uint32_t p = 0; p < q.n_perm; p++) {
-        q.sigma[p] = pk->sigma_coset[p];
+        q.sigma[p] = c3 ? pk->sigma_c3[p] : pk->sigma_coset[p];
         const Col& col = lay.perm_cols[p];
-        q.perm_val[p] = col.fixed ? pk->fixed_coset[col.idx] : qc.adv[col.idx];
+        q.perm_val[p] = col.fixed ? q.fix[col.idx] : qc.adv[col.idx];
     }
     for (uint32_t ci = 0; ci < lay.n_chunks; ci++) q.z[ci] = qc.z[ci];
     for (uint32_t l = 0; l < lay.n_lookups; l++) {
@@ -611,9 +658,9 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
         q.lk_s[l] = qc.lk_s[l];
         q.lk_in[l] = lay.single ? nullptr : qc.adv[lay.n_gate + l];
     }
-    q.l0 = pk->l0_coset;
-    q.l_last = pk->l_last_coset;
-    q.l_active = pk->l_active_coset;
+    q.l0 = c3 ? pk->l0_c3 : pk->l0_coset;
+    q.l_last = c3 ? pk->l_last_c3 : pk->l_last_coset;
+    q.l_active = c3 ? pk->l_active_c3 : pk->l_active_coset;
     q.xs = xs;
     // the kernel works in the carry-free field's internal form (x * 2^261): its constants are handed over times 32
     const Fr k32 = fr_from_u64(32);
@@ -655,7 +702,7 @@ int pk_quotient(zk_ctx* c, zk_pk_rec* pk, const QuotientCosets& qc, const Fr& be
     hipEventRecord(c->ev[ZK_T_QUOTIENT][0], st);
     const size_t bytes = sizeof(q) - sizeof(q.ypow) + (size_t)q.n_terms * sizeof(Fr);
     if (hipMemcpyAsync(pk->d_qargs, &q, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ZK_EHIP;
-    launch_quotient_dev(pk->d_qargs, lay.ext_k, log_slices, st);
+    launch_quotient_dev(pk->d_qargs, lay.ext_k, log_slices, st, c3);
     hipEventRecord(c->ev[ZK_T_QUOTIENT][1], st);
     c->ev_valid[ZK_T_QUOTIENT] = true;
     return ZK_OK;
@@ -907,6 +954,9 @@ struct Prover {
     // share the context's ping-pong scratch without an order between them (round 5's first form decided per call: under four
     // pipelines the count dips to one now and then, and 1 proof in ~ 1 500 came out wrong — tools/soak.py)
     bool xside = false;
+    // a quotient of three pieces (deg h < 3n) is taken over three of the extended domain's four cosets (poly.hip "three cosets"):
+    // the columns' coset forms are [3][n] coset-major, made by n-point transforms.  Decided once per proof (begin())
+    bool cosets3 = false;
     // (audit self-test, ZK_OPT_STREAM_AUDIT = 2: round 5's faulty form on purpose — the stream chosen per CALL, alternating, and no
     // join before a main-stream transform: the ledger must then refuse every proof whose transforms come in more than one call)
     bool fault_flip = false;
@@ -944,6 +994,20 @@ struct Prover {
             }
             int r = ctx_ntt_batch(c, src, n, dst, cnt, lay.k, true, false, n, xs);
             if (r) fail(r);
+        }
+        if (cosets3) {
+            // a quotient of three pieces: three n-point transforms per column into [3][n] coset-major values (poly.hip "three cosets")
+            const uint32_t b3 = std::max(1u, b1 / 3);
+            for (size_t i0 = 0; i0 < cols.size() && ok(); i0 += b3) {
+                const uint32_t cnt = (uint32_t)std::min<size_t>(b3, cols.size() - i0);
+                for (uint32_t q = 0; q < cnt; q++) {
+                    src[q] = cols[i0 + q].poly;
+                    dst[q] = cols[i0 + q].coset;
+                }
+                int r = ctx_ntt_cosets3(c, src, dst, cnt, lay.k, xs);
+                if (r) fail(r);
+            }
+            return;
         }
         for (size_t i0 = 0; i0 < cols.size() && ok(); i0 += b2) {
             const uint32_t cnt = (uint32_t)std::min<size_t>(b2, cols.size() - i0);
@@ -1025,6 +1089,7 @@ struct Prover {
             qc.lk_s.push_back(pk->lk_sp_coset[l]);
             qc.lk_z.push_back(pk->lk_z_coset[l]);
         }
+        qc.cosets3 = cosets3;
         xform_join();  // every coset form is complete
         if (!ok()) return rc;
         if (c->audit.on) {
@@ -1035,6 +1100,7 @@ struct Prover {
         }
         int r = pk_quotient(c, pk, qc, beta, gamma, y, true, pk->h_ext);
         if (r) return r;
+        if (cosets3) return ctx_intt_cosets3(c, pk->h_ext, lay.k);
         return ctx_ntt(c, pk->h_ext, N, pk->h_ext, lay.ext_k, true, true, N);
     }
 
@@ -1129,6 +1195,13 @@ struct Prover {
         c->msm_side = !batch_member && (c->opt_msm_stream == 1 || (c->opt_msm_stream == 0 && xside && c->opt_xform_stream == 0));
         if ((xside || c->msm_side || c->audit_fault) && (rc = ctx_lone_streams(c))) return rc;
         if ((rc = ctx_get_twiddles(c, lay.k, &tw)) || (rc = ctx_get_twiddles(c, lay.ext_k, &tw_ext))) return rc;
+        // auto: columns of 2^16 rows or more (measured, tools/r6_cosets3_ab.sh: k = 18 / 17 / 16 - 1 / - 3 / - 3 %, k = 17 EVM over four
+        // pipelines 196 -> 203 proofs/s; the many-column rows lose — three vectors per column fill the transforms' launches three
+        // times as fast: k = 13 / 12 / 11 + 5 / + 5 / + 12 %)
+        // (the members of a lock-step batch get the key's coset-major copies from the batch driver: prover_batch.h)
+        cosets3 = lay.n_h == 3 && 3 <= ctx_ntt_max_batch(lay.k) &&
+                  (c->opt_quotient_domain == 2 || (c->opt_quotient_domain == 0 && lay.k >= 16));
+        if (cosets3 && !pk->is_member && (rc = pk_ensure_cosets3(c, pk))) return rc;
         omega = fr_omega(lay.k);
         omega_inv = fe_inv_fast(omega);
         tr->common_scalar(pk->transcript_repr);

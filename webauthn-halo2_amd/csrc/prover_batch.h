@@ -137,6 +137,10 @@ struct BatchRun {
         const uint32_t bf = BLINDING_FACTORS, usable = lay.usable, T = 1u << lay.lookup_bits;
         for (Prover* p : P)
             if (p->begin()) return p->rc;
+        // the three-coset route (poly.hip): every proof's begin() took the same decision; the members read the key's coset-major
+        // copies through their own records
+        const bool c3 = P[0]->cosets3;
+        if (c3 && (rc = pk_ensure_cosets3(c, pk0))) return rc;
 
         // -- 1. advice
         const bool many = lay.n_adv > BATCH_ARGS_MIN;
@@ -454,9 +458,13 @@ struct BatchRun {
                 qc.lk_s.push_back(pk->lk_sp_coset[l]);
                 qc.lk_z.push_back(pk->lk_z_coset[l]);
             }
+            qc.cosets3 = c3;
             if (int r = pk_quotient(c, pk, qc, beta[q], gamma[q], y[q], true, pk->h_ext)) return r;
         }
-        {
+        if (c3) {
+            for (uint32_t q = 0; q < B; q++)
+                if (int r = ctx_intt_cosets3(c, P[q]->pk->h_ext, lay.k)) return r;
+        } else {
             const uint32_t b2 = ctx_ntt_max_batch(lay.ext_k);
             const Fr* src[NTT_MAX_BATCH];
             Fr* dst[NTT_MAX_BATCH];

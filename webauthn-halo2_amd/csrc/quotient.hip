@@ -48,11 +48,16 @@ __device__ __forceinline__ void q_acc(Fr29& sum, uint32_t& cnt, const Fr29& term
 // One row's share of the y-combination: slice `sl` of `ns` takes the gates, permutation chunks and lookups whose index is
 // sl mod ns (every group sum is linear in its terms, so the slices' results simply add up).  Returns
 // acc + l_0 s0 + l_last sl + l_active sa of the share: (<= 108 ; normalised).  SLICED = false is the whole row (sl = 0, ns = 1).
-template <bool SLICED>
+// C3: the row index is coset-major over three cosets (poly.hip "three cosets"): i = j n + r is the point zeta w_ext^(4 r + j), a
+// rotation moves r inside the coset, and the coset points are read from the 4n table with a stride.
+template <bool SLICED, bool C3 = false>
 __device__ __forceinline__ Fr29 quotient_row(const QuotientArgs& a, uint32_t i, uint32_t sl, uint32_t ns) {
     const uint32_t N = 1u << a.log_ext;
     const uint32_t mask = N - 1;
-    auto rot = [&](int r) { return (i + (uint32_t)(r * 4)) & mask; };  // two's complement wraps correctly mod N
+    const uint32_t nmask = (N >> 2) - 1, cbase = i & ~nmask;  // (C3) the row's coset
+    auto rot = [&](int r) {  // two's complement wraps correctly mod N / mod n
+        return C3 ? (cbase | ((i + (uint32_t)r) & nmask)) : ((i + (uint32_t)(r * 4)) & mask);
+    };
 
     const Fr29 beta = to29(a.beta), gamma = to29(a.gamma);  // (1 ; 29): the host passes 32 x the challenge (internal form)
     const Fr29 one = const_pow2_29<261, FrParams>();
@@ -98,7 +103,7 @@ __device__ __forceinline__ Fr29 quotient_row(const QuotientArgs& a, uint32_t i, 
         }
         // beta * x with x = zeta * w_ext^i (resident vector), then times delta per column
         const Fr29 delta = to29(a.delta);
-        const Fr29 bx0 = mul29(q_load(a.xs + i), beta);      // (2 ; 29)
+        const Fr29 bx0 = mul29(q_load(a.xs + (C3 ? 4 * (i & nmask) + (i >> (a.log_ext - 2)) : i)), beta);      // (2 ; 29)
         Fr29 bx = bx0;
         for (uint32_t c = sl; c < a.n_chunks; c += ns) {
             Fr29 left = q_load(a.z[c] + rot(1));             // (32 ; 29), then <= (8 ; 29)
@@ -146,14 +151,15 @@ __device__ __forceinline__ Fr29 quotient_row(const QuotientArgs& a, uint32_t i, 
     return norm29(add29(add29(acc, t0), add29(t1, t2)));  // 66 + 3 * 14 = 108 <= 168
 }
 
+template <bool C3>
 __global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __restrict__ ap) {
     const QuotientArgs& a = *ap;
     const uint32_t N = 1u << a.log_ext;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const Fr29 total = quotient_row<false>(a, i, 0, 1);
+    if (i >= (C3 ? 3 * (N >> 2) : N)) return;
+    const Fr29 total = quotient_row<false, C3>(a, i, 0, 1);
     // times 1/(X^n - 1) (or 1) in the standard form: the product is the standard form of the result, < 2p
-    Fr r = from29(mul29(total, to29(a.t_inv[i & 3])));
+    Fr r = from29(mul29(total, to29(a.t_inv[C3 ? i >> (a.log_ext - 2) : i & 3])));
     reduce_once(r);
     fe_store(a.out + i, r);
 }
@@ -161,13 +167,14 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotientArgs* __res
 // The many-column shapes (k <= 14: hundreds of gates and lookups over a few thousand rows) have too few rows to fill the chip
 // with one lane per row: 2^log_ns lanes share a row, each takes every 2^log_ns-th gate / chunk / lookup, and the shares are
 // added through LDS (each first brought below 2p by a product with "one").  Lanes of a workgroup: row-major within a slice.
+template <bool C3>
 __global__ __launch_bounds__(256) void quotient_sliced_kernel(const QuotientArgs* __restrict__ ap, uint32_t log_ns) {
     __shared__ uint32_t part[256 * 9];
     const QuotientArgs& a = *ap;
     const uint32_t ns = 1u << log_ns, rows = 256u >> log_ns;
     const uint32_t row = threadIdx.x & (rows - 1), sl = threadIdx.x >> (8 - log_ns);
-    const uint32_t i = blockIdx.x * rows + row;  // N is a multiple of 256: no partial workgroups
-    const Fr29 share = mul29(quotient_row<true>(a, i, sl, ns), const_pow2_29<261, FrParams>());  // (2 ; 29)
+    const uint32_t i = blockIdx.x * rows + row;  // N (and 3 N / 4) is a multiple of 256: no partial workgroups
+    const Fr29 share = mul29(quotient_row<true, C3>(a, i, sl, ns), const_pow2_29<261, FrParams>());  // (2 ; 29)
 #pragma unroll
     for (int l = 0; l < 9; l++) part[l * 256 + threadIdx.x] = share.l[l];
     __syncthreads();
@@ -179,19 +186,22 @@ __global__ __launch_bounds__(256) void quotient_sliced_kernel(const QuotientArgs
         for (int l = 0; l < 9; l++) v.l[l] = part[l * 256 + s * rows + row];
         total = norm29(add29(total, v));  // <= 2 * 16 p
     }
-    Fr r = from29(mul29(total, to29(a.t_inv[i & 3])));
+    Fr r = from29(mul29(total, to29(a.t_inv[C3 ? i >> (a.log_ext - 2) : i & 3])));
     reduce_once(r);
     fe_store(a.out + i, r);
 }
 
 // `d_args` is the argument block in device memory (too large for a kernarg segment)
 // `log_slices`: lanes per row (quotient_log_slices); 0 = one lane per row
-void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, uint32_t log_slices, hipStream_t st) {
-    const uint32_t N = 1u << log_ext;
-    if (log_slices == 0 || N < 256) {
-        hipLaunchKernelGGL(quotient_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d_args);
+// `cosets3`: the rows are the [3][n] coset-major rows of the three-coset route (every operand in that layout; 3 n rows)
+void launch_quotient_dev(const QuotientArgs* d_args, uint32_t log_ext, uint32_t log_slices, hipStream_t st, bool cosets3) {
+    const uint32_t N = cosets3 ? 3u << (log_ext - 2) : 1u << log_ext;
+    if (log_slices == 0 || N < 256 || (N & 255)) {
+        if (cosets3) hipLaunchKernelGGL(quotient_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, st, d_args);
+        else hipLaunchKernelGGL(quotient_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, st, d_args);
     } else {
-        hipLaunchKernelGGL(quotient_sliced_kernel, dim3(N >> (8 - log_slices)), dim3(256), 0, st, d_args, log_slices);
+        if (cosets3) hipLaunchKernelGGL(quotient_sliced_kernel<true>, dim3(N >> (8 - log_slices)), dim3(256), 0, st, d_args, log_slices);
+        else hipLaunchKernelGGL(quotient_sliced_kernel<false>, dim3(N >> (8 - log_slices)), dim3(256), 0, st, d_args, log_slices);
     }
 }
 
