@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from webauthn_halo2_amd import batch, circuit, engine as E  # noqa: E402
 
 p = circuit.K17
+if os.environ.get("ROW"):  # another bench_ecdsa.config row: ROW=18,2,1,1,17 (degree, advice, lookup advice, fixed, lookup bits)
+    v = [int(x) for x in os.environ["ROW"].split(",")]
+    p = circuit.CircuitParams(degree=v[0], num_advice=v[1], num_lookup_advice=v[2], num_fixed=v[3], lookup_bits=v[4])
 jobs = list(range(8))
 wit = batch.synthesize_jobs(p, jobs)
 fixed, copies = batch.structure(p)
@@ -53,6 +56,6 @@ for spec in (sys.argv[1:] or ["1", "2", "3", "4"]):
     [t.start() for t in ths]
     [t.join() for t in ths]
     dt = time.perf_counter() - t0
-    print(f"k=17 EVM OPTS={os.environ.get('OPTS', '-')}, {npipe} pipelines x lock-step {ls}: {npipe * reps / dt:6.1f} proofs/s ({dt / reps * 1e3:.2f} ms per proof and pipeline)", flush=True)
+    print(f"k={p.degree} EVM OPTS={os.environ.get('OPTS', '-')}, {npipe} pipelines x lock-step {ls}: {npipe * reps / dt:6.1f} proofs/s ({dt / reps * 1e3:.2f} ms per proof and pipeline)", flush=True)
     for pl in pipes[::-1]:
         pl.close()
