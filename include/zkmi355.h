@@ -135,6 +135,10 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
                                         whole extended domain (round 5's route), 2 = three cosets wherever h has three pieces.
                                         zk_prove_batch follows the same rule; the phase-level entry points (zk_coeff_to_extended, zk_quotient,
                                         zk_extended_to_coeff) always work on the whole domain in halo2's order */
+#define ZK_OPT_ACTIVITY_HOLD 14      /* how a context inside zk_prove / zk_prove_batch counts for the automatic stream rules of the OTHER contexts
+                                        of its device (ZK_OPT_MSM_TAIL_STREAM, ZK_OPT_XFORM_STREAM): 0 (default) active for the whole call — its
+                                        quotient / evaluation / multi-open phases enqueue no MSM pass for longer than the 4 ms window under load,
+                                        and the count dipped to two or three several times per proof; 1 = by its stamps alone (round 5's rule) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

@@ -35,11 +35,19 @@ factory.configure = configure  # (batch.Pipeline: the options also reach the pip
 for spec in (sys.argv[1:] or ["1", "2", "3", "4"]):
     npipe, ls = (int(x) for x in (spec.split("x") + ["1"])[:2])
     pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True)]
+    inter = bool(os.environ.get("INTERLEAVE"))  # a lone proof on every pipeline BEFORE the next one is created (side streams made early)
+    if inter:
+        pipes[0].load(0, wit[0])
+        pipes[0].prove(0, E.ZK_TRANSCRIPT_EVM, keep=True)
     for _ in range(npipe - 1):
         pipes.append(batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True, share_srs_with=pipes[0]))
+        if inter:
+            pipes[-1].load(0, wit[0])
+            pipes[-1].prove(0, E.ZK_TRANSCRIPT_EVM, keep=True)
     for pl in pipes:
         for j in jobs:
-            pl.load(j, wit[j])
+            if not (inter and j == 0):
+                pl.load(j, wit[j])
         pl.prove(0, E.ZK_TRANSCRIPT_EVM, keep=True)
     reps = 64
 

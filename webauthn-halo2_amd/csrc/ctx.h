@@ -39,6 +39,7 @@ struct SrsBlock {
 struct zk_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    bool stream_own_priority = false;  // made by ZK_OPT_STREAM_PRIORITY: destroyed with the context, not parked (engine.hip stream pool)
     int last_hip = 0;
     StreamAudit audit;  // ZK_OPT_STREAM_AUDIT (audit.h): the happens-before ledger of this context's streams, off by default
     bool audit_fault = false;  // ZK_OPT_STREAM_AUDIT = 2: the audit's self-test (the prover takes a knowingly unordered path)
@@ -71,6 +72,8 @@ struct zk_ctx {
     uint32_t opt_tail_main_above = 0;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE: auto mode puts the tails on the main stream with MORE than this many contexts active on the device (0 = the measured default, 2)
     uint32_t opt_batch_pass_cols = 0;  // ZK_OPT_BATCH_PASS_COLUMNS: columns per MSM pass of a lock-step batch (0 = max(min(2 B, 8), the single prover's pass width))
     uint32_t msm_min_cols = 0;         // the lanes' fixed-base workspaces take at least this many columns per pass (raised by zk_prove_batch, never lowered: the wider workspaces are kept)
+    uint32_t opt_no_activity_hold = 0;  // ZK_OPT_ACTIVITY_HOLD
+    bool act_held = false;         // inside a whole-proof call: the slot counts as active whatever its last stamp (ctx_activity_hold)
     int act_slot = -1;             // this context's slot in its device's activity table (engine.hip ctx_activity_*)
     // The context's TAIL stream (round 4: one, shared by the lanes; rounds 2-3 had one per lane).  Where a pass's reduction tail
     // runs is decided per pass (ctx_msm_begin_batch): on this stream while at most two contexts are ACTIVE on the device (have
@@ -202,6 +205,7 @@ int ctx_bind(zk_ctx* c);
 void ctx_activity_register(zk_ctx* c);
 void ctx_activity_unregister(zk_ctx* c);
 int ctx_activity_touch(zk_ctx* c);
+void ctx_activity_hold(zk_ctx* c, bool on);
 int ctx_lone_streams(zk_ctx* c);  // creates the transform / MSM streams of a lone proof on first use
 void ctx_release_spares(zk_ctx* c);  // frees the vectors zk_poly_free parked (caller holds c->mu, device bound)
 int ctx_ensure_scratch(zk_ctx* c, size_t n);

@@ -201,10 +201,62 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     return ZK_OK;
 }
 
+// ---- streams are kept, not destroyed (round 6).  The HIP runtime ties a stream to one of its (four) hardware queues when the stream
+// is made, from the state of its queue pool at that moment; a process that has destroyed streams gets a worse assignment for the
+// ones it makes next (measured, tools/inflight_k17.py 4 4: the same four pipelines 228 proofs/s when they are the process's first,
+// 190 when a set of contexts was destroyed before them — main streams end up sharing queues).  zk_ctx_destroy therefore parks a
+// context's streams (drained) in a per-device pool, main streams and side streams apart, and zk_ctx_create takes from it: a
+// context made after another was destroyed inherits a stream that already had a queue to itself.  (Never freed: a handful of
+// idle streams per device for the life of the process.  A stream made at a priority of its own — ZK_OPT_STREAM_PRIORITY — is
+// destroyed as before.)
+namespace {
+struct StreamPool {
+    std::mutex mu;
+    std::map<int, std::vector<hipStream_t>> main, side;
+    std::map<int, bool> primed;
+};
+StreamPool& stream_pool() {
+    static StreamPool* p = new StreamPool();  // (leaked on purpose: the HIP runtime may be gone before static destructors run)
+    return *p;
+}
+hipStream_t pool_take(int device, bool main_stream) {
+    StreamPool& p = stream_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (main_stream && !p.primed[device]) {
+        // the first context of a device: the main streams of its first four contexts (one per hardware queue of the runtime's
+        // default) are all made NOW, before any side stream exists, so that they get a queue each whatever the host does between
+        // its zk_ctx_create calls (a lone proof on the first context makes three side streams)
+        p.primed[device] = true;
+        for (int i = 0; i < 4; i++) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreate(&s) == hipSuccess) p.main[device].push_back(s);
+        }
+    }
+    auto& v = (main_stream ? p.main : p.side)[device];
+    if (v.empty()) return nullptr;
+    hipStream_t s = v.front();  // first in, first out: the oldest streams are the ones made while the queue pool was fresh
+    v.erase(v.begin());
+    return s;
+}
+void pool_park(int device, bool main_stream, hipStream_t s) {
+    if (!s) return;
+    hipStreamSynchronize(s);
+    StreamPool& p = stream_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    (main_stream ? p.main : p.side)[device].push_back(s);
+}
+}  // namespace
+int ctx_side_stream(zk_ctx* c, hipStream_t* out) {
+    if (*out) return ZK_OK;
+    hipStream_t s = pool_take(c->device, false);
+    if (!s && hipStreamCreate(&s) != hipSuccess) return ZK_EHIP;
+    *out = s;
+    return ZK_OK;
+}
+
 // the two further streams a LONE proof spreads over (ctx.h xform_stream, msm_stream), made when the first such proof asks
 int ctx_lone_streams(zk_ctx* c) {
-    if (!c->xform_stream && hipStreamCreate(&c->xform_stream) != hipSuccess) return ZK_EHIP;
-    if (!c->msm_stream && hipStreamCreate(&c->msm_stream) != hipSuccess) return ZK_EHIP;
+    if (ctx_side_stream(c, &c->xform_stream) || ctx_side_stream(c, &c->msm_stream)) return ZK_EHIP;
     return ZK_OK;
 }
 
@@ -216,6 +268,11 @@ int ctx_lone_streams(zk_ctx* c) {
 namespace {
 constexpr int ACT_DEVICES = 64, ACT_SLOTS = 64;
 constexpr int64_t ACT_WINDOW_NS = 4 * 1000 * 1000;  // a proving context enqueues a pass every 0.3 .. 1.5 ms
+// ... but not during its quotient / evaluation / multi-open phases, which under four pipelines last longer than the window: a
+// context inside a whole-proof call (zk_prove, zk_prove_batch) holds its slot "active" for the length of the call
+// (ctx_activity_hold), or the count would dip to two or three several times per proof and passes of the OTHER contexts would take
+// the side-stream regime under full load
+constexpr int64_t ACT_HELD = INT64_MAX;
 std::atomic<int64_t> g_act_ts[ACT_DEVICES][ACT_SLOTS];
 std::atomic<uint64_t> g_act_used[ACT_DEVICES];
 int64_t act_now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -245,16 +302,23 @@ void ctx_activity_unregister(zk_ctx* c) {
 int ctx_activity_touch(zk_ctx* c) {
     if (c->device < 0 || c->device >= ACT_DEVICES) return 1;
     const int64_t now = act_now();
-    if (c->act_slot >= 0) g_act_ts[c->device][c->act_slot].store(now);
+    if (c->act_slot >= 0 && !c->act_held) g_act_ts[c->device][c->act_slot].store(now);
     int active = c->act_slot >= 0 ? 0 : 1;
     uint64_t used = g_act_used[c->device].load();
     while (used) {
         const int slot = __builtin_ctzll(used);
         used &= used - 1;
         const int64_t ts = g_act_ts[c->device][slot].load();
-        if (ts && now - ts < ACT_WINDOW_NS) active++;
+        if (ts && (ts == ACT_HELD || now - ts < ACT_WINDOW_NS)) active++;
     }
     return active;
+}
+// a whole-proof call begins / ends on this context (prover.hip ProveQuiesce)
+void ctx_activity_hold(zk_ctx* c, bool on) {
+    if (on && c->opt_no_activity_hold) return;  // ZK_OPT_ACTIVITY_HOLD = 1: round 5's rule (stamps only)
+    c->act_held = on;
+    if (c->act_slot < 0 || c->device < 0 || c->device >= ACT_DEVICES) return;
+    g_act_ts[c->device][c->act_slot].store(on ? ACT_HELD : act_now());
 }
 
 int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_t batch, const G1Affine* d_bases, size_t n) {
@@ -282,7 +346,7 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     const int active = ctx_activity_touch(c);
     const uint32_t above = c->opt_tail_main_above ? c->opt_tail_main_above : 2u;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE; measured default (ctx.h)
     const bool tail_on_main = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && (uint32_t)active > above);
-    if ((!tail_on_main || c->msm_side) && !c->tail_stream) HIPCHK(c, hipStreamCreate(&c->tail_stream));  // made on first use (see zk_ctx_create)
+    if ((!tail_on_main || c->msm_side) && !c->tail_stream && ctx_side_stream(c, &c->tail_stream)) return ZK_EHIP;  // made on first use (see zk_ctx_create)
     L.tail = tail_on_main ? c->stream : c->tail_stream;
     if (L.tail == c->stream) c->acc_n[ZK_T_MSM_TAIL_MAIN]++;
     hipStream_t hs = c->stream;  // where the pass's head and accumulation run
@@ -452,7 +516,7 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
     zk_ctx* c = new (std::nothrow) zk_ctx();
     if (!c) return ZK_ENOMEM;
     c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+    if (hipSetDevice(device_id) != hipSuccess || ((c->stream = pool_take(device_id, true)) == nullptr && hipStreamCreate(&c->stream) != hipSuccess) ||
         hipHostMalloc(&c->host_small, 8 * sizeof(Fr)) != hipSuccess ||
         hipMalloc(&c->small, (2048 + 8) * sizeof(Fr)) != hipSuccess) {
         zk_ctx_destroy(c);
@@ -567,12 +631,15 @@ void zk_ctx_destroy(zk_ctx* c) {
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) hipEventDestroy(c->ev[i][j]);
     if (c->ev_msm_in) hipEventDestroy(c->ev_msm_in);
-    if (c->msm_stream) hipStreamDestroy(c->msm_stream);
+    pool_park(c->device, false, c->msm_stream);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     if (c->ev_xform) hipEventDestroy(c->ev_xform);
-    if (c->xform_stream) hipStreamDestroy(c->xform_stream);
-    if (c->tail_stream) hipStreamDestroy(c->tail_stream);
-    if (c->stream) hipStreamDestroy(c->stream);
+    pool_park(c->device, false, c->xform_stream);
+    pool_park(c->device, false, c->tail_stream);
+    if (c->stream) {
+        if (c->stream_own_priority) hipStreamDestroy(c->stream);
+        else pool_park(c->device, true, c->stream);
+    }
     delete c;
 }
 
@@ -726,6 +793,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
         case ZK_OPT_GP_BATCH_INVERT:
             c->opt_gp_batch_invert = value ? 1 : 0;
             return ZK_OK;
+        case ZK_OPT_ACTIVITY_HOLD:
+            if (value > 1) return ZK_EINVAL;
+            c->opt_no_activity_hold = (uint32_t)value;
+            return ZK_OK;
         case ZK_OPT_QUOTIENT_DOMAIN:
             if (value > 2) return ZK_EINVAL;
             c->opt_quotient_domain = (uint32_t)value;
@@ -747,8 +818,10 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
             hipStreamSynchronize(c->stream);
             for (int i = 0; i < zk_ctx::MSM_LANES; i++)
                 if (c->lanes[i].tail == c->stream) c->lanes[i].tail = ns;
-            hipStreamDestroy(c->stream);
+            if (c->stream_own_priority) hipStreamDestroy(c->stream);
+            else pool_park(c->device, true, c->stream);
             c->stream = ns;
+            c->stream_own_priority = true;
             c->audit.streams[0] = ns;
             return ZK_OK;
         }

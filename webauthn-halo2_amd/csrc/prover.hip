@@ -1843,7 +1843,7 @@ struct Prover {
 namespace {
 struct ProveQuiesce {
     zk_ctx* c;
-    explicit ProveQuiesce(zk_ctx* ctx) : c(ctx) {}
+    explicit ProveQuiesce(zk_ctx* ctx) : c(ctx) { ctx_activity_hold(c, true); }
     ProveQuiesce(const ProveQuiesce&) = delete;
     ProveQuiesce& operator=(const ProveQuiesce&) = delete;
     void settle() {
@@ -1857,6 +1857,7 @@ struct ProveQuiesce {
             c->xform_pending = false;
         }
         aud_sync(c, c->stream);
+        ctx_activity_hold(c, false);
     }
     ~ProveQuiesce() { settle(); }
 };

@@ -22,7 +22,7 @@ ZK_TRANSCRIPT_BLAKE2B, ZK_TRANSCRIPT_EVM = 0, 1
 ZK_SERDE_PROCESSED, ZK_SERDE_RAW_BYTES, ZK_SERDE_RAW_BYTES_UNCHECKED = 0, 1, 2
 ZK_OPT_MSM_WINDOW, ZK_OPT_MSM_BATCH, ZK_OPT_NTT_MAX_RADIX_LOG2, ZK_OPT_GP_BATCH_INVERT, ZK_OPT_MSM_TAIL_STREAM = 1, 2, 3, 4, 5
 ZK_OPT_MSM_TAIL_MAIN_ABOVE, ZK_OPT_BATCH_PASS_COLUMNS, ZK_OPT_XFORM_STREAM, ZK_OPT_MSM_STREAM, ZK_OPT_MSM_T1, ZK_OPT_STREAM_AUDIT = 6, 7, 8, 9, 10, 11
-ZK_OPT_STREAM_PRIORITY, ZK_OPT_QUOTIENT_DOMAIN = 12, 13
+ZK_OPT_STREAM_PRIORITY, ZK_OPT_QUOTIENT_DOMAIN, ZK_OPT_ACTIVITY_HOLD = 12, 13, 14
 ZK_SCHEME_DEFAULT, ZK_SCHEME_GWC, ZK_SCHEME_SHPLONK = 0, 1, 2
 
 
