@@ -39,7 +39,8 @@ struct SrsBlock {
 struct zk_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    bool stream_own_priority = false;  // made by ZK_OPT_STREAM_PRIORITY: destroyed with the context, not parked (engine.hip stream pool)
+    int stream_slot = -1;              // the context's slot in its device's stream pool (engine.hip): main and side streams are the slot's; -1: its own
+    bool stream_own_priority = false;  // the main stream was made by ZK_OPT_STREAM_PRIORITY: the context's own, destroyed with it
     int last_hip = 0;
     StreamAudit audit;  // ZK_OPT_STREAM_AUDIT (audit.h): the happens-before ledger of this context's streams, off by default
     bool audit_fault = false;  // ZK_OPT_STREAM_AUDIT = 2: the audit's self-test (the prover takes a knowingly unordered path)

@@ -201,62 +201,86 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
     return ZK_OK;
 }
 
-// ---- streams are kept, not destroyed (round 6).  The HIP runtime ties a stream to one of its (four) hardware queues when the stream
-// is made, from the state of its queue pool at that moment; a process that has destroyed streams gets a worse assignment for the
-// ones it makes next (measured, tools/inflight_k17.py 4 4: the same four pipelines 228 proofs/s when they are the process's first,
-// 190 when a set of contexts was destroyed before them — main streams end up sharing queues).  zk_ctx_destroy therefore parks a
-// context's streams (drained) in a per-device pool, main streams and side streams apart, and zk_ctx_create takes from it: a
-// context made after another was destroyed inherits a stream that already had a queue to itself.  (Never freed: a handful of
-// idle streams per device for the life of the process.  A stream made at a priority of its own — ZK_OPT_STREAM_PRIORITY — is
-// destroyed as before.)
+// ---- streams are kept, not destroyed, and made in a deliberate order (round 6).  The HIP runtime ties a stream to one of its
+// (four) hardware queues when the stream is made: the first four streams of a process get a queue each, every later one the queue
+// with the fewest streams on it (ties: the highest queue) — read off rocprofv3's Queue_Id with tools/queue_map.py.  Streams that
+// share a queue run in order, so WHICH streams share matters: a process that had destroyed a set of contexts got 190 instead of 228
+// proofs/s from its next four pipelines (k = 17, tools/inflight_k17.py 4 4: main streams sharing queues), and a context whose lone
+// proof finds its tail and its transform stream on one queue takes 12.0 instead of 11.1 ms (k = 19).  So the first context of a
+// device makes, in this order, the MAIN streams of the device's first four contexts (queues 0 .. 3) and then four blocks of four
+// side streams (each block: queues 3, 2, 1, 0).  Context slot i owns main stream i and, from block i, the side streams that do
+// not sit on its main's queue: its tail stream on queue 3 - i (so that the tails of the first two pipelines do not meet either),
+// its transform and MSM streams on the other two.  zk_ctx_destroy drains the slot's streams and frees the slot for the next
+// context; contexts beyond four slots (and a main stream made at its own priority, ZK_OPT_STREAM_PRIORITY) make their streams as
+// before and destroy them.  The pool is never freed (20 idle streams per device for the life of the process).  If another runtime
+// assigns queues differently nothing breaks: this is placement, not correctness.
 namespace {
+struct StreamSlots {
+    bool primed = false;
+    hipStream_t main[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[4][4] = {};  // [slot][j]: block `slot`, j-th made: queue 3 - j
+    bool used[4] = {false, false, false, false};
+};
 struct StreamPool {
     std::mutex mu;
-    std::map<int, std::vector<hipStream_t>> main, side;
-    std::map<int, bool> primed;
+    std::map<int, StreamSlots> dev;
 };
 StreamPool& stream_pool() {
     static StreamPool* p = new StreamPool();  // (leaked on purpose: the HIP runtime may be gone before static destructors run)
     return *p;
 }
-hipStream_t pool_take(int device, bool main_stream) {
+}  // namespace
+// a free slot of the device (current device = `device`), or -1: the caller makes its own streams
+static int pool_take_slot(int device, hipStream_t* main_out) {
     StreamPool& p = stream_pool();
     std::lock_guard<std::mutex> lk(p.mu);
-    if (main_stream && !p.primed[device]) {
-        // the first context of a device: the main streams of its first four contexts (one per hardware queue of the runtime's
-        // default) are all made NOW, before any side stream exists, so that they get a queue each whatever the host does between
-        // its zk_ctx_create calls (a lone proof on the first context makes three side streams)
-        p.primed[device] = true;
-        for (int i = 0; i < 4; i++) {
-            hipStream_t s = nullptr;
-            if (hipStreamCreate(&s) == hipSuccess) p.main[device].push_back(s);
+    StreamSlots& d = p.dev[device];
+    if (!d.primed) {
+        d.primed = true;
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreate(&d.main[i]) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++)
+            for (int j = 0; j < 4 && ok; j++) ok = hipStreamCreate(&d.side[i][j]) == hipSuccess;
+        if (!ok) {  // (out of resources: no slots on this device, contexts make their own streams)
+            for (int i = 0; i < 4; i++) d.used[i] = true;
         }
     }
-    auto& v = (main_stream ? p.main : p.side)[device];
-    if (v.empty()) return nullptr;
-    hipStream_t s = v.front();  // first in, first out: the oldest streams are the ones made while the queue pool was fresh
-    v.erase(v.begin());
-    return s;
+    for (int i = 0; i < 4; i++)
+        if (!d.used[i]) {
+            d.used[i] = true;
+            *main_out = d.main[i];
+            return i;
+        }
+    return -1;
 }
-void pool_park(int device, bool main_stream, hipStream_t s) {
-    if (!s) return;
-    hipStreamSynchronize(s);
+static void pool_release_slot(int device, int slot) {
     StreamPool& p = stream_pool();
     std::lock_guard<std::mutex> lk(p.mu);
-    (main_stream ? p.main : p.side)[device].push_back(s);
+    StreamSlots& d = p.dev[device];
+    hipStreamSynchronize(d.main[slot]);
+    for (int j = 0; j < 4; j++) hipStreamSynchronize(d.side[slot][j]);
+    d.used[slot] = false;
 }
-}  // namespace
-int ctx_side_stream(zk_ctx* c, hipStream_t* out) {
+// role: 0 the tail stream, 1 the transform stream, 2 the MSM stream
+int ctx_side_stream(zk_ctx* c, hipStream_t* out, int role) {
     if (*out) return ZK_OK;
-    hipStream_t s = pool_take(c->device, false);
-    if (!s && hipStreamCreate(&s) != hipSuccess) return ZK_EHIP;
-    *out = s;
-    return ZK_OK;
+    if (c->stream_slot >= 0) {
+        const int i = c->stream_slot;
+        int js[3], m = 0;
+        js[m++] = i;  // queue 3 - i: never the main's queue i
+        for (int j = 0; j < 4; j++)
+            if (j != i && j != 3 - i) js[m++] = j;  // (j = 3 - i sits on the main's queue: the block's spare)
+        StreamPool& p = stream_pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        *out = p.dev[c->device].side[i][js[role]];
+        return ZK_OK;
+    }
+    return hipStreamCreate(out) == hipSuccess ? ZK_OK : ZK_EHIP;
 }
 
 // the two further streams a LONE proof spreads over (ctx.h xform_stream, msm_stream), made when the first such proof asks
 int ctx_lone_streams(zk_ctx* c) {
-    if (ctx_side_stream(c, &c->xform_stream) || ctx_side_stream(c, &c->msm_stream)) return ZK_EHIP;
+    if (ctx_side_stream(c, &c->xform_stream, 1) || ctx_side_stream(c, &c->msm_stream, 2)) return ZK_EHIP;
     return ZK_OK;
 }
 
@@ -346,7 +370,7 @@ int ctx_msm_begin_batch(zk_ctx* c, int lane, const Fr* const* d_scalars, uint32_
     const int active = ctx_activity_touch(c);
     const uint32_t above = c->opt_tail_main_above ? c->opt_tail_main_above : 2u;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE; measured default (ctx.h)
     const bool tail_on_main = c->opt_tail_stream == 2 || (c->opt_tail_stream == 0 && (uint32_t)active > above);
-    if ((!tail_on_main || c->msm_side) && !c->tail_stream && ctx_side_stream(c, &c->tail_stream)) return ZK_EHIP;  // made on first use (see zk_ctx_create)
+    if ((!tail_on_main || c->msm_side) && !c->tail_stream && ctx_side_stream(c, &c->tail_stream, 0)) return ZK_EHIP;  // made on first use (see zk_ctx_create)
     L.tail = tail_on_main ? c->stream : c->tail_stream;
     if (L.tail == c->stream) c->acc_n[ZK_T_MSM_TAIL_MAIN]++;
     hipStream_t hs = c->stream;  // where the pass's head and accumulation run
@@ -516,7 +540,8 @@ ZK_API(zk_ctx_create, (int device_id, zk_ctx** out), (device_id, out)) {
     zk_ctx* c = new (std::nothrow) zk_ctx();
     if (!c) return ZK_ENOMEM;
     c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || ((c->stream = pool_take(device_id, true)) == nullptr && hipStreamCreate(&c->stream) != hipSuccess) ||
+    if (hipSetDevice(device_id) != hipSuccess ||
+        ((c->stream_slot = pool_take_slot(device_id, &c->stream)) < 0 && hipStreamCreate(&c->stream) != hipSuccess) ||
         hipHostMalloc(&c->host_small, 8 * sizeof(Fr)) != hipSuccess ||
         hipMalloc(&c->small, (2048 + 8) * sizeof(Fr)) != hipSuccess) {
         zk_ctx_destroy(c);
@@ -631,14 +656,17 @@ void zk_ctx_destroy(zk_ctx* c) {
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) hipEventDestroy(c->ev[i][j]);
     if (c->ev_msm_in) hipEventDestroy(c->ev_msm_in);
-    pool_park(c->device, false, c->msm_stream);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     if (c->ev_xform) hipEventDestroy(c->ev_xform);
-    pool_park(c->device, false, c->xform_stream);
-    pool_park(c->device, false, c->tail_stream);
-    if (c->stream) {
-        if (c->stream_own_priority) hipStreamDestroy(c->stream);
-        else pool_park(c->device, true, c->stream);
+    if (c->stream_slot >= 0) {
+        // the slot's streams stay (engine.hip stream pool); a main stream made at its own priority is the context's own
+        if (c->stream_own_priority && c->stream) hipStreamDestroy(c->stream);
+        pool_release_slot(c->device, c->stream_slot);
+    } else {
+        if (c->msm_stream) hipStreamDestroy(c->msm_stream);
+        if (c->xform_stream) hipStreamDestroy(c->xform_stream);
+        if (c->tail_stream) hipStreamDestroy(c->tail_stream);
+        if (c->stream) hipStreamDestroy(c->stream);
     }
     delete c;
 }
@@ -818,8 +846,7 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
             hipStreamSynchronize(c->stream);
             for (int i = 0; i < zk_ctx::MSM_LANES; i++)
                 if (c->lanes[i].tail == c->stream) c->lanes[i].tail = ns;
-            if (c->stream_own_priority) hipStreamDestroy(c->stream);
-            else pool_park(c->device, true, c->stream);
+            if (c->stream_own_priority || c->stream_slot < 0) hipStreamDestroy(c->stream);  // (a slot's main stream stays in its slot)
             c->stream = ns;
             c->stream_own_priority = true;
             c->audit.streams[0] = ns;
