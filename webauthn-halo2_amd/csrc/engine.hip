@@ -208,18 +208,19 @@ static int get_msm_ws(zk_ctx* c, int lane, size_t n, uint32_t table_window, MsmW
 // proofs/s from its next four pipelines (k = 17, tools/inflight_k17.py 4 4: main streams sharing queues), and a context whose lone
 // proof finds its tail and its transform stream on one queue takes 12.0 instead of 11.1 ms (k = 19).  So the first context of a
 // device makes, in this order, the MAIN streams of the device's first four contexts (queues 0 .. 3) and then four blocks of four
-// side streams (each block: queues 3, 2, 1, 0).  Context slot i owns main stream i and, from block i, the side streams that do
+// side streams (each block: queues 3, 2, 1, 0) - and the same again for four more contexts (main streams on queues 3 .. 0).  Context slot i owns main stream i and, from block i, the side streams that do
 // not sit on its main's queue: its tail stream on queue 3 - i (so that the tails of the first two pipelines do not meet either),
 // its transform and MSM streams on the other two.  zk_ctx_destroy drains the slot's streams and frees the slot for the next
-// context; contexts beyond four slots (and a main stream made at its own priority, ZK_OPT_STREAM_PRIORITY) make their streams as
-// before and destroy them.  The pool is never freed (20 idle streams per device for the life of the process).  If another runtime
+// context; contexts beyond the eight slots (and a main stream made at its own priority, ZK_OPT_STREAM_PRIORITY) make their streams as
+// before and destroy them.  The pool is never freed (40 idle streams per device for the life of the process).  If another runtime
 // assigns queues differently nothing breaks: this is placement, not correctness.
 namespace {
+constexpr int POOL_SLOTS = 8;  // two layers of four: slots 4 .. 7 repeat the pattern (their main streams land on queues 3 .. 0)
 struct StreamSlots {
     bool primed = false;
-    hipStream_t main[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t side[4][4] = {};  // [slot][j]: block `slot`, j-th made: queue 3 - j
-    bool used[4] = {false, false, false, false};
+    hipStream_t main[POOL_SLOTS] = {};
+    hipStream_t side[POOL_SLOTS][4] = {};  // [slot][j]: block `slot`, j-th made: queue 3 - j
+    bool used[POOL_SLOTS] = {};
 };
 struct StreamPool {
     std::mutex mu;
@@ -229,6 +230,9 @@ StreamPool& stream_pool() {
     static StreamPool* p = new StreamPool();  // (leaked on purpose: the HIP runtime may be gone before static destructors run)
     return *p;
 }
+// the hardware queue of slot s's main stream under the runtime's rule (first four streams: a queue each; then the least loaded
+// queue, ties to the highest): layer 0 = queues 0 .. 3, layer 1 (made after layer 0's side blocks) = queues 3 .. 0
+constexpr int slot_main_queue(int s) { return s < 4 ? s : 7 - s; }
 }  // namespace
 // a free slot of the device (current device = `device`), or -1: the caller makes its own streams
 static int pool_take_slot(int device, hipStream_t* main_out) {
@@ -238,19 +242,26 @@ static int pool_take_slot(int device, hipStream_t* main_out) {
     if (!d.primed) {
         d.primed = true;
         bool ok = true;
-        for (int i = 0; i < 4 && ok; i++) ok = hipStreamCreate(&d.main[i]) == hipSuccess;
-        for (int i = 0; i < 4 && ok; i++)
-            for (int j = 0; j < 4 && ok; j++) ok = hipStreamCreate(&d.side[i][j]) == hipSuccess;
+        for (int layer = 0; layer < POOL_SLOTS / 4 && ok; layer++) {
+            for (int i = 4 * layer; i < 4 * layer + 4 && ok; i++) ok = hipStreamCreate(&d.main[i]) == hipSuccess;
+            for (int i = 4 * layer; i < 4 * layer + 4 && ok; i++)
+                for (int j = 0; j < 4 && ok; j++) ok = hipStreamCreate(&d.side[i][j]) == hipSuccess;
+        }
         if (!ok) {  // (out of resources: no slots on this device, contexts make their own streams)
-            for (int i = 0; i < 4; i++) d.used[i] = true;
+            for (int i = 0; i < POOL_SLOTS; i++) d.used[i] = true;
         }
     }
-    for (int i = 0; i < 4; i++)
+    // layer 1 is handed out from the top: slot 7's main stream shares queue 0 with slot 0's, so the fifth context doubles up with the
+    // FIRST one (the oldest, most likely idle: a set-up or probe context) rather than with the fourth
+    static const int order[POOL_SLOTS] = {0, 1, 2, 3, 7, 6, 5, 4};
+    for (int k = 0; k < POOL_SLOTS; k++) {
+        const int i = order[k];
         if (!d.used[i]) {
             d.used[i] = true;
             *main_out = d.main[i];
             return i;
         }
+    }
     return -1;
 }
 static void pool_release_slot(int device, int slot) {
@@ -265,11 +276,11 @@ static void pool_release_slot(int device, int slot) {
 int ctx_side_stream(zk_ctx* c, hipStream_t* out, int role) {
     if (*out) return ZK_OK;
     if (c->stream_slot >= 0) {
-        const int i = c->stream_slot;
+        const int i = c->stream_slot, mq = slot_main_queue(i);
         int js[3], m = 0;
-        js[m++] = i;  // queue 3 - i: never the main's queue i
+        js[m++] = mq;  // side j sits on queue 3 - j: the tail takes the queue opposite the main's (3 - mq, never mq itself)
         for (int j = 0; j < 4; j++)
-            if (j != i && j != 3 - i) js[m++] = j;  // (j = 3 - i sits on the main's queue: the block's spare)
+            if (j != mq && j != 3 - mq) js[m++] = j;  // (j = 3 - mq sits on the main's queue: the block's spare)
         StreamPool& p = stream_pool();
         std::lock_guard<std::mutex> lk(p.mu);
         *out = p.dev[c->device].side[i][js[role]];
