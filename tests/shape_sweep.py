@@ -92,6 +92,9 @@ def main():
     seed, count = int(sys.argv[1], 0), int(sys.argv[2])
     mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
     eng = t.zk.Engine(0)
+    for o in os.environ.get("OPTS", "").split(","):  # OPTS=13=2: zk_ctx_set_option (e.g. the three-coset quotient on every shape it applies to)
+        if o:
+            eng.set_option(*(int(x) for x in o.split("=")))
     bad = 0
     if len(sys.argv) > 3 and sys.argv[3] == "full":
         for shape in ((1, 1, 1, 19, 18, 0), (2, 1, 1, 18, 17, 0), (4, 1, 1, 17, 16, 0), (8, 2, 1, 16, 15, 0)):
