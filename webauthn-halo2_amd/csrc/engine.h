@@ -11,7 +11,7 @@
 namespace zk {
 
 // ---- NTT (ntt.hip) ---------------------------------------------------------
-static constexpr uint32_t NTT_MAX_BATCH = 32;  // vectors transformed by one launch (grid.y)
+static constexpr uint32_t NTT_MAX_BATCH = 96;  // vectors transformed by one launch (grid.y): 32 columns x the three cosets of poly.hip "three cosets"
 struct NttJob {
     const Fr* src;      // n_in elements (rest of the 2^log_n vector is zero)
     Fr* dst;            // 2^log_n elements (n_out stored)
