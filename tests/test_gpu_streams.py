@@ -157,3 +157,65 @@ def test_stream_priority_option_leaves_results_unchanged():
         base.set_option(E.ZK_OPT_STREAM_PRIORITY, 3)
     base.set_option(E.ZK_OPT_STREAM_PRIORITY, 1)  # on a context that has already worked: drained, then replaced
     assert np.array_equal(base.commit(base.poly(n, col), E.ZK_BASIS_LAGRANGE), want)
+
+
+def test_stream_pool_more_contexts_than_slots_and_reuse():
+    """The per-device stream pool (engine.hip): eight slots of streams made in a fixed order, taken by zk_ctx_create and given back
+    by zk_ctx_destroy; contexts beyond the slots make their own streams.  Twelve contexts at once, then again after all were
+    destroyed: every context commits the same column to the same point, alone and from twelve threads."""
+    k = 12
+    n = 1 << k
+    col = _column(n, 5)
+    want = None
+    for round_ in range(2):
+        engs = [zk.Engine(0)]
+        engs[0].srs_setup(k)
+        for _ in range(11):
+            engs.append(zk.Engine(0, share_with=engs[0]))
+        polys = [e.poly(n, col) for e in engs]
+        got = [e.commit(p, E.ZK_BASIS_LAGRANGE).copy() for e, p in zip(engs, polys)]
+        want = got[0] if want is None else want
+        assert all(np.array_equal(g, want) for g in got)
+        out = [None] * len(engs)
+
+        def work(i):
+            for _ in range(30):
+                out[i] = engs[i].commit(polys[i], E.ZK_BASIS_LAGRANGE).copy()
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(engs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert all(np.array_equal(o, want) for o in out)
+        for e in engs[::-1]:
+            e.close()
+
+
+def test_activity_hold_option_same_bytes():
+    """ZK_OPT_ACTIVITY_HOLD: a context inside zk_prove counts as active for the whole call (default) or by its stamps alone (1) —
+    placement only: two pipelines proving side by side give the same bytes under either rule."""
+    from webauthn_halo2_amd import batch, circuit
+
+    p = circuit.CircuitParams(degree=10, num_advice=3, num_lookup_advice=2, num_fixed=1, lookup_bits=8)
+    fixed, copies = batch.structure(p)
+    wit = batch.synthesize_jobs(p, [0, 1, 2, 3], processes=1)
+    proofs = {}
+    for rule in (0, 1):
+        def factory(dev, rule=rule):
+            e = zk.Engine(dev)
+            e.set_option(E.ZK_OPT_ACTIVITY_HOLD, rule)
+            return e
+
+        factory.configure = lambda e, rule=rule: e.set_option(E.ZK_OPT_ACTIVITY_HOLD, rule)
+        pipes = [batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True)]
+        pipes.append(batch.Pipeline(0, p, fixed, copies, engine_factory=factory, deterministic_seeds=True, share_srs_with=pipes[0]))
+        for q, pl in enumerate(pipes):
+            for j in (0, 1, 2, 3)[q::2]:
+                pl.load(j, wit[j])
+        proofs[rule] = batch.run(pipes, [0, 1, 2, 3])
+        for pl in pipes[::-1]:
+            pl.close()
+    assert proofs[0] == proofs[1] and len(set(proofs[0].values())) == 4
+    with pytest.raises(zk.ZkError):
+        zk.Engine(0).set_option(E.ZK_OPT_ACTIVITY_HOLD, 2)
