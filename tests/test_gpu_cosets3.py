@@ -94,3 +94,15 @@ def test_lock_step_batches_take_the_route_too(shape):
         assert want is None or got == want, order
         want = got
         eng.close()
+
+
+@pytest.mark.parametrize("shape,seed", [((8, 3, 2, 2, 5), 1234), ((9, 4, 1, 1, 6), 99), ((10, 4, 1, 1, 7), 5)])
+def test_adversarial_layouts_on_three_cosets(shape, seed):
+    """The layouts this repo's generator never produces (tests/adversarial_layout.py: overlapping gates on irregular rows, long copy
+    cycles, constants on every row, an all-zero gate column) through the three-coset route, against the plain-Python oracle."""
+    eng = zk.Engine(0)
+    eng.set_option(E.ZK_OPT_QUOTIENT_DOMAIN, 2)
+    try:
+        t.test_adversarial_layout_matches_plain_python_oracle(eng, shape, seed)  # (the test's body: keygen, both transcripts, verify)
+    finally:
+        eng.close()
