@@ -7,7 +7,7 @@ import webauthn_halo2_amd as zk
 from webauthn_halo2_amd import engine as E
 
 eng = zk.Engine(0)
-for k in (21, 19):
+for k in [int(x) for x in os.environ.get("KS", "21,19").split(",")]:
     n = 1 << k
     a = np.frombuffer(np.random.default_rng(1).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
     a[:, 3] &= 0x0FFFFFFFFFFFFFFF

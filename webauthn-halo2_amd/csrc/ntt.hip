@@ -44,8 +44,13 @@ namespace zk {
 #ifndef ZK_NTT_PAD
 #define ZK_NTT_PAD 1
 #endif
-static constexpr int NTT_TILE_LOG = ZK_NTT_TILE_LOG;      // 512 elements x 36 B = 18 KiB of LDS: ~7 workgroups share a CU
-static constexpr int NTT_THREADS = 1 << (NTT_TILE_LOG - 2);  // one radix-4 butterfly group per lane and round
+// The tile (elements a workgroup holds in LDS) is a template parameter of the pass kernel since round 6: 2^9 (512 elements x 36 B =
+// 18 KiB of LDS, 128 lanes: ~7 workgroups share a CU), 2^10 and 2^11 (72 KiB, 512 lanes: two workgroups per CU).  The larger tiles
+// exist for TWO-PASS plans of the mid sizes (ntt_run): a pass costs a load / inter-pass twiddle product / reduce / store round
+// per element whatever its radix, and radix 2^9 / 2^10 passes need tiles of at least two 32-byte columns to keep the global
+// accesses 64 bytes wide.  ZK_NTT_TILE_LOG (build-time) pins one tile for every size (the round-3 tuning variants).
+static constexpr int NTT_TILE_LOG = ZK_NTT_TILE_LOG;      // the default tile
+static constexpr int NTT_TILE_LOG_MAX = 11;
 typedef Fe29<FrParams> Fr29;
 
 struct NttPassArgs {
@@ -189,14 +194,16 @@ __device__ __forceinline__ void round0(Fr29& e0, Fr29& e1, Fr29& e2, Fr29& e3, c
 //   only r < R/4 is loaded, into a compact array; positions brev(r) = 0 mod 4 are the only non-zero ones, so stages 0 and 1
 //   (groups of four adjacent positions) just copy x to all four — round 0 is skipped, round 1 reads the compact array.
 enum { NTT_GENERAL = 0, NTT_FOLD = 1, NTT_ZQ = 2 };
-template <uint32_t KIN, int MODE>
+template <uint32_t KIN, int MODE, int TL = NTT_TILE_LOG>
 #ifndef ZK_NTT_WAVES
 #define ZK_NTT_WAVES 0
 #endif
 #if ZK_NTT_WAVES
 __attribute__((amdgpu_waves_per_eu(ZK_NTT_WAVES, ZK_NTT_WAVES)))
 #endif
-__global__ __launch_bounds__(NTT_THREADS, ZK_NTT_MINW) void ntt_pass_kernel(const NttPassArgs a) {
+__global__ __launch_bounds__(1 << (TL - 2), ZK_NTT_MINW) void ntt_pass_kernel(const NttPassArgs a) {
+    constexpr uint32_t NTT_THREADS = 1u << (TL - 2);  // one radix-4 butterfly group per lane and round
+    constexpr int NTT_TILE_LOG = TL;                  // (shadows the file-level default inside the kernel)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Fr* __restrict__ vin = a.in[blockIdx.y];
     Fr* __restrict__ vout = a.out[blockIdx.y];
@@ -495,8 +502,28 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         dsts[b] = job.batch ? job.dsts[b] : job.dst;
     }
     uint32_t bits[8];
-    uint32_t max_r = job.max_log_r ? job.max_log_r : 7;
-    if (max_r > (uint32_t)NTT_TILE_LOG) max_r = NTT_TILE_LOG;
+    // The plan: largest radix and tile by transform size.  Measured (tools/ntt_sweep.py, one vector, ms; 3 passes of 2^7 on the 2^9
+    // tile -> the plan below): 2^15 0.044 -> 0.032, 2^16 0.047 -> 0.034 (two passes of 2^8, tile 2^9); 2^17 0.052 -> 0.043, 2^18 0.076 ->
+    // 0.051 (two passes of 2^9, tile 2^10); 2^19 0.103 -> 0.079, 2^20 0.174 -> 0.158 (two passes of 2^10, tile 2^11); 2^21 stays at
+    // three passes of 2^7 (two passes of 2^11 / 2^10 on the 2^11 tile: 0.37 against 0.30 ms — one 32-byte column per tile row).
+    // An explicit radix (ZK_OPT_NTT_MAX_RADIX_LOG2) takes the smallest tile that holds it; a build that pins ZK_NTT_TILE_LOG keeps
+    // its tile and the old default radix for every size.
+    uint32_t tl = NTT_TILE_LOG, max_r = 7;
+    if (job.max_log_r) {
+        max_r = job.max_log_r;
+        if (ZK_NTT_TILE_LOG == 9) tl = max_r < 9 ? 9 : max_r > (uint32_t)NTT_TILE_LOG_MAX ? NTT_TILE_LOG_MAX : max_r;
+    } else if (ZK_NTT_TILE_LOG == 9) {
+        if (log_n <= 16) {
+            max_r = 8;
+        } else if (log_n <= 18) {
+            max_r = 9;
+            tl = 10;
+        } else if (log_n <= 20) {
+            max_r = 10;
+            tl = 11;
+        }
+    }
+    if (max_r > tl) max_r = tl;
     const int np = ntt_plan(log_n, max_r, bits);
     if (np == 0) {  // N == 1
         for (uint32_t b = 0; b < batch; b++)
@@ -541,7 +568,7 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         a.log_n = log_n;
         a.log_r = bits[p];
         a.log_ns = log_ns;
-        uint32_t log_t = NTT_TILE_LOG - a.log_r;
+        uint32_t log_t = tl - a.log_r;
         if (log_t > log_n - a.log_r) log_t = log_n - a.log_r;
         a.log_t = log_t;
         a.inverse = job.inverse;
@@ -551,7 +578,7 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         // the last of several passes takes its conversion (and a uniform output scaling) from tw_last: no final product
         const bool fold = FOLD_ON && np >= 2 && p == np - 1 && job.tw_last != nullptr && (!job.has_post || job.tw_last_has_post);
         // the first pass of a transform over an input that is >= 3/4 zeros skips its first two stages
-        const bool zq = ZQ_ON && p == 0 && (uint64_t)job.n_in * 4 <= N && a.log_r >= 4 && a.log_r + log_t == (uint32_t)NTT_TILE_LOG;
+        const bool zq = ZQ_ON && p == 0 && (uint64_t)job.n_in * 4 <= N && a.log_r >= 4 && a.log_r + log_t == tl;
         a.has_pre = (p == 0) ? job.has_pre : 0;
         a.has_post = (p == np - 1 && !fold) ? job.has_post : 0;
         for (int i = 0; i < 3; i++) {
@@ -561,14 +588,23 @@ hipError_t ntt_run(const NttJob& job, hipStream_t st) {
         const uint32_t blocks = N >> (a.log_r + a.log_t);
         const size_t row_bytes = ZK_NTT_SOA ? ((size_t)36 << a.log_t) : (((size_t)9 << a.log_t) + ZK_NTT_PAD) * 4;
         const size_t lds = (row_bytes << a.log_r) + ((size_t)36 << a.log_r) / 2 + (zq ? (row_bytes << (a.log_r - 2)) : 0);
-        if (zq)
-            hipLaunchKernelGGL((ntt_pass_kernel<32, NTT_ZQ>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
-        else if (p == 0)
-            hipLaunchKernelGGL((ntt_pass_kernel<32, NTT_GENERAL>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
-        else if (fold)
-            hipLaunchKernelGGL((ntt_pass_kernel<6, NTT_FOLD>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
-        else
-            hipLaunchKernelGGL((ntt_pass_kernel<6, NTT_GENERAL>), dim3(blocks, batch), dim3(NTT_THREADS), lds, st, a);
+        const int mode = zq ? 0 : p == 0 ? 1 : fold ? 2 : 3;
+#define ZK_NTT_LAUNCH(TLV)                                                                                                             \
+    do {                                                                                                                               \
+        const dim3 grid(blocks, batch), blk(1u << ((TLV) - 2));                                                                        \
+        if (mode == 0) hipLaunchKernelGGL((ntt_pass_kernel<32, NTT_ZQ, TLV>), grid, blk, lds, st, a);                                  \
+        else if (mode == 1) hipLaunchKernelGGL((ntt_pass_kernel<32, NTT_GENERAL, TLV>), grid, blk, lds, st, a);                        \
+        else if (mode == 2) hipLaunchKernelGGL((ntt_pass_kernel<6, NTT_FOLD, TLV>), grid, blk, lds, st, a);                            \
+        else hipLaunchKernelGGL((ntt_pass_kernel<6, NTT_GENERAL, TLV>), grid, blk, lds, st, a);                                        \
+    } while (0)
+#if ZK_NTT_TILE_LOG == 9
+        if (tl == 11) ZK_NTT_LAUNCH(11);
+        else if (tl == 10) ZK_NTT_LAUNCH(10);
+        else ZK_NTT_LAUNCH(9);
+#else
+        ZK_NTT_LAUNCH(ZK_NTT_TILE_LOG);
+#endif
+#undef ZK_NTT_LAUNCH
         for (uint32_t b = 0; b < batch; b++) cur_in[b] = a.out[b];
         which ^= 1;
         log_ns += bits[p];
