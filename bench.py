@@ -339,7 +339,7 @@ def kernel_rooflines(eng, pl, wl):
     p, ext = eng.poly(n, col), eng.poly(N)
     for _ in range(2):
         eng.lagrange_to_coeff(p)
-    row("ntt_pass_kernel x3", "best_fft 2^19 inverse (lagrange_to_coeff)", 64.0 * n, eng.last_ms(E.ZK_T_NTT))
+    row("ntt_pass_kernel x2", "best_fft 2^19 inverse (lagrange_to_coeff): two passes of 2^10 / 2^9 on 2 048-element tiles", 64.0 * n, eng.last_ms(E.ZK_T_NTT))
     for _ in range(2):
         eng.coeff_to_extended(p, ext)
     row("ntt_pass_kernel x3", "coeff_to_extended 2^19 -> 2^21 (reads n, writes 4n)", 32.0 * (n + N), eng.last_ms(E.ZK_T_NTT))
