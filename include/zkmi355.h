@@ -138,7 +138,10 @@ int zk_sync(zk_ctx* ctx);                 /* hipStreamSynchronize on the context
 #define ZK_OPT_ACTIVITY_HOLD 14      /* how a context inside zk_prove / zk_prove_batch counts for the automatic stream rules of the OTHER contexts
                                         of its device (ZK_OPT_MSM_TAIL_STREAM, ZK_OPT_XFORM_STREAM): 0 (default) active for the whole call — its
                                         quotient / evaluation / multi-open phases enqueue no MSM pass for longer than the 4 ms window under load,
-                                        and the count dipped to two or three several times per proof; 1 = by its stamps alone (round 5's rule) */
+                                        and the count dipped to two or three several times per proof; 1 = by its stamps alone (round 5's rule);
+                                        2 = this context counts as active from now on, whatever entry points it uses, until the option is set
+                                        to 0 or 1 — for the worker contexts of a host that drives the phase-level ABI (its calls between two MSM
+                                        passes are invisible to the 4 ms window) */
 int zk_ctx_set_option(zk_ctx* ctx, int option, int64_t value);
 
 /* ---- fine-grained drop-in seam (host buffers in, host buffers out) --------

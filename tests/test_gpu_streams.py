@@ -218,4 +218,25 @@ def test_activity_hold_option_same_bytes():
             pl.close()
     assert proofs[0] == proofs[1] and len(set(proofs[0].values())) == 4
     with pytest.raises(zk.ZkError):
-        zk.Engine(0).set_option(E.ZK_OPT_ACTIVITY_HOLD, 2)
+        zk.Engine(0).set_option(E.ZK_OPT_ACTIVITY_HOLD, 3)
+    # 2: a context held active by its host (phase-level ABI): three such contexts, idle, and a fourth one's lone commits take the
+    # loaded regime (tails on the main stream); released again, they go back to the side stream
+    k = 12
+    n = 1 << k
+    engs = [zk.Engine(0)]
+    engs[0].srs_setup(k)
+    for _ in range(3):
+        engs.append(zk.Engine(0, share_with=engs[0]))
+    poly = engs[3].poly(n, _column(n, 3))
+    engs[3].commit(poly, E.ZK_BASIS_LAGRANGE)
+    time.sleep(0.02)
+    for value, on_main in ((2, 10), (0, 0)):
+        for e in engs[:3]:
+            e.set_option(E.ZK_OPT_ACTIVITY_HOLD, value)
+        time.sleep(0.02)  # (a context that lets go counts as just-active for the 4 ms window)
+        engs[3].timer_reset()
+        for _ in range(10):
+            engs[3].commit(poly, E.ZK_BASIS_LAGRANGE)
+        assert engs[3].timer_stats(E.ZK_T_MSM_TAIL_MAIN)[1] == on_main, value
+    for e in engs[::-1]:
+        e.close()

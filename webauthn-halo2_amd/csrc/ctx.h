@@ -73,7 +73,8 @@ struct zk_ctx {
     uint32_t opt_tail_main_above = 0;  // ZK_OPT_MSM_TAIL_MAIN_ABOVE: auto mode puts the tails on the main stream with MORE than this many contexts active on the device (0 = the measured default, 2)
     uint32_t opt_batch_pass_cols = 0;  // ZK_OPT_BATCH_PASS_COLUMNS: columns per MSM pass of a lock-step batch (0 = max(min(2 B, 8), the single prover's pass width))
     uint32_t msm_min_cols = 0;         // the lanes' fixed-base workspaces take at least this many columns per pass (raised by zk_prove_batch, never lowered: the wider workspaces are kept)
-    uint32_t opt_no_activity_hold = 0;  // ZK_OPT_ACTIVITY_HOLD
+    uint32_t opt_no_activity_hold = 0;  // ZK_OPT_ACTIVITY_HOLD = 1
+    bool opt_activity_pinned = false;   // ZK_OPT_ACTIVITY_HOLD = 2: active until the option is changed
     bool act_held = false;         // inside a whole-proof call: the slot counts as active whatever its last stamp (ctx_activity_hold)
     int act_slot = -1;             // this context's slot in its device's activity table (engine.hip ctx_activity_*)
     // The context's TAIL stream (round 4: one, shared by the lanes; rounds 2-3 had one per lane).  Where a pass's reduction tail

@@ -351,6 +351,7 @@ int ctx_activity_touch(zk_ctx* c) {
 // a whole-proof call begins / ends on this context (prover.hip ProveQuiesce)
 void ctx_activity_hold(zk_ctx* c, bool on) {
     if (on && c->opt_no_activity_hold) return;  // ZK_OPT_ACTIVITY_HOLD = 1: round 5's rule (stamps only)
+    if (!on && c->opt_activity_pinned) return;  // ZK_OPT_ACTIVITY_HOLD = 2: the host holds this context active itself
     c->act_held = on;
     if (c->act_slot < 0 || c->device < 0 || c->device >= ACT_DEVICES) return;
     g_act_ts[c->device][c->act_slot].store(on ? ACT_HELD : act_now());
@@ -833,8 +834,12 @@ ZK_API(zk_ctx_set_option, (zk_ctx* c, int option, int64_t value), (c, option, va
             c->opt_gp_batch_invert = value ? 1 : 0;
             return ZK_OK;
         case ZK_OPT_ACTIVITY_HOLD:
-            if (value > 1) return ZK_EINVAL;
-            c->opt_no_activity_hold = (uint32_t)value;
+            if (value > 2) return ZK_EINVAL;
+            c->opt_no_activity_hold = value == 1;
+            // 2: held from now on, whatever the entry points used (a phase-level host's worker context); 0 / 1 let go of such a hold
+            c->opt_activity_pinned = value == 2;
+            if (!c->act_held || value != 2) ctx_activity_hold(c, false);
+            if (value == 2) ctx_activity_hold(c, true);
             return ZK_OK;
         case ZK_OPT_QUOTIENT_DOMAIN:
             if (value > 2) return ZK_EINVAL;
