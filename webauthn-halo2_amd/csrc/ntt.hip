@@ -45,7 +45,8 @@ namespace zk {
 #define ZK_NTT_PAD 1
 #endif
 // The tile (elements a workgroup holds in LDS) is a template parameter of the pass kernel since round 6: 2^9 (512 elements x 36 B =
-// 18 KiB of LDS, 128 lanes: ~7 workgroups share a CU), 2^10 and 2^11 (72 KiB, 512 lanes: two workgroups per CU).  The larger tiles
+// 18 KiB of LDS, 128 lanes: ~7 workgroups share a CU), 2^10 (256 lanes, ~48 KiB with the in-tile twiddles) and 2^11 (512 lanes, ~96 KiB:
+// one workgroup per CU — gfx950 gives a workgroup up to 160 KiB).  The larger tiles
 // exist for TWO-PASS plans of the mid sizes (ntt_run): a pass costs a load / inter-pass twiddle product / reduce / store round
 // per element whatever its radix, and radix 2^9 / 2^10 passes need tiles of at least two 32-byte columns to keep the global
 // accesses 64 bytes wide.  ZK_NTT_TILE_LOG (build-time) pins one tile for every size (the round-3 tuning variants).
